@@ -1,0 +1,260 @@
+// api.hip - host side of the C ABI declared in include/hgs_rast.h: buffer carving and the
+// launch sequences.  No allocation, no synchronisation, no global state.
+//
+// Forward launch chain (one stream, 1 memset + 9 launches, no host round trip):
+//   memset tile_count -> preprocess_fwd -> scan -> fill -> sort_{huge,large,medium,small}
+//   -> render_fwd -> (async copy of hgs_status to pinned host memory)
+// Backward: render_bwd (bucket-parallel) -> preprocess_bwd.
+#include "hgs_common.h"
+
+// Single translation unit: the kernels are included so the launches below bind directly.
+#include "preprocess.hip"
+#include "binning.hip"
+#include "render_fwd.hip"
+#include "render_bwd.hip"
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+
+struct GeomCarve {
+  size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
+      tile_wgstart, tile_maxcontrib, status, total;
+};
+
+inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
+
+GeomCarve carve_geom(int P, int H, int W) {
+  const size_t T = (size_t)grid_dim(W) * grid_dim(H);
+  const size_t nblk = ((size_t)P + HGS_BLOCK - 1) / HGS_BLOCK;
+  GeomCarve c;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = hgs_align_up(off + bytes, ALIGN); return o; };
+  c.geom = take((size_t)P * sizeof(GeomRec));
+  c.block_sums = take(nblk * 4);
+  c.block_base = take(nblk * 4);
+  c.tile_count = take(T * 4);
+  c.tile_start = take((T + 1) * 4);
+  c.tile_order = take(T * 4);
+  c.tile_bstart = take((T + 1) * 4);
+  c.tile_wgstart = take((T + 1) * 4);
+  c.tile_maxcontrib = take(T * 4);
+  c.status = take(sizeof(hgs_status));
+  c.total = off;
+  return c;
+}
+
+struct BinCarve { size_t keys, recs, bstate, total; };
+
+BinCarve carve_bin(int64_t cap) {
+  BinCarve c;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = hgs_align_up(off + bytes, ALIGN); return o; };
+  const size_t C = (size_t)(cap > 0 ? cap : 0);
+  c.keys = take(C * 8);
+  c.recs = take(C * sizeof(SortRec));
+  c.bstate = take(((C + HGS_BUCKET - 1) / HGS_BUCKET) * HGS_BSTATE_FLOATS * sizeof(float));
+  c.total = off;
+  return c;
+}
+
+Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_t cap) {
+  const GeomCarve g = carve_geom(P, H, W);
+  const BinCarve b = carve_bin(cap);
+  char* gp = static_cast<char*>(geom);
+  char* bp = static_cast<char*>(bin);
+  Layout L;
+  L.geom = reinterpret_cast<GeomRec*>(gp + g.geom);
+  L.block_sums = reinterpret_cast<uint32_t*>(gp + g.block_sums);
+  L.block_base = reinterpret_cast<uint32_t*>(gp + g.block_base);
+  L.tile_count = reinterpret_cast<uint32_t*>(gp + g.tile_count);
+  L.tile_start = reinterpret_cast<uint32_t*>(gp + g.tile_start);
+  L.tile_order = reinterpret_cast<uint32_t*>(gp + g.tile_order);
+  L.tile_bstart = reinterpret_cast<uint32_t*>(gp + g.tile_bstart);
+  L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
+  L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
+  L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
+  L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
+  L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
+  L.n_contrib = static_cast<uint32_t*>(img);
+  return L;
+}
+
+View make_view(const hgs_settings* s, int P, int M, int64_t cap) {
+  View v;
+  v.viewmatrix = s->viewmatrix;
+  v.projmatrix = s->projmatrix;
+  v.campos = s->campos;
+  v.bg = s->bg;
+  v.tanfovx = s->tanfovx;
+  v.tanfovy = s->tanfovy;
+  v.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
+  v.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
+  v.scale_modifier = s->scale_modifier;
+  v.W = s->image_width;
+  v.H = s->image_height;
+  v.grid_x = grid_dim(v.W);
+  v.grid_y = grid_dim(v.H);
+  v.T = v.grid_x * v.grid_y;
+  v.P = P;
+  v.M = M;
+  v.D = s->sh_degree;
+  v.nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  v.entry_capacity = (uint32_t)(cap < 0 ? 0 : (cap > 0xffffffffll ? 0xffffffffll : cap));
+  return v;
+}
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? HGS_OK : -(1000 + (int)e); }
+
+#define HGS_LAUNCH_CHECK()                       \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return hip_rc(e__);   \
+  } while (0)
+
+bool settings_ok(const hgs_settings* s) {
+  return s && s->image_height > 0 && s->image_width > 0 && s->bg && s->viewmatrix &&
+         s->projmatrix && s->campos && s->sh_degree >= 0 && s->sh_degree <= 3 &&
+         s->image_width <= 16 * 65535 && s->image_height <= 16 * 65535;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hgs_abi_version(void) { return 1; }
+
+size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
+  if (P < 0 || H <= 0 || W <= 0) return 0;
+  return carve_geom(P, H, W).total;
+}
+size_t hgs_bin_bytes(int64_t entry_capacity) { return carve_bin(entry_capacity).total; }
+size_t hgs_img_bytes(int32_t H, int32_t W) {
+  if (H <= 0 || W <= 0) return 0;
+  return hgs_align_up((size_t)H * W * 4, ALIGN);
+}
+size_t hgs_bwd_scratch_bytes(int64_t R) {
+  return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_ROW_FLOATS * sizeof(float), ALIGN);
+}
+
+int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3D,
+                const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, const float* rotations, const float* cov3D_precomp,
+                float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                void* geom, void* bin, int64_t entry_capacity, void* img,
+                int32_t store_bwd_state, hgs_status* status_host, void* stream_) {
+  if (!settings_ok(s) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
+      entry_capacity < 0)
+    return HGS_EINVAL;
+  if (P > 0) {
+    if (!means3D || !opacities || !radii) return HGS_EINVAL;
+    if ((shs != nullptr) == (colors_precomp != nullptr)) return HGS_ESHAPE;
+    const bool has_sr = scales != nullptr && rotations != nullptr;
+    if ((scales != nullptr) != (rotations != nullptr)) return HGS_ESHAPE;
+    if (has_sr == (cov3D_precomp != nullptr)) return HGS_ESHAPE;
+    if (shs && M < (s->sh_degree + 1) * (s->sh_degree + 1)) return HGS_ESHAPE;
+    if (entry_capacity > 0 && !bin) return HGS_EINVAL;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const View v = make_view(s, P, M, entry_capacity);
+  const Layout L = make_layout(geom, bin, img, P, v.H, v.W, entry_capacity);
+  hgs_status* status_dev =
+      reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(P, v.H, v.W).status);
+
+  hipError_t e = hipMemsetAsync(L.tile_count, 0, (size_t)v.T * 4, stream);
+  if (e != hipSuccess) return hip_rc(e);
+  if (v.nblk > 0) {
+    hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
+                       means3D, shs, colors_precomp, opacities, scales, rotations,
+                       cov3D_precomp, radii);
+    HGS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev);
+  HGS_LAUNCH_CHECK();
+  if (v.nblk > 0 && entry_capacity > 0) {
+    hipLaunchKernelGGL(hgs_k_fill, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, status_dev);
+    HGS_LAUNCH_CHECK();
+    // tiles are ordered heavy-first, so a class with more than LO entries per tile can only
+    // occupy the first capacity/LO positions of tile_order
+    auto class_grid = [&](int64_t lo) {
+      const int64_t g = entry_capacity / lo + 1;
+      return (unsigned)(g < v.T ? g : v.T);
+    };
+    hipLaunchKernelGGL(hgs_k_sort_huge, dim3(class_grid(16384)), dim3(1024), 0, stream, v, L, status_dev);
+    HGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
+    HGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hgs_k_sort_medium, dim3(class_grid(1024)), dim3(512), 0, stream, v, L, status_dev);
+    HGS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hgs_k_sort_small, dim3(v.T), dim3(256), 0, stream, v, L, status_dev);
+    HGS_LAUNCH_CHECK();
+  }
+  if (store_bwd_state)
+    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T), dim3(256), 0, stream, v, L, status_dev,
+                       out_color, out_depth, out_alpha);
+  else
+    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T), dim3(256), 0, stream, v, L,
+                       status_dev, out_color, out_depth, out_alpha);
+  HGS_LAUNCH_CHECK();
+  if (status_host) {
+    e = hipMemcpyAsync(status_host, status_dev, sizeof(hgs_status), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  return HGS_OK;
+}
+
+int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* opacities,
+                 const float* scales, const float* rotations, const float* cov3D_precomp,
+                 const int32_t* radii, const float* out_color, const float* out_depth,
+                 const float* out_alpha, const float* dL_dout_color,
+                 const float* dL_dout_depth, const float* dL_dout_alpha, const void* geom,
+                 const void* bin, const void* img, const hgs_status* status,
+                 void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                 float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                 float* dL_drotations, float* dL_dcov3D_precomp, void* stream_) {
+  (void)opacities; (void)radii;
+  if (!settings_ok(s) || P < 0 || !status || !geom || !img) return HGS_EINVAL;
+  if (status->overflow) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!means3D || !out_color || !out_depth || !out_alpha) return HGS_EINVAL;
+  if ((shs != nullptr) == (colors_precomp != nullptr)) return HGS_ESHAPE;
+  if ((scales != nullptr) != (rotations != nullptr)) return HGS_ESHAPE;
+  if ((scales != nullptr) == (cov3D_precomp != nullptr)) return HGS_ESHAPE;
+  if (shs && !dL_dshs) return HGS_EINVAL;
+  if (status->num_rendered > 0 && (!bin || !bwd_scratch)) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  // entry_capacity only fixes the carve offsets of keys/recs/bstate: the caller must pass
+  // the same bin buffer, and the capacity travels in reserved[0] of the status block.
+  const int64_t cap = (int64_t)status->reserved[0];
+  const View v = make_view(s, P, M, cap);
+  const Layout L = make_layout(const_cast<void*>(geom), const_cast<void*>(bin),
+                               const_cast<void*>(img), P, v.H, v.W, cap);
+  float* rows = static_cast<float*>(bwd_scratch);
+  if (status->bwd_groups > 0) {
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(status->bwd_groups), dim3(256), 0, stream, v, L,
+                       out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
+                       dL_dout_alpha, rows);
+    HGS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(hgs_k_preprocess_bwd, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, rows,
+                     means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans3D,
+                     dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales,
+                     dL_drotations, dL_dcov3D_precomp);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+int hgs_mark_visible(const hgs_settings* s, int32_t P, const float* means3D, uint8_t* present,
+                     void* stream_) {
+  if (!s || !s->viewmatrix || P < 0) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!means3D || !present) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(hgs_k_mark_visible, dim3((P + HGS_BLOCK - 1) / HGS_BLOCK), dim3(HGS_BLOCK),
+                     0, stream, s->viewmatrix, (int)P, means3D, present);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+}  // extern "C"

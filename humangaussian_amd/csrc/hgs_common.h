@@ -1,0 +1,133 @@
+// hgs_common.h - shared device-side definitions for libhgs_rast (gfx950 / CDNA4 only).
+//
+// Data layout in HBM (one render call = one view):
+//
+//   geom buffer   (saved for backward)        bin buffer (sized by entry_capacity C)
+//   ---------------------------------         --------------------------------------------
+//   GeomRec  geom[P]            64 B each     uint64  keys[C]     (depth_bits<<32 | idx)
+//   uint32   block_sums[NBLK]                 SortRec recs[C]     48 B, depth-sorted per tile
+//   uint32   block_base[NBLK]                 float   bstate[C/64][6][256]  per-bucket pixel state
+//   uint32   tile_count[T]    (fill cursor)
+//   uint32   tile_start[T+1]                  img buffer:  uint32 n_contrib[H*W]
+//   uint32   tile_order[T]    (heavy first)
+//   uint32   tile_bstart[T+1] (bucket-state prefix)        bwd scratch: float grad_rows[R][12]
+//   uint32   tile_wgstart[T+1](backward WG prefix)
+//   uint32   tile_maxcontrib[T]
+//
+// wave = 64 lanes everywhere; a "bucket" is 64 consecutive entries of one tile's list.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hgs_rast.h"
+
+#define HGS_TILE 16
+#define HGS_TILE_PIX 256
+#define HGS_BLOCK 256          // Gaussians per preprocess / fill workgroup
+#define HGS_BUCKET 64          // entries per backward bucket (= one wave)
+#define HGS_BWD_WAVES 4        // buckets per backward workgroup
+#define HGS_NEAR_Z 0.2f
+#define HGS_ALPHA_MIN (1.0f / 255.0f)
+#define HGS_ALPHA_MAX 0.99f
+#define HGS_T_EPS 0.0001f
+#define HGS_BSTATE_FLOATS (6 * HGS_TILE_PIX)   // T, C0, C1, C2, D, W per pixel
+#define HGS_ROW_FLOATS 12                       // grad row per entry (10 used)
+
+struct __attribute__((aligned(16))) GeomRec {   // 64 B, one per Gaussian
+  float mx, my;         // pixel-space mean
+  float ca, cb, cc;     // conic (inverse 2D covariance)
+  float op;             // opacity
+  float r, g, b;        // view-dependent colour (after +0.5, clamp)
+  float depth;          // view-space z
+  uint32_t rect_lo;     // minx | miny << 16   (tile units)
+  uint32_t rect_hi;     // maxx | maxy << 16   (exclusive)
+  uint32_t offset;      // exclusive prefix of tiles_touched = first entry id
+  int32_t radius;       // 0 => culled
+  uint32_t clamped;     // bit c set: colour channel c was clamped at 0
+  uint32_t flags;       // bit0: t.x/t.z frustum-clamped, bit1: t.y/t.z clamped
+};
+
+struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian) entry
+  float mx, my, ca, cb, cc, op, r, g, b, depth;
+  uint32_t entry;       // entry id = geom.offset + position of the tile in the rect
+  uint32_t idx;         // Gaussian index
+};
+
+struct Layout {          // pointers carved out of the caller's buffers
+  GeomRec* geom;
+  uint32_t* block_sums;
+  uint32_t* block_base;
+  uint32_t* tile_count;
+  uint32_t* tile_start;
+  uint32_t* tile_order;
+  uint32_t* tile_bstart;
+  uint32_t* tile_wgstart;
+  uint32_t* tile_maxcontrib;
+  unsigned long long* keys;
+  SortRec* recs;
+  float* bstate;
+  uint32_t* n_contrib;
+};
+
+struct View {            // per-call constants, passed by value to every kernel
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* campos;
+  const float* bg;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  int32_t W, H, grid_x, grid_y, T;
+  int32_t P, M, D, nblk;
+  uint32_t entry_capacity;
+};
+
+static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// pixel of a forward-render thread inside its tile: wave w owns the 8x8 block
+// (w&1, w>>1); lane l is (l&7, l>>3) inside it.
+__device__ __forceinline__ void hgs_fwd_thread_pixel(int tid, int& lx, int& ly) {
+  const int w = tid >> 6, l = tid & 63;
+  lx = ((w & 1) << 3) | (l & 7);
+  ly = ((w >> 1) << 3) | (l >> 3);
+}
+
+// The one place alpha is evaluated, shared by forward and backward so both take the
+// identical instruction sequence (skip decisions must agree).  Returns false when the
+// pair is skipped (power > 0 or alpha < 1/255).
+__device__ __forceinline__ bool hgs_eval_alpha(float dx, float dy, float ca, float cb,
+                                               float cc, float op, float& G, float& alpha) {
+  const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+  G = __expf(power);
+  alpha = fminf(HGS_ALPHA_MAX, op * G);
+  return (power <= 0.0f) && (alpha >= HGS_ALPHA_MIN);
+}
+
+__device__ __forceinline__ uint32_t hgs_wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan over the workgroup (NT threads, multiple of 64).  `wtot` needs NT/64
+// entries of LDS.  Returns the exclusive prefix; `total` = workgroup sum.
+template <int NT>
+__device__ __forceinline__ uint32_t hgs_block_excl_scan(uint32_t v, uint32_t* wtot,
+                                                        uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = hgs_wave_incl_scan(v);
+  __syncthreads();                 // protect wtot from a previous use
+  if (lane == 63) wtot[w] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) {
+    const uint32_t t = wtot[k];
+    if (k < w) base += t;
+    tot += t;
+  }
+  total = tot;
+  return base + incl - v;
+}

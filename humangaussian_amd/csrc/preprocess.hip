@@ -1,0 +1,504 @@
+// preprocess.hip - per-Gaussian forward (stage F1 of SURVEY.md 2.3(B)) and its backward
+// (B2 + B3 fused, plus the deterministic gather of the per-entry gradient rows).
+//
+// Replaces upstream's preprocessCUDA / computeCov2DCUDA / computeCov3D / computeColorFromSH
+// (un-vendored; behaviour specified in SURVEY.md Appendix A.2 / A.6).  The arithmetic is
+// written in the exact left-to-right order of oracle/gs_oracle.py::preprocess and the
+// library is built with -ffp-contract=off, so radii / rects match the oracle bit-for-bit.
+//
+// Roofline: pure streaming, HBM-bound.  Forward reads 44+12*M' B and writes 64+4 B per
+// Gaussian (M' = active SH coefficients); backward reads 44+12*M' + 64 + 48*tiles_touched
+// and writes 56+12*M B.
+#include "hgs_common.h"
+
+namespace {
+
+__device__ __constant__ const float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ const float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f,
+                                                0.31539156525252005f, -1.0925484305920792f,
+                                                0.5462742152960396f};
+__device__ __constant__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
+                                                -0.4570457994644658f, 0.3731763325901154f,
+                                                -0.4570457994644658f, 1.445305721320277f,
+                                                -0.5900435899266435f};
+
+struct Cov3 { float c0, c1, c2, c3, c4, c5; };   // xx xy xz yy yz zz
+
+struct RotScale {
+  float R00, R01, R02, R10, R11, R12, R20, R21, R22;
+  float sx, sy, sz;
+};
+
+__device__ __forceinline__ RotScale make_rotscale(const float* __restrict__ scales,
+                                                  const float* __restrict__ rots, int i,
+                                                  float mod) {
+  RotScale o;
+  o.sx = mod * scales[3 * i + 0];
+  o.sy = mod * scales[3 * i + 1];
+  o.sz = mod * scales[3 * i + 2];
+  const float4 q = reinterpret_cast<const float4*>(rots)[i];
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  o.R00 = 1.0f - 2.0f * (y * y + z * z);
+  o.R01 = 2.0f * (x * y - r * z);
+  o.R02 = 2.0f * (x * z + r * y);
+  o.R10 = 2.0f * (x * y + r * z);
+  o.R11 = 1.0f - 2.0f * (x * x + z * z);
+  o.R12 = 2.0f * (y * z - r * x);
+  o.R20 = 2.0f * (x * z - r * y);
+  o.R21 = 2.0f * (y * z + r * x);
+  o.R22 = 1.0f - 2.0f * (x * x + y * y);
+  return o;
+}
+
+__device__ __forceinline__ Cov3 cov3d_from(const RotScale& q) {
+  const float L00 = q.R00 * q.sx, L01 = q.R01 * q.sy, L02 = q.R02 * q.sz;
+  const float L10 = q.R10 * q.sx, L11 = q.R11 * q.sy, L12 = q.R12 * q.sz;
+  const float L20 = q.R20 * q.sx, L21 = q.R21 * q.sy, L22 = q.R22 * q.sz;
+  Cov3 c;
+  c.c0 = L00 * L00 + L01 * L01 + L02 * L02;
+  c.c1 = L00 * L10 + L01 * L11 + L02 * L12;
+  c.c2 = L00 * L20 + L01 * L21 + L02 * L22;
+  c.c3 = L10 * L10 + L11 * L11 + L12 * L12;
+  c.c4 = L10 * L20 + L11 * L21 + L12 * L22;
+  c.c5 = L20 * L20 + L21 * L21 + L22 * L22;
+  return c;
+}
+
+// Everything the EWA projection produces that forward and backward both need.
+struct Proj2D {
+  float tx0, ty0, tz;          // view-space mean
+  float tx, ty;                // after the frustum clamp
+  bool clx, cly;
+  float M00, M01, M02, M10, M11, M12;
+  float u0, u1, u2, w0, w1, w2;
+  float a, b, c, det;
+};
+
+__device__ __forceinline__ void view_point(const float* __restrict__ V, float x, float y,
+                                           float z, float& tx, float& ty, float& tz) {
+  tx = V[0] * x + V[4] * y + V[8] * z + V[12];
+  ty = V[1] * x + V[5] * y + V[9] * z + V[13];
+  tz = V[2] * x + V[6] * y + V[10] * z + V[14];
+}
+
+__device__ __forceinline__ void project_cov(const View& v, const float* __restrict__ V,
+                                            const Cov3& s, Proj2D& o) {
+  const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+  const float txtz = o.tx0 / o.tz, tytz = o.ty0 / o.tz;
+  o.clx = (txtz < -limx) || (txtz > limx);
+  o.cly = (tytz < -limy) || (tytz > limy);
+  o.tx = fminf(limx, fmaxf(-limx, txtz)) * o.tz;
+  o.ty = fminf(limy, fmaxf(-limy, tytz)) * o.tz;
+  const float J00 = v.focal_x / o.tz;
+  const float J02 = -(v.focal_x * o.tx) / (o.tz * o.tz);
+  const float J11 = v.focal_y / o.tz;
+  const float J12 = -(v.focal_y * o.ty) / (o.tz * o.tz);
+  o.M00 = J00 * V[0] + J02 * V[2];
+  o.M01 = J00 * V[4] + J02 * V[6];
+  o.M02 = J00 * V[8] + J02 * V[10];
+  o.M10 = J11 * V[1] + J12 * V[2];
+  o.M11 = J11 * V[5] + J12 * V[6];
+  o.M12 = J11 * V[9] + J12 * V[10];
+  o.u0 = o.M00 * s.c0 + o.M01 * s.c1 + o.M02 * s.c2;
+  o.u1 = o.M00 * s.c1 + o.M01 * s.c3 + o.M02 * s.c4;
+  o.u2 = o.M00 * s.c2 + o.M01 * s.c4 + o.M02 * s.c5;
+  o.w0 = o.M10 * s.c0 + o.M11 * s.c1 + o.M12 * s.c2;
+  o.w1 = o.M10 * s.c1 + o.M11 * s.c3 + o.M12 * s.c4;
+  o.w2 = o.M10 * s.c2 + o.M11 * s.c4 + o.M12 * s.c5;
+  o.a = (o.u0 * o.M00 + o.u1 * o.M01 + o.u2 * o.M02) + 0.3f;
+  o.b = o.u0 * o.M10 + o.u1 * o.M11 + o.u2 * o.M12;
+  o.c = (o.w0 * o.M10 + o.w1 * o.M11 + o.w2 * o.M12) + 0.3f;
+  o.det = o.a * o.c - o.b * o.b;
+}
+
+// SH basis evaluation for one Gaussian; sh points at its (M,3) block.
+__device__ __forceinline__ void eval_sh(int deg, const float* __restrict__ sh, float x,
+                                        float y, float z, float out[3]) {
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float res = SH_C0 * sh[ch];
+    if (deg > 0) {
+      res = res - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        res = res + SH_C2[0] * xy * sh[12 + ch] + SH_C2[1] * yz * sh[15 + ch] +
+              SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + SH_C2[3] * xz * sh[21 + ch] +
+              SH_C2[4] * (xx - yy) * sh[24 + ch];
+        if (deg > 2) {
+          res = res + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] +
+                SH_C3[1] * xy * z * sh[30 + ch] +
+                SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] +
+                SH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+        }
+      }
+    }
+    out[ch] = res;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ forward
+// One thread per Gaussian.  Also counts per-tile list lengths (one atomic per touched
+// tile) and emits the workgroup's sum of tiles_touched for the offset scan.
+extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
+hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
+                     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                     const float* __restrict__ opacities, const float* __restrict__ scales,
+                     const float* __restrict__ rotations,
+                     const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
+  __shared__ uint32_t wtot[HGS_BLOCK / 64];
+  const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  const float* __restrict__ V = v.viewmatrix;
+  const float* __restrict__ PM = v.projmatrix;
+
+  GeomRec rec;
+  rec.mx = rec.my = rec.ca = rec.cb = rec.cc = rec.op = 0.f;
+  rec.r = rec.g = rec.b = rec.depth = 0.f;
+  rec.rect_lo = rec.rect_hi = rec.offset = 0u;
+  rec.radius = 0;
+  rec.clamped = rec.flags = 0u;
+  uint32_t tt = 0;
+
+  if (i < v.P) {
+    const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    Proj2D pj;
+    view_point(V, x, y, z, pj.tx0, pj.ty0, pj.tz);
+    if (pj.tz > HGS_NEAR_Z) {
+      const float hx = PM[0] * x + PM[4] * y + PM[8] * z + PM[12];
+      const float hy = PM[1] * x + PM[5] * y + PM[9] * z + PM[13];
+      const float hw = PM[3] * x + PM[7] * y + PM[11] * z + PM[15];
+      const float pw = 1.0f / (hw + 0.0000001f);
+      const float projx = hx * pw, projy = hy * pw;
+      Cov3 s;
+      if (cov3D_precomp) {
+        const float* c = cov3D_precomp + 6 * (size_t)i;
+        s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
+      } else {
+        s = cov3d_from(make_rotscale(scales, rotations, i, v.scale_modifier));
+      }
+      project_cov(v, V, s, pj);
+      if (pj.det != 0.0f) {
+        const float det_inv = 1.0f / pj.det;
+        const float mid = 0.5f * (pj.a + pj.c);
+        const float root = sqrtf(fmaxf(0.1f, mid * mid - pj.det));
+        const float lam = fmaxf(mid + root, mid - root);
+        const float radf = ceilf(3.0f * sqrtf(lam));
+        const float mx = ((projx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
+        const float my = ((projy + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+        const int gxm = v.grid_x, gym = v.grid_y;
+        const int rminx = min(gxm, max(0, (int)((mx - radf) / 16.0f)));
+        const int rminy = min(gym, max(0, (int)((my - radf) / 16.0f)));
+        const int rmaxx = min(gxm, max(0, (int)((mx + radf + 15.0f) / 16.0f)));
+        const int rmaxy = min(gym, max(0, (int)((my + radf + 15.0f) / 16.0f)));
+        const int area = (rmaxx - rminx) * (rmaxy - rminy);
+        if (area > 0) {
+          tt = (uint32_t)area;
+          rec.mx = mx; rec.my = my;
+          rec.ca = pj.c * det_inv; rec.cb = -pj.b * det_inv; rec.cc = pj.a * det_inv;
+          rec.op = opacities[i];
+          rec.depth = pj.tz;
+          rec.rect_lo = (uint32_t)rminx | ((uint32_t)rminy << 16);
+          rec.rect_hi = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
+          rec.radius = (int)radf;
+          rec.flags = (pj.clx ? 1u : 0u) | (pj.cly ? 2u : 0u);
+          if (colors_precomp) {
+            rec.r = colors_precomp[3 * i + 0];
+            rec.g = colors_precomp[3 * i + 1];
+            rec.b = colors_precomp[3 * i + 2];
+          } else {
+            const float* cp = v.campos;
+            const float ddx = x - cp[0], ddy = y - cp[1], ddz = z - cp[2];
+            const float n = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            float col[3];
+            eval_sh(v.D, shs + (size_t)i * v.M * 3, ddx / n, ddy / n, ddz / n, col);
+            uint32_t cl = 0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              col[ch] = col[ch] + 0.5f;
+              if (col[ch] < 0.0f) { cl |= (1u << ch); col[ch] = 0.0f; }
+            }
+            rec.r = col[0]; rec.g = col[1]; rec.b = col[2];
+            rec.clamped = cl;
+          }
+          // per-tile list lengths
+          for (int ty = rminy; ty < rmaxy; ++ty)
+            for (int tx = rminx; tx < rmaxx; ++tx)
+              atomicAdd(&L.tile_count[ty * gxm + tx], 1u);
+        }
+      }
+    }
+    radii[i] = rec.radius;
+    uint4* dst = reinterpret_cast<uint4*>(&L.geom[i]);
+    const uint4* src = reinterpret_cast<const uint4*>(&rec);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+  }
+  uint32_t total;
+  (void)hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
+  if (threadIdx.x == 0) L.block_sums[blockIdx.x] = total;
+}
+
+// ----------------------------------------------------------------------------- backward
+// One thread per Gaussian: sums its tiles_touched gradient rows (contiguous, fixed order
+// => deterministic), then chains through conic -> cov2D -> (cov3D, mean), projection,
+// depth, SH and Sigma = R S^2 R^T.  Every output element is written exactly once.
+extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
+hgs_k_preprocess_bwd(View v, Layout L, const float* __restrict__ grad_rows,
+                     const float* __restrict__ means3D, const float* __restrict__ shs,
+                     const float* __restrict__ colors_precomp,
+                     const float* __restrict__ scales, const float* __restrict__ rotations,
+                     const float* __restrict__ cov3D_precomp,
+                     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+                     float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
+                     float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
+                     float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+  const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  if (i >= v.P) return;
+  const float* __restrict__ V = v.viewmatrix;
+  const float* __restrict__ PM = v.projmatrix;
+  const GeomRec g = L.geom[i];
+
+  float gmx = 0.f, gmy = 0.f, gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f;
+  float gr = 0.f, gg = 0.f, gb = 0.f, gdep = 0.f;
+  float dmean[3] = {0.f, 0.f, 0.f};
+  float dsc[3] = {0.f, 0.f, 0.f};
+  float drot[4] = {0.f, 0.f, 0.f, 0.f};
+  float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float draw[3] = {0.f, 0.f, 0.f};     // gradient wrt the pre-clamp colour
+  const bool vis = g.radius > 0;
+
+  if (vis) {
+    const int rw = (int)(g.rect_hi & 0xffffu) - (int)(g.rect_lo & 0xffffu);
+    const int rh = (int)(g.rect_hi >> 16) - (int)(g.rect_lo >> 16);
+    const int tt = rw * rh;
+    const float4* rows = reinterpret_cast<const float4*>(grad_rows) + 3 * (size_t)g.offset;
+    for (int k = 0; k < tt; ++k) {
+      const float4 r0 = rows[3 * k + 0], r1 = rows[3 * k + 1], r2 = rows[3 * k + 2];
+      gmx += r0.x; gmy += r0.y; gA += r0.z; gB += r0.w;
+      gC += r1.x; gop += r1.y; gr += r1.z; gg += r1.w;
+      gb += r2.x; gdep += r2.y;
+    }
+
+    const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    Proj2D pj;
+    view_point(V, x, y, z, pj.tx0, pj.ty0, pj.tz);
+    Cov3 s;
+    RotScale rs;
+    if (cov3D_precomp) {
+      const float* c = cov3D_precomp + 6 * (size_t)i;
+      s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
+    } else {
+      rs = make_rotscale(scales, rotations, i, v.scale_modifier);
+      s = cov3d_from(rs);
+    }
+    project_cov(v, V, s, pj);
+
+    // ---- conic -> cov2D (a, b, c)
+    const float a = pj.a, b = pj.b, c = pj.c;
+    const float inv2 = 1.0f / (pj.det * pj.det);
+    const float dLa = inv2 * (-c * c * gA + b * c * gB - b * b * gC);
+    const float dLb = inv2 * (2.0f * b * c * gA - (pj.det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
+    const float dLc = inv2 * (-b * b * gA + a * b * gB - a * a * gC);
+
+    // ---- cov2D -> packed cov3D
+    const float M0[3] = {pj.M00, pj.M01, pj.M02}, M1[3] = {pj.M10, pj.M11, pj.M12};
+    dcov[0] = dLa * M0[0] * M0[0] + dLb * M0[0] * M1[0] + dLc * M1[0] * M1[0];
+    dcov[3] = dLa * M0[1] * M0[1] + dLb * M0[1] * M1[1] + dLc * M1[1] * M1[1];
+    dcov[5] = dLa * M0[2] * M0[2] + dLb * M0[2] * M1[2] + dLc * M1[2] * M1[2];
+    dcov[1] = 2.f * dLa * M0[0] * M0[1] + dLb * (M0[0] * M1[1] + M0[1] * M1[0]) + 2.f * dLc * M1[0] * M1[1];
+    dcov[2] = 2.f * dLa * M0[0] * M0[2] + dLb * (M0[0] * M1[2] + M0[2] * M1[0]) + 2.f * dLc * M1[0] * M1[2];
+    dcov[4] = 2.f * dLa * M0[1] * M0[2] + dLb * (M0[1] * M1[2] + M0[2] * M1[1]) + 2.f * dLc * M1[1] * M1[2];
+
+    // ---- cov2D -> M -> J -> t
+    const float u[3] = {pj.u0, pj.u1, pj.u2}, w[3] = {pj.w0, pj.w1, pj.w2};
+    float dM0[3], dM1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      dM0[k] = 2.f * dLa * u[k] + dLb * w[k];
+      dM1[k] = 2.f * dLc * w[k] + dLb * u[k];
+    }
+    const float dJ00 = dM0[0] * V[0] + dM0[1] * V[4] + dM0[2] * V[8];
+    const float dJ02 = dM0[0] * V[2] + dM0[1] * V[6] + dM0[2] * V[10];
+    const float dJ11 = dM1[0] * V[1] + dM1[1] * V[5] + dM1[2] * V[9];
+    const float dJ12 = dM1[0] * V[2] + dM1[1] * V[6] + dM1[2] * V[10];
+    const float tzi = 1.0f / pj.tz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
+    const float fx = v.focal_x, fy = v.focal_y;
+    float dt[3];
+    dt[0] = pj.clx ? 0.f : -fx * tz2 * dJ02;
+    dt[1] = pj.cly ? 0.f : -fy * tz2 * dJ12;
+    dt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + 2.f * fx * pj.tx * tz3 * dJ02 +
+            2.f * fy * pj.ty * tz3 * dJ12;
+    // depth head: depth = t.z
+    dt[2] += gdep;
+#pragma unroll
+    for (int bq = 0; bq < 3; ++bq)
+      dmean[bq] += V[4 * bq + 0] * dt[0] + V[4 * bq + 1] * dt[1] + V[4 * bq + 2] * dt[2];
+
+    // ---- pixel mean -> NDC -> homogeneous -> mean
+    const float dpx = gmx * 0.5f * (float)v.W, dpy = gmy * 0.5f * (float)v.H;
+    const float hx = PM[0] * x + PM[4] * y + PM[8] * z + PM[12];
+    const float hy = PM[1] * x + PM[5] * y + PM[9] * z + PM[13];
+    const float hw = PM[3] * x + PM[7] * y + PM[11] * z + PM[15];
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float dhx = dpx * pw, dhy = dpy * pw;
+    const float dhw = -(dpx * hx + dpy * hy) * pw * pw;
+#pragma unroll
+    for (int bq = 0; bq < 3; ++bq)
+      dmean[bq] += PM[4 * bq + 0] * dhx + PM[4 * bq + 1] * dhy + PM[4 * bq + 3] * dhw;
+
+    // ---- colour
+    if (!colors_precomp) {
+      draw[0] = (g.clamped & 1u) ? 0.f : gr;
+      draw[1] = (g.clamped & 2u) ? 0.f : gg;
+      draw[2] = (g.clamped & 4u) ? 0.f : gb;
+    }
+
+    // ---- Sigma -> scale / rotation
+    if (!cov3D_precomp) {
+      const float G00 = dcov[0], G11 = dcov[3], G22 = dcov[5];
+      const float G01 = 0.5f * dcov[1], G02 = 0.5f * dcov[2], G12 = 0.5f * dcov[4];
+      const float Lm[3][3] = {{rs.R00 * rs.sx, rs.R01 * rs.sy, rs.R02 * rs.sz},
+                              {rs.R10 * rs.sx, rs.R11 * rs.sy, rs.R12 * rs.sz},
+                              {rs.R20 * rs.sx, rs.R21 * rs.sy, rs.R22 * rs.sz}};
+      const float Gm[3][3] = {{G00, G01, G02}, {G01, G11, G12}, {G02, G12, G22}};
+      const float Rm[3][3] = {{rs.R00, rs.R01, rs.R02}, {rs.R10, rs.R11, rs.R12},
+                              {rs.R20, rs.R21, rs.R22}};
+      const float sv[3] = {rs.sx, rs.sy, rs.sz};
+      float D[3][3];   // dL/dR
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float ds = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+          const float dLik = 2.f * (Gm[ii][0] * Lm[0][k] + Gm[ii][1] * Lm[1][k] + Gm[ii][2] * Lm[2][k]);
+          ds += dLik * Rm[ii][k];
+          D[ii][k] = dLik * sv[k];
+        }
+        dsc[k] = ds * v.scale_modifier;
+      }
+      const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+      const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
+      drot[0] = 2.f * (-qz * D[0][1] + qy * D[0][2] + qz * D[1][0] - qx * D[1][2] - qy * D[2][0] + qx * D[2][1]);
+      drot[1] = 2.f * (qy * D[0][1] + qz * D[0][2] + qy * D[1][0] - 2.f * qx * D[1][1] - r * D[1][2] +
+                       qz * D[2][0] + r * D[2][1] - 2.f * qx * D[2][2]);
+      drot[2] = 2.f * (-2.f * qy * D[0][0] + qx * D[0][1] + r * D[0][2] + qx * D[1][0] + qz * D[1][2] -
+                       r * D[2][0] + qz * D[2][1] - 2.f * qy * D[2][2]);
+      drot[3] = 2.f * (-2.f * qz * D[0][0] - r * D[0][1] + qx * D[0][2] + r * D[1][0] - 2.f * qz * D[1][1] +
+                       qy * D[1][2] + qx * D[2][0] + qy * D[2][1]);
+    }
+  }
+
+  // ---- SH backward (writes dL_dshs for every Gaussian, zeros when culled)
+  if (dL_dshs) {
+    float* out = dL_dshs + (size_t)i * v.M * 3;
+    const int ncoef = (v.D + 1) * (v.D + 1);
+    if (vis && shs) {
+      const float* cp = v.campos;
+      const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+      const float ox = x - cp[0], oy = y - cp[1], oz = z - cp[2];
+      const float n = sqrtf(ox * ox + oy * oy + oz * oz);
+      const float dx = ox / n, dy = oy / n, dz = oz / n;
+      const float* sh = shs + (size_t)i * v.M * 3;
+      float basis[16];
+      basis[0] = SH_C0;
+      float ddir[3] = {0.f, 0.f, 0.f};
+      if (v.D > 0) {
+        basis[1] = -SH_C1 * dy; basis[2] = SH_C1 * dz; basis[3] = -SH_C1 * dx;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          ddir[0] += draw[ch] * (-SH_C1 * sh[9 + ch]);
+          ddir[1] += draw[ch] * (-SH_C1 * sh[3 + ch]);
+          ddir[2] += draw[ch] * (SH_C1 * sh[6 + ch]);
+        }
+        if (v.D > 1) {
+          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+          const float xy = dx * dy, yz = dy * dz, xz = dx * dz;
+          basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz;
+          basis[6] = SH_C2[2] * (2.f * zz - xx - yy);
+          basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float s4 = sh[12 + ch], s5 = sh[15 + ch], s6 = sh[18 + ch], s7 = sh[21 + ch], s8 = sh[24 + ch];
+            ddir[0] += draw[ch] * (SH_C2[0] * dy * s4 + SH_C2[2] * -2.f * dx * s6 + SH_C2[3] * dz * s7 + SH_C2[4] * 2.f * dx * s8);
+            ddir[1] += draw[ch] * (SH_C2[0] * dx * s4 + SH_C2[1] * dz * s5 + SH_C2[2] * -2.f * dy * s6 + SH_C2[4] * -2.f * dy * s8);
+            ddir[2] += draw[ch] * (SH_C2[1] * dy * s5 + SH_C2[2] * 4.f * dz * s6 + SH_C2[3] * dx * s7);
+          }
+          if (v.D > 2) {
+            basis[9] = SH_C3[0] * dy * (3.f * xx - yy);
+            basis[10] = SH_C3[1] * xy * dz;
+            basis[11] = SH_C3[2] * dy * (4.f * zz - xx - yy);
+            basis[12] = SH_C3[3] * dz * (2.f * zz - 3.f * xx - 3.f * yy);
+            basis[13] = SH_C3[4] * dx * (4.f * zz - xx - yy);
+            basis[14] = SH_C3[5] * dz * (xx - yy);
+            basis[15] = SH_C3[6] * dx * (xx - 3.f * yy);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              const float s9 = sh[27 + ch], s10 = sh[30 + ch], s11 = sh[33 + ch], s12 = sh[36 + ch];
+              const float s13 = sh[39 + ch], s14 = sh[42 + ch], s15 = sh[45 + ch];
+              ddir[0] += draw[ch] * (SH_C3[0] * s9 * 6.f * xy + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2.f * xy +
+                                     SH_C3[3] * s12 * -6.f * xz + SH_C3[4] * s13 * (4.f * zz - 3.f * xx - yy) +
+                                     SH_C3[5] * s14 * 2.f * xz + SH_C3[6] * s15 * 3.f * (xx - yy));
+              ddir[1] += draw[ch] * (SH_C3[0] * s9 * 3.f * (xx - yy) + SH_C3[1] * s10 * xz +
+                                     SH_C3[2] * s11 * (4.f * zz - xx - 3.f * yy) + SH_C3[3] * s12 * -6.f * yz +
+                                     SH_C3[4] * s13 * -2.f * xy + SH_C3[5] * s14 * -2.f * yz + SH_C3[6] * s15 * -6.f * xy);
+              ddir[2] += draw[ch] * (SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 8.f * yz +
+                                     SH_C3[3] * s12 * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s13 * 8.f * xz +
+                                     SH_C3[5] * s14 * (xx - yy));
+            }
+          }
+        }
+      }
+      for (int k = 0; k < v.M; ++k) {
+        const float bk = (k < ncoef) ? basis[k] : 0.f;
+        out[3 * k + 0] = bk * draw[0];
+        out[3 * k + 1] = bk * draw[1];
+        out[3 * k + 2] = bk * draw[2];
+      }
+      // d(normalize)/d(dir_orig)
+      const float dot = dx * ddir[0] + dy * ddir[1] + dz * ddir[2];
+      dmean[0] += (ddir[0] - dx * dot) / n;
+      dmean[1] += (ddir[1] - dy * dot) / n;
+      dmean[2] += (ddir[2] - dz * dot) / n;
+    } else {
+      for (int k = 0; k < 3 * v.M; ++k) out[k] = 0.f;
+    }
+  }
+
+  if (dL_dmeans3D) {
+    dL_dmeans3D[3 * i + 0] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
+  }
+  if (dL_dmeans2D) {
+    dL_dmeans2D[3 * i + 0] = gmx * 0.5f * (float)v.W;
+    dL_dmeans2D[3 * i + 1] = gmy * 0.5f * (float)v.H;
+    dL_dmeans2D[3 * i + 2] = 0.f;
+  }
+  if (dL_dcolors) {
+    dL_dcolors[3 * i + 0] = gr; dL_dcolors[3 * i + 1] = gg; dL_dcolors[3 * i + 2] = gb;
+  }
+  if (dL_dopac) dL_dopac[i] = gop;
+  if (dL_dscales) {
+    dL_dscales[3 * i + 0] = dsc[0]; dL_dscales[3 * i + 1] = dsc[1]; dL_dscales[3 * i + 2] = dsc[2];
+  }
+  if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+  if (dL_dcov3D) {
+    float* o = dL_dcov3D + 6 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = dcov[k];
+  }
+}
+
+// ------------------------------------------------------------------------- mark visible
+extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
+hgs_k_mark_visible(const float* __restrict__ V, int P, const float* __restrict__ means3D,
+                   uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  if (i >= P) return;
+  const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+  const float tz = V[2] * x + V[6] * y + V[10] * z + V[14];
+  present[i] = tz > HGS_NEAR_Z ? 1 : 0;
+}

@@ -1,0 +1,291 @@
+"""Host-side mirror of the `diff_gaussian_rasterization` Python API (ashawkey fork) on top of
+libhgs_rast.so.  Same names, argument meaning, return tuple and error behaviour as the
+module the reference imports at
+  /root/reference/gaussiansplatting/gaussian_renderer/__init__.py:14  (call :36-51, :86-94)
+  /root/reference/gs_renderer.py:10-13                               (call :951-966, :1006-1015)
+so those files run unchanged when `diff_gaussian_rasterization` resolves to this package
+(the top-level `diff_gaussian_rasterization/` shim re-exports it).
+
+PyTorch is plumbing only: it owns the tensors, the current HIP stream and autograd; all
+arithmetic happens in the HIP library reached through ctypes (plain pointers and sizes).
+There is no CPU path: non-HIP tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import HgsSettings, HgsStatus
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---------------------------------------------------------------------------- plumbing
+
+class _DeviceState:
+    """Per-device grow-only estimate of the entry capacity (R) + a pinned status mirror."""
+
+    def __init__(self):
+        self.capacity = 0
+        self.status_pinned = torch.zeros(8, dtype=torch.int32).pin_memory()
+
+
+_device_state: dict = {}
+
+
+def _state(device: torch.device) -> _DeviceState:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _device_state.get(key)
+    if st is None:
+        st = _device_state[key] = _DeviceState()
+    return st
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    if t.device != device:
+        raise RuntimeError(f"expected a tensor on {device}, got {t.device}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _opt(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if (t is None or t.numel() == 0) else t
+
+
+def _make_settings(rs: GaussianRasterizationSettings, device, keep: list) -> HgsSettings:
+    bg = _f32c(rs.bg.reshape(-1), device)
+    vm = _f32c(rs.viewmatrix, device)
+    pm = _f32c(rs.projmatrix, device)
+    cp = _f32c(rs.campos.reshape(-1), device)
+    if bg.numel() != 3 or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
+        raise RuntimeError("bg/campos must have 3 elements, viewmatrix/projmatrix 16")
+    keep.extend([bg, vm, pm, cp])
+    s = HgsSettings()
+    s.image_height = int(rs.image_height)
+    s.image_width = int(rs.image_width)
+    s.tanfovx = float(rs.tanfovx)
+    s.tanfovy = float(rs.tanfovy)
+    s.bg = bg.data_ptr()
+    s.scale_modifier = float(rs.scale_modifier)
+    s.viewmatrix = vm.data_ptr()
+    s.projmatrix = pm.data_ptr()
+    s.sh_degree = int(rs.sh_degree)
+    s.campos = cp.data_ptr()
+    s.prefiltered = int(bool(rs.prefiltered))
+    s.debug = int(bool(rs.debug))
+    return s
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"libhgs_rast: {what} failed with code {rc}")
+
+
+def _round_capacity(n: int) -> int:
+    return max(1 << 16, (int(n) + 0xFFFF) & ~0xFFFF)
+
+
+# ------------------------------------------------------------------------ autograd node
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Replaces upstream's `_RasterizeGaussians` (forward -> `_C.rasterize_gaussians`,
+    backward -> `_C.rasterize_gaussians_backward`)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings, want_grad):
+        lib = _lib.load()
+        device = means3D.device
+        if device.type != "cuda":
+            raise RuntimeError("humangaussian_amd: tensors must live on a HIP device "
+                               "(torch device type 'cuda'); there is no CPU path")
+        P = int(means3D.shape[0])
+        if P != 0 and (means3D.dim() != 2 or means3D.shape[1] != 3):
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+
+        keep: list = []
+        with torch.cuda.device(device):
+            settings = _make_settings(raster_settings, device, keep)
+            m3 = _f32c(means3D, device)
+            sh_ = _opt(sh); cp_ = _opt(colors_precomp)
+            sc_ = _opt(scales); ro_ = _opt(rotations); cv_ = _opt(cov3Ds_precomp)
+            sh_ = None if sh_ is None else _f32c(sh_, device)
+            cp_ = None if cp_ is None else _f32c(cp_, device)
+            sc_ = None if sc_ is None else _f32c(sc_, device)
+            ro_ = None if ro_ is None else _f32c(ro_, device)
+            cv_ = None if cv_ is None else _f32c(cv_, device)
+            op_ = _f32c(opacities, device)
+            M = int(sh_.shape[1]) if sh_ is not None else 0
+            if sh_ is not None and (sh_.dim() != 3 or sh_.shape[0] != P or sh_.shape[2] != 3):
+                raise RuntimeError("shs must have dimensions (num_points, M, 3)")
+
+            color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+            depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
+            alpha = torch.empty((1, H, W), dtype=torch.float32, device=device)
+            radii = torch.empty((P,), dtype=torch.int32, device=device)
+            geom = torch.empty(lib.hgs_geom_bytes(P, H, W), dtype=torch.uint8, device=device)
+            img = torch.empty(lib.hgs_img_bytes(H, W), dtype=torch.uint8, device=device)
+
+            st = _state(device)
+            stream = torch.cuda.current_stream(device)
+            cap = max(st.capacity, _round_capacity(4 * P)) if P > 0 else 0
+            status = None
+            for _ in range(3):
+                binbuf = torch.empty(lib.hgs_bin_bytes(cap), dtype=torch.uint8, device=device)
+                rc = lib.hgs_forward(
+                    ctypes.byref(settings), P, M, _ptr(m3), _ptr(sh_), _ptr(cp_), _ptr(op_),
+                    _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(color), _ptr(depth), _ptr(alpha),
+                    _ptr(radii), _ptr(geom), _ptr(binbuf), cap, _ptr(img),
+                    1 if want_grad else 0, ctypes.c_void_p(st.status_pinned.data_ptr()),
+                    ctypes.c_void_p(stream.cuda_stream))
+                if rc == -2:
+                    raise RuntimeError("inconsistent optional inputs (shs/colors_precomp, "
+                                       "scales+rotations/cov3D_precomp)")
+                _check(rc, "hgs_forward")
+                # one host sync per forward, like upstream's blocking read of num_rendered
+                stream.synchronize()
+                status = [int(x) & 0xFFFFFFFF for x in st.status_pinned.tolist()]
+                if not status[4]:
+                    break
+                cap = _round_capacity(int(status[0] * 1.25) + 1)   # overflow: grow, re-run
+            else:
+                raise RuntimeError("libhgs_rast: entry capacity did not converge")
+            st.capacity = max(st.capacity, cap)
+
+        ctx.raster_settings = raster_settings
+        ctx.status = status
+        ctx.P, ctx.M = P, M
+        ctx.has = (sh_ is not None, cp_ is not None, sc_ is not None, cv_ is not None)
+        ctx.in_shapes = (tuple(means3D.shape), tuple(opacities.shape))
+        if want_grad:
+            ctx.save_for_backward(m3, sh_ if sh_ is not None else m3.new_empty(0),
+                                  cp_ if cp_ is not None else m3.new_empty(0), op_,
+                                  sc_ if sc_ is not None else m3.new_empty(0),
+                                  ro_ if ro_ is not None else m3.new_empty(0),
+                                  cv_ if cv_ is not None else m3.new_empty(0),
+                                  radii, color, depth, alpha, geom, binbuf, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        lib = _lib.load()
+        (m3, sh_, cp_, op_, sc_, ro_, cv_, radii, color, depth, alpha, geom, binbuf,
+         img) = ctx.saved_tensors
+        has_sh, has_cp, has_sr, has_cv = ctx.has
+        device = m3.device
+        P, M = ctx.P, ctx.M
+        keep: list = []
+        with torch.cuda.device(device):
+            settings = _make_settings(ctx.raster_settings, device, keep)
+            gc = None if grad_color is None else _f32c(grad_color, device)
+            gd = None if grad_depth is None else _f32c(grad_depth, device)
+            ga = None if grad_alpha is None else _f32c(grad_alpha, device)
+            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)  # noqa: E731
+            d_means3D = new(P, 3)
+            d_means2D = new(P, 3)
+            d_opac = new(*ctx.in_shapes[1])
+            d_sh = new(P, M, 3) if has_sh else None
+            d_cp = new(P, 3) if has_cp else None
+            d_sc = new(P, 3) if has_sr else None
+            d_ro = new(P, 4) if has_sr else None
+            d_cv = new(P, 6) if has_cv else None
+            st = HgsStatus()
+            (st.num_rendered, st.active_tiles, st.num_buckets, st.bwd_groups,
+             st.overflow) = ctx.status[:5]
+            st.reserved[0], st.reserved[1], st.reserved[2] = ctx.status[5:8]
+            scratch = torch.empty(lib.hgs_bwd_scratch_bytes(st.num_rendered), dtype=torch.uint8,
+                                  device=device)
+            stream = torch.cuda.current_stream(device)
+            rc = lib.hgs_backward(
+                ctypes.byref(settings), P, M, _ptr(m3), _ptr(sh_ if has_sh else None),
+                _ptr(cp_ if has_cp else None), _ptr(op_), _ptr(sc_ if has_sr else None),
+                _ptr(ro_ if has_sr else None), _ptr(cv_ if has_cv else None), _ptr(radii),
+                _ptr(color), _ptr(depth), _ptr(alpha), _ptr(gc), _ptr(gd), _ptr(ga),
+                _ptr(geom), _ptr(binbuf), _ptr(img), ctypes.byref(st), _ptr(scratch),
+                _ptr(d_means3D), _ptr(d_means2D), _ptr(d_sh), _ptr(d_cp), _ptr(d_opac),
+                _ptr(d_sc), _ptr(d_ro), _ptr(d_cv), ctypes.c_void_p(stream.cuda_stream))
+            _check(rc, "hgs_backward")
+        return (d_means3D, d_means2D, d_sh, d_cp, d_opac, d_sc, d_ro, d_cv, None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    want_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad
+        for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                  cov3Ds_precomp))
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,
+                                     rotations, cov3Ds_precomp, raster_settings, want_grad)
+
+
+# --------------------------------------------------------------------------- the module
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test (replaces `_C.mark_visible`)."""
+        lib = _lib.load()
+        with torch.no_grad():
+            device = positions.device
+            if device.type != "cuda":
+                raise RuntimeError("humangaussian_amd: tensors must live on a HIP device")
+            keep: list = []
+            with torch.cuda.device(device):
+                settings = _make_settings(self.raster_settings, device, keep)
+                pos = _f32c(positions, device)
+                P = int(pos.shape[0])
+                present = torch.zeros((P,), dtype=torch.uint8, device=device)
+                rc = lib.hgs_mark_visible(ctypes.byref(settings), P, _ptr(pos), _ptr(present),
+                                          ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+                _check(rc, "hgs_mark_visible")
+            return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or '
+                            'precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        if shs is None:
+            shs = empty
+        if colors_precomp is None:
+            colors_precomp = empty
+        if scales is None:
+            scales = empty
+        if rotations is None:
+            rotations = empty
+        if cov3D_precomp is None:
+            cov3D_precomp = empty
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                   rotations, cov3D_precomp, raster_settings)

@@ -1,0 +1,130 @@
+"""Mirrors of the reference's two render wrappers around the rasterizer, behaviour-identical
+(same argument meaning, same returned dict keys) so callers switch by import only:
+
+* `render()`           <- /root/reference/gaussiansplatting/gaussian_renderer/__init__.py:18-104
+                          (called per view by threestudio/systems/GaussianDreamer.py:244-248)
+* `Renderer.render()`  <- /root/reference/gs_renderer.py:923-1028 (animation.py:477-484)
+
+`viewpoint_camera` / `pc` / `pipe` are duck-typed exactly like the reference objects
+(`scene/cameras.py:17-67`, `scene/gaussian_model.py:95-118`, `arguments/__init__.py:63-68`).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+_SH_C0 = 0.28209479177387814
+_SH_C1 = 0.4886025119029199
+
+
+def _eval_sh_deg01(deg, sh, dirs):
+    """Only used by the `convert_SHs_python` branch (kept for API completeness)."""
+    res = _SH_C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        res = res - _SH_C1 * y * sh[..., 1] + _SH_C1 * z * sh[..., 2] - _SH_C1 * x * sh[..., 3]
+    if deg > 1:
+        raise NotImplementedError("convert_SHs_python above degree 1: pass shs to the rasterizer")
+    return res
+
+
+def _tan_half(fov):
+    # the reference calls math.tan on a 0-dim device tensor (D2H sync per view,
+    # gaussian_renderer/__init__.py:33-34); accept both floats and tensors
+    return math.tan(float(fov) * 0.5)
+
+
+def _screenspace_points(xyz):
+    pts = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        pts.retain_grad()
+    except Exception:
+        pass
+    return pts
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
+           override_color=None):
+    """Render one view.  Returns the reference's dict: render, viewspace_points,
+    visibility_filter, radii, depth_3dgs, alpha_3dgs."""
+    screenspace_points = _screenspace_points(pc.get_xyz)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=_tan_half(viewpoint_camera.FoVx),
+        tanfovy=_tan_half(viewpoint_camera.FoVy),
+        bg=bg_color,
+        scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center,
+        prefiltered=False,
+        debug=bool(getattr(pipe, "debug", False)),
+    )
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D = pc.get_xyz
+    opacity = pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if getattr(pipe, "convert_SHs_python", False):
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(_eval_sh_deg01(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    f = lambda t: None if t is None else t.float()  # noqa: E731  (AMP: kernels are fp32)
+    rendered_image, radii, depth, alpha = rasterizer(
+        means3D=f(means3D), means2D=f(screenspace_points), shs=f(shs),
+        colors_precomp=f(colors_precomp), opacities=f(opacity), scales=f(scales),
+        rotations=f(rotations), cov3D_precomp=f(cov3D_precomp))
+
+    return {"render": rendered_image,
+            "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0,
+            "radii": radii,
+            "depth_3dgs": depth,
+            "alpha_3dgs": alpha}
+
+
+class Renderer:
+    """`gs_renderer.Renderer.render` mirror: takes any object exposing the reference
+    GaussianModel getters as `gaussians`."""
+
+    def __init__(self, gaussians, white_background: bool = True, device="cuda"):
+        self.gaussians = gaussians
+        self.white_background = white_background
+        self.bg_color = torch.tensor([1, 1, 1] if white_background else [0, 0, 0],
+                                     dtype=torch.float32, device=device)
+
+    def render(self, viewpoint_camera, scaling_modifier=1.0, bg_color=None, override_color=None,
+               compute_cov3D_python=False, convert_SHs_python=False):
+        class _Pipe:
+            pass
+        pipe = _Pipe()
+        pipe.compute_cov3D_python = compute_cov3D_python
+        pipe.convert_SHs_python = convert_SHs_python
+        pipe.debug = False
+        out = render(viewpoint_camera, self.gaussians, pipe,
+                     self.bg_color if bg_color is None else bg_color, scaling_modifier,
+                     override_color)
+        return {"image": out["render"].clamp(0, 1),     # gs_renderer.py:1017
+                "depth": out["depth_3dgs"],
+                "alpha": out["alpha_3dgs"],
+                "viewspace_points": out["viewspace_points"],
+                "visibility_filter": out["visibility_filter"],
+                "radii": out["radii"]}

@@ -1,0 +1,184 @@
+"""Synthetic inputs for benchmarks and tests (no datasets, no SMPL-X files on the box).
+
+* `humanoid_points`  - area-uniform samples on a capsule humanoid with the extents of the
+  SMPL-X body HumanGaussian initialises from (after `threestudio/utils/poser.py:337-352`:
+  about 1.20 x 0.30 x 1.56, z-up, surface area ~1.5), standing in for `pcb()`
+  (`threestudio/systems/GaussianDreamer.py:220-232`).
+* `init_cloud`       - Gaussian parameters as `GaussianModel.create_from_pcd` makes them
+  (`gaussiansplatting/scene/gaussian_model.py:124-147`: isotropic scale from the mean 3-NN
+  distance, opacity 0.1, identity rotation, colour 0.5), or a randomised "mid-training"
+  variant.
+* `orbit_camera`     - c2w as `threestudio/data/uncond.py:378-495` builds it, then the
+  matrices exactly as `gaussiansplatting/scene/cameras.py:22-53` +
+  `utils/graphics_utils.py:73-99` derive them (analytically on the host).
+All numpy / CPU torch; callers move tensors to the device.
+"""
+from __future__ import annotations
+
+import math
+from typing import NamedTuple
+
+import numpy as np
+import torch
+
+SH_C0 = 0.28209479177387814
+
+
+# ------------------------------------------------------------------------------ cloud
+
+def humanoid_points(n: int, seed: int = 0) -> np.ndarray:
+    """(n,3) float32 points, z-up, centred, height ~1.56, arm span ~1.20, depth ~0.30."""
+    rng = np.random.default_rng(seed)
+    # (kind, centre/endpoints, radii) ; cylinders sampled on the lateral surface,
+    # ellipsoids/spheres on the surface; weights = approximate areas
+    parts = [
+        ("cyl", (-0.09, 0.0, -0.78), (-0.09, 0.0, -0.02), (0.065, 0.065)),   # left leg
+        ("cyl", (0.09, 0.0, -0.78), (0.09, 0.0, -0.02), (0.065, 0.065)),     # right leg
+        ("cyl", (0.0, 0.0, -0.02), (0.0, 0.0, 0.53), (0.16, 0.10)),          # torso (elliptic)
+        ("cyl", (0.17, 0.0, 0.48), (0.60, 0.0, 0.42), (0.04, 0.04)),         # arms
+        ("cyl", (-0.17, 0.0, 0.48), (-0.60, 0.0, 0.42), (0.04, 0.04)),
+        ("sph", (0.0, 0.0, 0.66), None, (0.10, 0.12)),                       # head
+    ]
+    areas = []
+    for kind, a, b, r in parts:
+        if kind == "cyl":
+            L = np.linalg.norm(np.subtract(b, a))
+            per = 2 * math.pi * math.sqrt((r[0] ** 2 + r[1] ** 2) / 2)
+            areas.append(per * L)
+        else:
+            areas.append(4 * math.pi * r[0] * r[1])
+    areas = np.asarray(areas)
+    counts = rng.multinomial(n, areas / areas.sum())
+    out = []
+    for (kind, a, b, r), c in zip(parts, counts):
+        if c == 0:
+            continue
+        th = rng.uniform(0, 2 * math.pi, c)
+        if kind == "cyl":
+            a, b = np.asarray(a), np.asarray(b)
+            axis = b - a
+            L = np.linalg.norm(axis)
+            axis = axis / L
+            ref = np.array([0.0, 1.0, 0.0])
+            e1 = np.cross(axis, ref); e1 /= np.linalg.norm(e1)
+            e2 = np.cross(axis, e1)
+            u = rng.uniform(0, 1, c)
+            pts = (a[None] + u[:, None] * L * axis[None]
+                   + r[0] * np.cos(th)[:, None] * e1[None] + r[1] * np.sin(th)[:, None] * e2[None])
+        else:
+            zc = rng.uniform(-1, 1, c)
+            rr = np.sqrt(1 - zc * zc)
+            pts = np.asarray(a)[None] + np.stack(
+                [r[0] * rr * np.cos(th), r[0] * rr * np.sin(th), r[1] * zc], 1)
+        out.append(pts)
+    pts = np.concatenate(out, 0)
+    rng.shuffle(pts, axis=0)          # the real cloud has no spatial order in index space
+    return pts.astype(np.float32)
+
+
+def mean_knn_dist2(points: np.ndarray, k: int = 3) -> np.ndarray:
+    """Mean squared distance to the k nearest neighbours (what simple_knn.distCUDA2
+    returns, `submodules/simple-knn/simple_knn.cu:147-183`)."""
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(points).query(points, k=k + 1)
+    return (d[:, 1:] ** 2).mean(1).astype(np.float32)
+
+
+class Cloud(NamedTuple):
+    means3D: torch.Tensor     # (P,3)
+    shs: torch.Tensor         # (P,M,3)
+    opacities: torch.Tensor   # (P,1)  post-sigmoid
+    scales: torch.Tensor      # (P,3)  post-exp
+    rotations: torch.Tensor   # (P,4)  post-normalise (w,x,y,z)
+    sh_degree: int
+
+
+def init_cloud(n: int, sh_degree: int = 0, variant: str = "mid", seed: int = 0) -> Cloud:
+    rng = np.random.default_rng(seed + 1)
+    pts = humanoid_points(n, seed)
+    M = (sh_degree + 1) ** 2
+    d2 = np.maximum(mean_knn_dist2(pts), 1e-7)
+    log_scale = np.log(np.sqrt(d2))[:, None].repeat(3, 1)
+    shs = np.zeros((n, M, 3), np.float32)
+    shs[:, 0, :] = (0.5 - 0.5) / SH_C0                      # RGB2SH(0.5)
+    if variant == "init":
+        opac = np.full((n, 1), 0.1, np.float32)
+        quat = np.zeros((n, 4), np.float32); quat[:, 0] = 1.0
+    elif variant == "mid":
+        shs[:, 0, :] += rng.normal(0, 0.3, (n, 3)) / 1.0
+        if M > 1:
+            shs[:, 1:, :] = rng.normal(0, 0.1, (n, M - 1, 3))
+        opac = rng.uniform(0.05, 0.95, (n, 1)).astype(np.float32)
+        log_scale = log_scale + rng.normal(0, 0.3, (n, 3))
+        quat = rng.normal(0, 1, (n, 4)).astype(np.float32)
+        quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    else:
+        raise ValueError(variant)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
+    return Cloud(t(pts), t(shs), t(opac), t(np.exp(log_scale)), t(quat), sh_degree)
+
+
+# ----------------------------------------------------------------------------- cameras
+
+class Cam(NamedTuple):
+    image_height: int
+    image_width: int
+    FoVx: float
+    FoVy: float
+    world_view_transform: torch.Tensor   # (4,4) = w2c^T
+    full_proj_transform: torch.Tensor    # (4,4) = V @ P^T
+    camera_center: torch.Tensor          # (3,)
+    c2w: torch.Tensor                    # (4,4)
+
+
+def c2w_orbit(elev_deg: float, azim_deg: float, dist: float, center=(0.0, 0.0, 0.0)) -> np.ndarray:
+    el, az = math.radians(elev_deg), math.radians(azim_deg)
+    ctr = np.asarray(center, np.float64)
+    pos = ctr + dist * np.array([math.cos(el) * math.cos(az), math.cos(el) * math.sin(az),
+                                 math.sin(el)])
+    up = np.array([0.0, 0.0, 1.0])
+    look = ctr - pos; look /= np.linalg.norm(look)
+    right = np.cross(look, up); right /= np.linalg.norm(right)
+    up2 = np.cross(right, look); up2 /= np.linalg.norm(up2)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, up2, -look, pos
+    return c2w
+
+
+def camera_from_c2w(c2w: np.ndarray, fovy: float, H: int, W: int, znear=0.01, zfar=100.0) -> Cam:
+    focal = H / (2.0 * math.tan(fovy / 2.0))
+    fovx = 2.0 * math.atan(W / (2.0 * focal))
+    w2c = np.linalg.inv(c2w)
+    w2c[1:3, :3] *= -1          # the reference's "rectify" step (cameras.py:28-29)
+    w2c[:3, 3] *= -1
+    V = w2c.T
+    ty, tx = math.tan(fovy / 2.0), math.tan(fovx / 2.0)
+    Pm = np.zeros((4, 4))
+    Pm[0, 0] = 1.0 / tx
+    Pm[1, 1] = 1.0 / ty
+    Pm[3, 2] = 1.0
+    Pm[2, 2] = zfar / (zfar - znear)
+    Pm[2, 3] = -(zfar * znear) / (zfar - znear)
+    full = V @ Pm.T
+    center = np.linalg.inv(V)[3, :3]
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
+    return Cam(H, W, fovx, fovy, f32(V), f32(full), f32(center), f32(c2w))
+
+
+def orbit_camera(elev_deg, azim_deg, dist, fovy_deg, H, W, center=(0.0, 0.0, 0.0)) -> Cam:
+    return camera_from_c2w(c2w_orbit(elev_deg, azim_deg, dist, center), math.radians(fovy_deg), H, W)
+
+
+def random_cameras(n: int, H: int, W: int, seed: int = 0, stratified: bool = True):
+    """`configs/test.yaml` ranges: fovy 40-70 deg, distance 1.5-2.0, elevation -30..30,
+    azimuth stratified over the batch like `uncond.py:353-361`."""
+    rng = np.random.default_rng(seed + 7)
+    cams = []
+    for i in range(n):
+        if stratified:
+            az = (rng.uniform() + i) / n * 360.0 - 180.0
+        else:
+            az = rng.uniform(-180, 180)
+        cams.append(orbit_camera(rng.uniform(-30, 30), az, rng.uniform(1.5, 2.0),
+                                 rng.uniform(40, 70), H, W))
+    return cams

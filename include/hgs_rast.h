@@ -1,0 +1,121 @@
+/*
+ * hgs_rast.h - C ABI of libhgs_rast.so, the MI355X (gfx950) differentiable 3D Gaussian
+ * Splatting rasterizer that drops in behind HumanGaussian's
+ * `diff_gaussian_rasterization` extension.
+ *
+ * The reference has no C ABI: its boundary is the pybind11 module
+ * `diff_gaussian_rasterization._C` of the un-vendored ashawkey fork, reached from
+ *   /root/reference/gaussiansplatting/gaussian_renderer/__init__.py:14,36-51,86-94
+ *   /root/reference/gs_renderer.py:10-13,951-966,1006-1015
+ * Each entry point below names the `_C` function it replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says HOST;
+ *   - the caller owns every buffer; the library never allocates, frees or synchronises;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no global state,
+ *     so calls on distinct streams / devices may run concurrently;
+ *   - return value: 0 on success, a negative HGS_E* code for argument errors, or
+ *     -(1000 + hipError_t) when a launch fails.  Nothing throws across the ABI.
+ *   - tensors are fp32, contiguous, row-major with the shapes of SURVEY.md section 3.3.
+ */
+#ifndef HGS_RAST_H
+#define HGS_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGS_OK 0
+#define HGS_EINVAL (-1)   /* bad argument (null pointer, negative size, ...) */
+#define HGS_ESHAPE (-2)   /* "exactly one of shs / colors_precomp", "scales+rotations / cov3D" */
+
+/* Mirrors GaussianRasterizationSettings, same field order as the reference call site
+ * gaussian_renderer/__init__.py:36-49.  bg / viewmatrix / projmatrix / campos stay on the
+ * device (the reference hands over CUDA tensors); matrices are the row-major bytes of the
+ * (4,4) tensors, i.e. viewmatrix = w2c^T, projmatrix = viewmatrix @ P^T (cameras.py:50-52). */
+typedef struct hgs_settings {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  const float* bg;          /* [3]  */
+  float scale_modifier;
+  const float* viewmatrix;  /* [16] */
+  const float* projmatrix;  /* [16] */
+  int32_t sh_degree;        /* ACTIVE degree (0..3) */
+  const float* campos;      /* [3]  */
+  int32_t prefiltered;
+  int32_t debug;
+} hgs_settings;
+
+/* Written by hgs_forward into the tail of the geom buffer (device) and, once the stream
+ * reaches that point, mirrored to `status_host` (HOST, pinned) when it is non-NULL. */
+typedef struct hgs_status {
+  uint32_t num_rendered;   /* R = sum of tiles touched (upstream's `num_rendered`)      */
+  uint32_t active_tiles;   /* tiles with a non-empty list                              */
+  uint32_t num_buckets;    /* 64-Gaussian bucket states the forward stored             */
+  uint32_t bwd_groups;     /* workgroups hgs_backward launches for the blend backward  */
+  uint32_t overflow;       /* != 0: R exceeded entry_capacity; outputs are INVALID,    */
+                           /*       call again with entry_capacity >= num_rendered     */
+  uint32_t reserved[3];    /* [0] = entry_capacity the bin buffer was carved with       */
+} hgs_status;
+
+/* ---- buffer sizing (host-side arithmetic, no device work) --------------------------
+ * Replaces the three resize callbacks (geometry / binning / image state) that upstream's
+ * rasterize_gaussians() drives through torch.  geom: per-Gaussian + per-tile state;
+ * bin: per-(tile,Gaussian) entry state, sized by entry_capacity; img: per-pixel state;
+ * bwd_scratch: per-entry gradient rows used only inside hgs_backward. */
+size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
+size_t hgs_bin_bytes(int64_t entry_capacity);
+size_t hgs_img_bytes(int32_t image_height, int32_t image_width);
+size_t hgs_bwd_scratch_bytes(int64_t num_rendered);
+
+/* ---- forward: replaces _C.rasterize_gaussians --------------------------------------
+ * Exactly one of shs / colors_precomp and exactly one of {scales,rotations} /
+ * cov3D_precomp must be non-NULL (HGS_ESHAPE otherwise), matching the fork's Python
+ * checks.  shs is (P, M, 3); M = max coefficient count of the tensor.
+ * out_color (3,H,W), out_depth (1,H,W), out_alpha (1,H,W), radii (P) int32.
+ * store_bwd_state = 0 skips the bucket-state stores (no-grad / inference calls).
+ * P == 0 writes background / zeros and reports num_rendered = 0. */
+int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
+                const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp,
+                float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                void* geom, void* bin, int64_t entry_capacity, void* img,
+                int32_t store_bwd_state, hgs_status* status_host,
+                void* stream);
+
+/* ---- backward: replaces _C.rasterize_gaussians_backward ----------------------------
+ * `status` is a HOST copy of what hgs_forward reported (read after the stream has passed
+ * the forward).  out_* are the forward's outputs (unmodified), dL_dout_* the incoming
+ * gradients (any of them may be NULL = zeros).  Every dL_d* output that is non-NULL is
+ * fully overwritten (no pre-zeroing needed, no atomics: results are deterministic);
+ * dL_dmeans2D is (P,3) in NDC units with z = 0. */
+int hgs_backward(const hgs_settings* s, int32_t P, int32_t M,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const int32_t* radii,
+                 const float* out_color, const float* out_depth, const float* out_alpha,
+                 const float* dL_dout_color, const float* dL_dout_depth,
+                 const float* dL_dout_alpha,
+                 const void* geom, const void* bin, const void* img,
+                 const hgs_status* status, void* bwd_scratch,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                 float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                 float* dL_drotations, float* dL_dcov3D_precomp,
+                 void* stream);
+
+/* ---- frustum test: replaces _C.mark_visible ----------------------------------------
+ * present[i] = 1 iff the view-space depth of means3D[i] exceeds 0.2. */
+int hgs_mark_visible(const hgs_settings* s, int32_t P, const float* means3D,
+                     uint8_t* present, void* stream);
+
+/* Library / ABI version (bumped on any signature change). */
+int hgs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGS_RAST_H */

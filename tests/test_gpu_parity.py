@@ -1,0 +1,279 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical
+seeded inputs.  Tolerances are BASELINE.json's: |dRGB|, |dalpha| <= 1e-4, depth <= 1e-4 x
+max depth, gradients <= 1e-3 x max|oracle gradient| per tensor; radii / tile rects exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from abi_runner import RawCall
+from helpers import cov3d_from, make_scene, oracle_settings
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+def oracle_forward(scene, dtype=torch.float32, mod=1.0, colors_precomp=None, cov3D=None,
+                   grads=None, sh_degree=None):
+    st = oracle_settings(scene, mod)
+    if sh_degree is not None:
+        st = st._replace(sh_degree=sh_degree)
+    names = ["means3D", "opacities"]
+    ins = {"means3D": scene["means3D"], "opacities": scene["opacities"]}
+    if colors_precomp is None:
+        ins["shs"] = scene["shs"]
+    else:
+        ins["colors_precomp"] = colors_precomp
+    if cov3D is None:
+        ins["scales"], ins["rotations"] = scene["scales"], scene["rotations"]
+    else:
+        ins["cov3D_precomp"] = cov3D
+    ins = {k: v.to(dtype).clone().requires_grad_(grads is not None) for k, v in ins.items()}
+    P = scene["means3D"].shape[0]
+    m2d = torch.zeros(P, 3, dtype=dtype, requires_grad=grads is not None)
+    out = oracle.rasterize(ins["means3D"], m2d, ins.get("shs"), ins.get("colors_precomp"),
+                           ins["opacities"], ins.get("scales"), ins.get("rotations"),
+                           ins.get("cov3D_precomp"), st, dtype=dtype, return_aux=True)
+    color, radii, depth, alpha, aux = out
+    g = None
+    if grads is not None:
+        loss = sum((o * w.to(dtype)).sum() for o, w in zip((color, depth, alpha), grads) if w is not None)
+        tens = list(ins.values()) + [m2d]
+        gl = torch.autograd.grad(loss, tens, allow_unused=True)
+        g = {k: (torch.zeros_like(t) if x is None else x) for k, x, t in zip(list(ins) + ["means2D"], gl, tens)}
+    return color.detach(), radii, depth.detach(), alpha.detach(), aux, g
+
+
+def check_images(rc, ocolor, odepth, oalpha):
+    dmax = max(1.0, float(odepth.max()))
+    assert torch.isfinite(rc.color).all() and torch.isfinite(rc.depth).all() and torch.isfinite(rc.alpha).all()
+    ec = (rc.color.cpu() - ocolor.float()).abs().max().item()
+    ed = (rc.depth.cpu() - odepth.float()).abs().max().item()
+    ea = (rc.alpha.cpu() - oalpha.float()).abs().max().item()
+    assert ec <= IMG_TOL, f"color err {ec}"
+    assert ea <= IMG_TOL, f"alpha err {ea}"
+    assert ed <= IMG_TOL * dmax, f"depth err {ed}"
+
+
+def check_grads(got, ref):
+    for k, r in ref.items():
+        gk = got[k]
+        assert gk is not None, k
+        assert torch.isfinite(gk).all(), f"non-finite gradient {k}"
+        r = r.float().reshape(gk.shape)
+        scale = max(r.abs().max().item(), 1e-12)
+        err = (gk - r).abs().max().item()
+        assert err <= GRAD_TOL * scale, f"grad {k}: err {err:.3e} vs scale {scale:.3e}"
+        if r.abs().max() > 0:
+            cos = torch.nn.functional.cosine_similarity(gk.double().flatten(), r.double().flatten(), dim=0)
+            assert cos > 1 - 1e-5, f"grad {k}: cosine {cos}"
+
+
+def rand_grads(H, W, seed=1, with_alpha=True):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g),
+            torch.randn(1, H, W, generator=g) if with_alpha else None)
+
+
+# ----------------------------------------------------------------------------- forward
+
+@pytest.mark.parametrize("deg,M", [(0, 1), (1, 4), (2, 9), (3, 16), (0, 16), (2, 16)])
+def test_forward_sh_degrees(deg, M):
+    sc = make_scene(P=300, sh_degree=deg, M=M, seed=deg + 10 * M, H=64, W=80)
+    rc = RawCall(sc)
+    assert rc.forward() == 0 and not rc.status[4]
+    oc, orad, od, oa, aux, _ = oracle_forward(sc)
+    assert torch.equal(rc.radii.cpu(), orad)
+    check_images(rc, oc, od, oa)
+    assert rc.status[0] == int(aux["pre"]["tiles_touched"].sum())
+
+
+def test_preprocess_records_bitwise():
+    """Per-Gaussian quantities agree with the fp32 oracle bit-for-bit (same op order,
+    contraction off) - so ceil()/==/int() decisions can never flake."""
+    sc = make_scene(P=2000, sh_degree=3, seed=3, H=128, W=96, spread=0.6)
+    rc = RawCall(sc)
+    assert rc.forward() == 0
+    rec = rc.geom_records()
+    pre = oracle.preprocess(sc["means3D"], None, sc["shs"], None, sc["opacities"], sc["scales"],
+                            sc["rotations"], None, oracle_settings(sc))
+    vis = pre["visible"].numpy()
+    assert vis.sum() > 1000
+    assert np.array_equal(rec["radius"], pre["radii"].numpy())
+    for name, ref in (("mx", pre["mean2D"][:, 0]), ("my", pre["mean2D"][:, 1]),
+                      ("ca", pre["conic"][:, 0]), ("cb", pre["conic"][:, 1]),
+                      ("cc", pre["conic"][:, 2]), ("depth", pre["depth"])):
+        a, b = rec[name][vis], ref.numpy()[vis]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+    col = np.stack([rec["r"], rec["g"], rec["b"]], 1)[vis]
+    assert np.abs(col - pre["rgb"].numpy()[vis]).max() <= 1e-6
+    rect = pre["rect"].numpy()[vis]
+    assert np.array_equal(rec["rect_lo"][vis] & 0xFFFF, rect[:, 0])
+    assert np.array_equal(rec["rect_lo"][vis] >> 16, rect[:, 1])
+    assert np.array_equal(rec["rect_hi"][vis] & 0xFFFF, rect[:, 2])
+    assert np.array_equal(rec["rect_hi"][vis] >> 16, rect[:, 3])
+    # entry-id prefix = exclusive scan of tiles_touched in index order
+    tt = pre["tiles_touched"].numpy()
+    off = np.cumsum(tt) - tt
+    assert np.array_equal(rec["offset"][vis], off[vis].astype(np.uint32))
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (17, 33), (100, 60), (1, 1)])
+def test_forward_ragged_image_sizes(H, W):
+    sc = make_scene(P=150, seed=H * 100 + W, H=H, W=W)
+    rc = RawCall(sc)
+    assert rc.forward() == 0
+    oc, orad, od, oa, _, _ = oracle_forward(sc)
+    assert torch.equal(rc.radii.cpu(), orad)
+    check_images(rc, oc, od, oa)
+
+
+def test_forward_precomputed_inputs_and_scale_modifier():
+    sc = make_scene(P=250, sh_degree=0, seed=5)
+    colors = torch.rand(250, 3)
+    cov = cov3d_from(sc, mod=0.7)
+    rc = RawCall(sc, colors_precomp=colors, cov3D_precomp=cov)
+    assert rc.forward() == 0
+    oc, orad, od, oa, _, _ = oracle_forward(sc, colors_precomp=colors, cov3D=cov)
+    assert torch.equal(rc.radii.cpu(), orad)
+    check_images(rc, oc, od, oa)
+    rc2 = RawCall(sc, scale_modifier=0.7)
+    assert rc2.forward() == 0
+    oc2, orad2, od2, oa2, _, _ = oracle_forward(sc, mod=0.7)
+    assert torch.equal(rc2.radii.cpu(), orad2)
+    check_images(rc2, oc2, od2, oa2)
+
+
+def test_edge_cases_empty_culled_single():
+    sc = make_scene(P=1, seed=1)
+    for P in (0, 1):
+        s2 = dict(sc)
+        for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+            s2[k] = sc[k][:P]
+        rc = RawCall(s2)
+        assert rc.forward() == 0
+        oc, orad, od, oa, _, _ = oracle_forward(s2)
+        check_images(rc, oc, od, oa)
+        assert torch.equal(rc.radii.cpu(), orad)
+    # everything behind the camera -> background only, radii 0, R = 0
+    s3 = make_scene(P=100, seed=2)
+    s3["means3D"] = s3["means3D"] + torch.tensor(s3["cam"].camera_center) * 2.0
+    rc = RawCall(s3)
+    assert rc.forward() == 0
+    assert rc.status[0] == 0 and int(rc.radii.abs().sum()) == 0
+    assert torch.allclose(rc.color.cpu(), s3["bg"][:, None, None].expand_as(rc.color.cpu()))
+    assert float(rc.alpha.abs().max()) == 0.0 and float(rc.depth.abs().max()) == 0.0
+    g = rc.backward(*rand_grads(rc.H, rc.W))
+    for k, v in g.items():
+        if v is not None:
+            assert float(v.abs().max()) == 0.0, k
+
+
+def test_capacity_overflow_is_reported_and_retry_works():
+    sc = make_scene(P=400, seed=7)
+    rc = RawCall(sc, capacity=16)
+    assert rc.forward() == 0
+    assert rc.status[4] != 0 and rc.status[0] > 16          # overflow flagged, R reported
+    rc2 = RawCall(sc, capacity=rc.status[0])                 # exact fit
+    assert rc2.forward() == 0 and rc2.status[4] == 0
+    oc, orad, od, oa, _, _ = oracle_forward(sc)
+    check_images(rc2, oc, od, oa)
+
+
+@pytest.mark.parametrize("n", [700, 1500, 5000, 18000])
+def test_long_tile_lists_sort_classes_and_early_termination(n):
+    """Many Gaussians stacked over a few tiles: exercises the medium / large / global sort
+    classes, multi-bucket state, depth ties (duplicated points) and T < 1e-4 termination."""
+    g = torch.Generator().manual_seed(n)
+    sc = make_scene(P=n, seed=n, H=32, W=48, spread=0.02, scale=0.01, dist=2.0)
+    sc["means3D"][: n // 4] = sc["means3D"][n // 4: 2 * (n // 4)]      # exact depth ties
+    sc["opacities"] = 0.02 + 0.5 * torch.rand(n, 1, generator=g)
+    rc = RawCall(sc, capacity=max(8 * n, 1 << 16))
+    assert rc.forward() == 0 and not rc.status[4]
+    oc, orad, od, oa, aux, _ = oracle_forward(sc)
+    assert torch.equal(rc.radii.cpu(), orad)
+    assert int((aux["ranges"][:, 1] - aux["ranges"][:, 0]).max()) > min(n, 16384) * 0.5
+    check_images(rc, oc, od, oa)
+    ncon = np.frombuffer(rc.img[: rc.H * rc.W * 4].cpu().numpy().tobytes(), dtype=np.uint32).reshape(rc.H, rc.W)
+    assert np.array_equal(ncon, aux["n_contrib"].numpy().astype(np.uint32))
+
+
+# ---------------------------------------------------------------------------- backward
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_backward_vs_fp64_oracle(deg):
+    sc = make_scene(P=220, sh_degree=deg, seed=20 + deg, H=64, W=64)
+    rc = RawCall(sc)
+    assert rc.forward() == 0
+    grads = rand_grads(64, 64, seed=deg)
+    got = rc.backward(*grads)
+    *_, ref = oracle_forward(sc, dtype=torch.float64, grads=grads)
+    check_grads(got, ref)
+
+
+def test_backward_precomputed_inputs_and_scale_modifier():
+    sc = make_scene(P=180, sh_degree=0, seed=31)
+    colors = torch.rand(180, 3)
+    cov = cov3d_from(sc)
+    rc = RawCall(sc, colors_precomp=colors, cov3D_precomp=cov)
+    assert rc.forward() == 0
+    grads = rand_grads(rc.H, rc.W, seed=3)
+    got = rc.backward(*grads)
+    *_, ref = oracle_forward(sc, dtype=torch.float64, colors_precomp=colors, cov3D=cov, grads=grads)
+    check_grads(got, ref)
+    rc2 = RawCall(sc, scale_modifier=1.3)
+    assert rc2.forward() == 0
+    got2 = rc2.backward(*grads)
+    *_, ref2 = oracle_forward(sc, dtype=torch.float64, mod=1.3, grads=grads)
+    check_grads(got2, ref2)
+
+
+def test_backward_multibucket_termination_and_bg():
+    """Lists of several buckets with early termination, non-zero background, and only some
+    of the three output gradients present."""
+    n = 1200
+    g = torch.Generator().manual_seed(5)
+    sc = make_scene(P=n, seed=77, H=32, W=32, spread=0.03, scale=0.012, bg=(0.9, 0.5, 0.2))
+    sc["opacities"] = 0.05 + 0.6 * torch.rand(n, 1, generator=g)
+    rc = RawCall(sc)
+    assert rc.forward() == 0
+    for grads in (rand_grads(32, 32, 9), (rand_grads(32, 32, 10)[0], None, None),
+                  (None, rand_grads(32, 32, 11)[1], None)):
+        got = rc.backward(*grads)
+        *_, ref = oracle_forward(sc, dtype=torch.float64, grads=grads)
+        check_grads(got, ref)
+
+
+def test_backward_frustum_clamp_quirk():
+    """Gaussians beyond 1.3 x tan(fov) take the clamped-Jacobian branch."""
+    sc = make_scene(P=120, seed=41, H=48, W=48, spread=1.6, scale=0.5, fovy=25.0, dist=1.2)
+    rc = RawCall(sc)
+    assert rc.forward() == 0
+    assert (rc.geom_records()["flags"] != 0).sum() > 3
+    grads = rand_grads(48, 48, seed=2)
+    got = rc.backward(*grads)
+    oc, orad, od, oa, _, ref = oracle_forward(sc, dtype=torch.float64, grads=grads)
+    assert torch.equal(rc.radii.cpu(), oracle_forward(sc)[1])
+    check_grads(got, ref)
+
+
+def test_backward_is_deterministic_and_linear():
+    sc = make_scene(P=600, sh_degree=1, seed=51, H=64, W=64, spread=0.2)
+    rc = RawCall(sc)
+    assert rc.forward() == 0
+    g1, g2 = rand_grads(64, 64, 1), rand_grads(64, 64, 2)
+    a = rc.backward(*g1)
+    b = rc.backward(*g1)
+    for k in a:
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), f"{k} not bitwise reproducible"
+    c = rc.backward(*g2)
+    s = rc.backward(*[x + y for x, y in zip(g1, g2)])
+    for k in a:
+        if a[k] is not None:
+            ref = a[k] + c[k]
+            assert (s[k] - ref).abs().max() <= 1e-4 * max(1e-9, ref.abs().max()), k
