@@ -30,6 +30,7 @@ from __future__ import annotations
 import math
 from typing import NamedTuple, Optional
 
+import numpy as np
 import torch
 
 TILE = 16
@@ -131,8 +132,14 @@ def preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotatio
     H, W = int(settings.image_height), int(settings.image_width)
     P = means3D.shape[0]
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
-    fx = W / (2.0 * settings.tanfovx)
-    fy = H / (2.0 * settings.tanfovy)
+    # scalars are formed the way the host code of the rasterizer forms them: the tangents
+    # arrive as fp32, focal = W / (2 * tan) and the 1.3x frustum limit are fp32 products
+    ft = np.float32 if dtype == torch.float32 else np.float64
+    tanx, tany = ft(np.float32(settings.tanfovx)), ft(np.float32(settings.tanfovy))
+    fx = float(ft(W) / (ft(2.0) * tanx))
+    fy = float(ft(H) / (ft(2.0) * tany))
+    limx, limy = float(ft(np.float32(1.3)) * tanx), float(ft(np.float32(1.3)) * tany)
+    tanx, tany = float(tanx), float(tany)
 
     x, y, z = means3D[:, 0], means3D[:, 1], means3D[:, 2]
     tx0 = V[0, 0] * x + V[1, 0] * y + V[2, 0] * z + V[3, 0]
@@ -153,12 +160,11 @@ def preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotatio
     if cov3D_precomp is not None and cov3D_precomp.numel() > 0:
         c0, c1, c2, c3, c4, c5 = (cov3D_precomp[:, i] for i in range(6))
     else:
-        c0, c1, c2, c3, c4, c5 = _cov3d_from_scale_rot(scales, rotations,
-                                                       float(settings.scale_modifier))
+        c0, c1, c2, c3, c4, c5 = _cov3d_from_scale_rot(
+            scales, rotations, float(np.float32(settings.scale_modifier)))
 
     # EWA projection with the frustum clamp (value AND gradient quirk)
     tz_safe = torch.where(in_front, tz, torch.ones_like(tz))
-    limx, limy = 1.3 * settings.tanfovx, 1.3 * settings.tanfovy
     txtz, tytz = tx0 / tz_safe, ty0 / tz_safe
     vx = torch.clamp(txtz, -limx, limx) * tz_safe
     vy = torch.clamp(tytz, -limy, limy) * tz_safe
@@ -168,10 +174,13 @@ def preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotatio
     tx = torch.where(clx, vx.detach(), tx0 + (vx - tx0).detach())
     ty = torch.where(cly, vy.detach(), ty0 + (vy - ty0).detach())
 
-    J00 = fx / tz_safe
-    J02 = -(fx * tx) / (tz_safe * tz_safe)
-    J11 = fy / tz_safe
-    J12 = -(fy * ty) / (tz_safe * tz_safe)
+    # NB: torch evaluates `python_scalar / tensor` as reciprocal(tensor) * scalar, which
+    # rounds differently from a true division - divide tensor by tensor instead.
+    fx_t, fy_t = torch.full_like(tz_safe, fx), torch.full_like(tz_safe, fy)
+    J00 = fx_t / tz_safe
+    J02 = -(fx_t * tx) / (tz_safe * tz_safe)
+    J11 = fy_t / tz_safe
+    J12 = -(fy_t * ty) / (tz_safe * tz_safe)
     M00, M01, M02 = (J00 * V[0, 0] + J02 * V[0, 2], J00 * V[1, 0] + J02 * V[1, 2],
                      J00 * V[2, 0] + J02 * V[2, 2])
     M10, M11, M12 = (J11 * V[0, 1] + J12 * V[0, 2], J11 * V[1, 1] + J12 * V[1, 2],

@@ -1,0 +1,87 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/hgs_rast.h declares (no compute calls - there is no GPU here), the sizing
+functions behave, and the Python API mirrors the reference's names / errors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from humangaussian_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "hgs_rast.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|size_t)\s+(hgs_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.EXPORTS), (declared, set(_lib.EXPORTS))
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.hgs_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.HgsStatus) == 32
+    s = _lib.HgsSettings
+    assert [f[0] for f in s._fields_] == [
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+        "projmatrix", "sh_degree", "campos", "prefiltered", "debug"]
+    # natural C layout on LP64: 4+4+4+4 | 8 | 4(+4) | 8 | 8 | 4(+4) | 8 | 4+4
+    assert ctypes.sizeof(s) == 72 and s.bg.offset == 16 and s.viewmatrix.offset == 32
+    assert s.campos.offset == 56 and s.debug.offset == 68
+
+
+def test_buffer_sizing(lib):
+    g = lib.hgs_geom_bytes(100000, 1024, 1024)
+    assert g >= 100000 * 64 + 6 * 4096 * 4 and g % 256 == 0
+    assert lib.hgs_geom_bytes(0, 16, 16) > 0 and lib.hgs_geom_bytes(-1, 16, 16) == 0
+    assert lib.hgs_img_bytes(1024, 1024) == 1024 * 1024 * 4
+    b1, b2 = lib.hgs_bin_bytes(1 << 20), lib.hgs_bin_bytes(1 << 21)
+    assert b1 >= (1 << 20) * (8 + 48 + 96) and abs(b2 - 2 * b1) <= 4096
+    assert lib.hgs_bin_bytes(0) == 0
+    assert lib.hgs_bwd_scratch_bytes(1000) >= 48000
+
+
+def test_argument_validation_without_gpu(lib):
+    s = _lib.HgsSettings()
+    assert lib.hgs_forward(ctypes.byref(s), 1, 1, *([None] * 13), 0, None, 0, None, None) == -1
+    assert lib.hgs_mark_visible(None, 1, None, None, None) == -1
+
+
+def test_python_api_mirrors_reference_names_and_errors():
+    import diff_gaussian_rasterization as dgr
+    from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
+    assert dgr.GaussianRasterizer is GaussianRasterizer
+    assert GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+        "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    rs = GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0,
+                                       torch.zeros(3), False, False)
+    r = GaussianRasterizer(raster_settings=rs)
+    m = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 1, 3))
+    # the product path has no CPU fallback: CPU tensors fail loudly
+    with pytest.raises(RuntimeError, match="HIP device"):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=torch.zeros(4, 1, 3),
+          scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "humangaussian_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
