@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py - rasterize fwd+bwd Gaussians/s @1024^2, 100k points (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path per rank: forward + backward of ONE 1024^2 view of the
+100k-Gaussian SMPL-X-like cloud through the reference-compatible API
+(GaussianRasterizer -> libhgs_rast.so), inputs resident in HBM, plus - for N>1 - the single
+all-gather of the per-rank gradient packs (view-parallel, weak scaling: one view per rank).
+value = P * N * K / t, t = max over ranks of the barrier-bracketed wall time of K steps.
+
+Extra objects on the JSON line: `roofline` (dominant kernel, timed live with HIP events
+recorded by the library on its launch stream) and `cpu_baseline` (the PyTorch CPU oracle,
+one fwd+bwd of the same view on the host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, synth  # noqa: E402
+from humangaussian_amd import rasterizer as _rast  # noqa: E402
+from humangaussian_amd import view_parallel as vp  # noqa: E402
+
+P_POINTS = 100_000
+RES = 1024
+SH_DEGREE = 0
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+
+FWD_STAGES = ["preprocess_fwd", "scan", "fill", "sort", "render_fwd"]
+BWD_STAGES = ["render_bwd", "preprocess_bwd"]
+
+
+def algorithmic_bytes(stage, P, M, R, npix, T):
+    """Per-launch algorithmic bytes, SURVEY.md 8(d) terms split by stage."""
+    return {
+        "preprocess_fwd": P * (44 + 12 * M + 76),
+        "scan": 8 * T + 8 * ((P + 255) // 256),
+        "fill": P * 16 + 12 * R,
+        "sort": 24 * R,
+        "render_fwd": 44 * R + 24 * npix,
+        "render_bwd": 84 * R + 28 * npix,
+        "preprocess_bwd": P * (116 + 12 * M + 56 + 12 * M) + 40 * R,
+    }[stage]
+
+
+def camera_for_rank(r):
+    return synth.orbit_camera(10.0, 30.0 + 45.0 * r, 1.75, 55.0, RES, RES)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--points", type=int, default=P_POINTS)
+    ap.add_argument("--variant", default="mid", choices=["mid", "init"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    P = args.points
+    cloud = synth.init_cloud(P, SH_DEGREE, args.variant, seed=0)
+    M = cloud.shs.shape[1]
+    cam = camera_for_rank(rank)
+    leaves = {k: getattr(cloud, k).to(dev).requires_grad_(True)
+              for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    bg = torch.zeros(3, device=dev)
+    rs = GaussianRasterizationSettings(
+        RES, RES, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+        cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), SH_DEGREE,
+        cam.camera_center.to(dev), False, False)
+    rasterizer = GaussianRasterizer(rs)
+    g = torch.Generator().manual_seed(1 + rank)
+    gc = (torch.randn(3, RES, RES, generator=g) * 1e-3).to(dev)
+    gd = (torch.randn(1, RES, RES, generator=g) * 1e-3).to(dev)
+    ga = (torch.randn(1, RES, RES, generator=g) * 1e-3).to(dev)
+
+    def step():
+        for t in leaves.values():
+            t.grad = None
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        color, radii, depth, alpha = rasterizer(
+            means3D=leaves["means3D"], means2D=means2D, shs=leaves["shs"],
+            opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"])
+        torch.autograd.backward([color, depth, alpha], [gc, gd, ga])
+        if world > 1:
+            grads = {k: leaves[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+            grads["means2D"] = means2D.grad
+            total = vp.allgather_reduce(vp.pack_contribution(grads, radii))
+            return total
+        return means2D.grad
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---------------- per-kernel timing (outside the timed region; library-recorded events)
+    nprof = 20
+    fwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    bwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for e in fwd_ev + bwd_ev:
+        e.record()
+    torch.cuda.synchronize()
+    _rast.set_stage_events([e.cuda_event for e in fwd_ev], [e.cuda_event for e in bwd_ev])
+    acc = {k: 0.0 for k in FWD_STAGES + BWD_STAGES}
+    for _ in range(nprof):
+        step()
+        torch.cuda.synchronize()
+        for i, k in enumerate(FWD_STAGES):
+            acc[k] += fwd_ev[i].elapsed_time(fwd_ev[i + 1])
+        for i, k in enumerate(BWD_STAGES):
+            acc[k] += bwd_ev[i].elapsed_time(bwd_ev[i + 1])
+    _rast.set_stage_events(None, None)
+    stage_us = {k: v / nprof * 1e3 for k, v in acc.items()}
+    R = _rast._state(dev).status_pinned[0].item() & 0xFFFFFFFF
+    npix, T = RES * RES, (RES // 16) ** 2
+    dom = max(stage_us, key=stage_us.get)
+    dom_bytes = algorithmic_bytes(dom, P, M, R, npix, T)
+    achieved = dom_bytes / (stage_us[dom] * 1e-6) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    path_bytes = P * (292 + 36 * M) + 164 * R + 52 * npix + 8 * T
+    gpu_us = sum(stage_us.values())
+
+    # ---------------- CPU baseline: the PyTorch oracle on the host cores (rank 0, N=1)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        torch.set_num_threads(os.cpu_count() or 1)
+        st = oracle.OracleSettings(RES, RES, rs.tanfovx, rs.tanfovy, torch.zeros(3), 1.0,
+                                   cam.world_view_transform, cam.full_proj_transform, SH_DEGREE,
+                                   cam.camera_center, False, False)
+        ins = [getattr(cloud, k).clone().requires_grad_(True)
+               for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        tc = time.perf_counter()
+        c, _, d, a = oracle.rasterize(ins[0], None, ins[1], None, ins[2], ins[3], ins[4], None, st)
+        ((c * gc.cpu()).sum() + (d * gd.cpu()).sum() + (a * ga.cpu()).sum()).backward()
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": P / tcpu, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"1 fwd+bwd of the same {P}-Gaussian 1024^2 view by the PyTorch CPU oracle "
+                         f"({tcpu:.1f} s, torch {torch.__version__}, {torch.get_num_threads()} threads)"}
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "rasterize fwd+bwd Gaussians/sec @1024^2, 100k pts",
+            "value": P * world * args.steps / elapsed,
+            "unit": "Gaussians/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {P} SMPL-X-like Gaussians ({args.variant}-training "
+                                   f"state, SH degree {SH_DEGREE}), one 1024x1024 orbit view per GPU "
+                                   "(elev 10, azim 30+45*rank, dist 1.75, fovy 55), fwd+bwd",
+                       "views_per_step": world, "num_rendered_R": int(R),
+                       "parallelism": f"view-parallel x{world}" + (", 1 all-gather/step" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes": dom_bytes, "avg_us": stage_us[dom],
+                         "note": "blend kernels are VALU-bound (no dense contraction, no MFMA); "
+                                 "HBM fraction reported as BASELINE.json asks",
+                         "path": {"algorithmic_bytes": path_bytes, "gpu_us_sum": gpu_us,
+                                  "achieved": path_bytes / (gpu_us * 1e-6) / 1e9,
+                                  "frac": path_bytes / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
+            "stage_us": stage_us,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

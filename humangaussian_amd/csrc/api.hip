@@ -112,6 +112,14 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? HGS_OK : -(1000 + (in
     if (e__ != hipSuccess) return hip_rc(e__);   \
   } while (0)
 
+#define HGS_STAGE(k)                                                              \
+  do {                                                                            \
+    if (stage_events && stage_events[k]) {                                        \
+      hipError_t e__ = hipEventRecord(static_cast<hipEvent_t>(stage_events[k]), stream); \
+      if (e__ != hipSuccess) return hip_rc(e__);                                  \
+    }                                                                             \
+  } while (0)
+
 bool settings_ok(const hgs_settings* s) {
   return s && s->image_height > 0 && s->image_width > 0 && s->bg && s->viewmatrix &&
          s->projmatrix && s->campos && s->sh_degree >= 0 && s->sh_degree <= 3 &&
@@ -122,7 +130,7 @@ bool settings_ok(const hgs_settings* s) {
 
 extern "C" {
 
-int hgs_abi_version(void) { return 1; }
+int hgs_abi_version(void) { return 2; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;
@@ -142,7 +150,8 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                 const float* scales, const float* rotations, const float* cov3D_precomp,
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 void* geom, void* bin, int64_t entry_capacity, void* img,
-                int32_t store_bwd_state, hgs_status* status_host, void* stream_) {
+                int32_t store_bwd_state, hgs_status* status_host, void* const* stage_events,
+                void* stream_) {
   if (!settings_ok(s) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
     return HGS_EINVAL;
@@ -161,6 +170,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
   hgs_status* status_dev =
       reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(P, v.H, v.W).status);
 
+  HGS_STAGE(0);
   hipError_t e = hipMemsetAsync(L.tile_count, 0, (size_t)v.T * 4, stream);
   if (e != hipSuccess) return hip_rc(e);
   if (v.nblk > 0) {
@@ -169,11 +179,14 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                        cov3D_precomp, radii);
     HGS_LAUNCH_CHECK();
   }
+  HGS_STAGE(1);
   hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev);
   HGS_LAUNCH_CHECK();
+  HGS_STAGE(2);
   if (v.nblk > 0 && entry_capacity > 0) {
     hipLaunchKernelGGL(hgs_k_fill, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
+    HGS_STAGE(3);
     // tiles are ordered heavy-first, so a class with more than LO entries per tile can only
     // occupy the first capacity/LO positions of tile_order
     auto class_grid = [&](int64_t lo) {
@@ -189,6 +202,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     hipLaunchKernelGGL(hgs_k_sort_small, dim3(v.T), dim3(256), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
   }
+  HGS_STAGE(4);
   if (store_bwd_state)
     hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T), dim3(256), 0, stream, v, L, status_dev,
                        out_color, out_depth, out_alpha);
@@ -196,6 +210,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T), dim3(256), 0, stream, v, L,
                        status_dev, out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
+  HGS_STAGE(5);
   if (status_host) {
     e = hipMemcpyAsync(status_host, status_dev, sizeof(hgs_status), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return hip_rc(e);
@@ -212,7 +227,8 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
                  const void* bin, const void* img, const hgs_status* status,
                  void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                  float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
-                 float* dL_drotations, float* dL_dcov3D_precomp, void* stream_) {
+                 float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
+                 void* stream_) {
   (void)opacities; (void)radii;
   if (!settings_ok(s) || P < 0 || !status || !geom || !img) return HGS_EINVAL;
   if (status->overflow) return HGS_EINVAL;
@@ -231,6 +247,7 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
   const Layout L = make_layout(const_cast<void*>(geom), const_cast<void*>(bin),
                                const_cast<void*>(img), P, v.H, v.W, cap);
   float* rows = static_cast<float*>(bwd_scratch);
+  HGS_STAGE(0);
   if (status->bwd_groups > 0) {
     hipLaunchKernelGGL(hgs_k_render_bwd, dim3(status->bwd_groups), dim3(256), 0, stream, v, L,
                        out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
@@ -242,6 +259,7 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
                      dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales,
                      dL_drotations, dL_dcov3D_precomp);
   HGS_LAUNCH_CHECK();
+  HGS_STAGE(2);
   return HGS_OK;
 }
 

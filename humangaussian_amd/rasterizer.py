@@ -103,6 +103,21 @@ def _check(rc: int, what: str):
         raise RuntimeError(f"libhgs_rast: {what} failed with code {rc}")
 
 
+# Measurement hook (bench.py only): arrays of hipEvent_t handles recorded after each stage
+# of the next forward / backward calls (see HGS_FWD_STAGES / HGS_BWD_STAGES in hgs_rast.h).
+_stage_events = {"fwd": None, "bwd": None}
+
+
+def set_stage_events(fwd=None, bwd=None):
+    """fwd / bwd: sequences of raw hipEvent_t handles (ints) or None to disable."""
+    def mk(seq):
+        if seq is None:
+            return None
+        arr = (ctypes.c_void_p * len(seq))(*[ctypes.c_void_p(int(h)) for h in seq])
+        return arr
+    _stage_events["fwd"], _stage_events["bwd"] = mk(fwd), mk(bwd)
+
+
 def _round_capacity(n: int) -> int:
     return max(1 << 16, (int(n) + 0xFFFF) & ~0xFFFF)
 
@@ -160,7 +175,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(color), _ptr(depth), _ptr(alpha),
                     _ptr(radii), _ptr(geom), _ptr(binbuf), cap, _ptr(img),
                     1 if want_grad else 0, ctypes.c_void_p(st.status_pinned.data_ptr()),
-                    ctypes.c_void_p(stream.cuda_stream))
+                    _stage_events["fwd"], ctypes.c_void_p(stream.cuda_stream))
                 if rc == -2:
                     raise RuntimeError("inconsistent optional inputs (shs/colors_precomp, "
                                        "scales+rotations/cov3D_precomp)")
@@ -227,7 +242,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _ptr(color), _ptr(depth), _ptr(alpha), _ptr(gc), _ptr(gd), _ptr(ga),
                 _ptr(geom), _ptr(binbuf), _ptr(img), ctypes.byref(st), _ptr(scratch),
                 _ptr(d_means3D), _ptr(d_means2D), _ptr(d_sh), _ptr(d_cp), _ptr(d_opac),
-                _ptr(d_sc), _ptr(d_ro), _ptr(d_cv), ctypes.c_void_p(stream.cuda_stream))
+                _ptr(d_sc), _ptr(d_ro), _ptr(d_cv), _stage_events["bwd"],
+                ctypes.c_void_p(stream.cuda_stream))
             _check(rc, "hgs_backward")
         return (d_means3D, d_means2D, d_sh, d_cp, d_opac, d_sc, d_ro, d_cv, None, None)
 

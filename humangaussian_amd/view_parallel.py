@@ -1,0 +1,144 @@
+"""View-parallel multi-GPU rendering: one process per GPU, views sharded round-robin,
+Gaussian parameters replicated, ONE collective per step.
+
+The reference renders its B views sequentially on one GPU and accumulates, per Gaussian,
+  * parameter gradients (autograd sums them over views),
+  * `radii` max over views                     (threestudio/systems/GaussianDreamer.py:253-256),
+  * `viewspace_points.grad` summed over views   (GaussianDreamer.py:385-387),
+so views are independent units.  Here rank r renders views r, r+G, ...;
+each rank packs its per-Gaussian contribution into one (P, F) fp32 tensor
+[means3D 3 | means2D 3 | sh 3M | opacity 1 | scales 3 | rotations 4 | radii 1]
+and a single all-gather (RCCL over xGMI; gloo in the CPU tests) hands every rank all G
+packs; the reduction (sum / max) is then done locally in rank order, so the result is
+bit-identical on every rank and independent of arrival order.
+
+A direct all-gather of a 6.8 MB pack rides the 7 point-to-point xGMI links in parallel
+(about 45 us at 153 GB/s per link) - a ring all-reduce would be per-link bound.
+The rasterizer is passed in (`render_fn`) so the host logic is testable without a GPU;
+the default is the HIP rasterizer and there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+GRAD_KEYS = ("means3D", "means2D", "shs", "opacities", "scales", "rotations")
+
+
+def shard_views(num_views: int, rank: int, world: int) -> List[int]:
+    """View v belongs to rank v mod world (frames of an animation shard the same way)."""
+    return list(range(rank, num_views, world))
+
+
+def pack_contribution(grads: Dict[str, torch.Tensor], radii: torch.Tensor) -> torch.Tensor:
+    """(P, F) fp32 pack.  radii (int32) travel as exact fp32 integers (< 2^24)."""
+    P = radii.shape[0]
+    cols = [grads[k].reshape(P, -1).float() for k in GRAD_KEYS]
+    cols.append(radii.reshape(P, 1).float())
+    return torch.cat(cols, dim=1).contiguous()
+
+
+def unpack_contribution(pack: torch.Tensor, shapes: Dict[str, torch.Size]):
+    out, c = {}, 0
+    P = pack.shape[0]
+    for k in GRAD_KEYS:
+        n = int(torch.Size(shapes[k]).numel() // max(P, 1)) if P else 0
+        out[k] = pack[:, c:c + n].reshape(shapes[k])
+        c += n
+    radii = pack[:, c].round().to(torch.int32)
+    return out, radii
+
+
+def allgather_reduce(pack: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather every rank's pack, then reduce locally in rank order:
+    gradient columns are summed, the last column (radii) takes the max."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return pack
+    world = dist.get_world_size(group)
+    gathered = torch.empty((world,) + tuple(pack.shape), dtype=pack.dtype, device=pack.device)
+    dist.all_gather_into_tensor(gathered, pack, group=group)
+    total = gathered[0].clone()
+    for r in range(1, world):                     # fixed order => deterministic sum
+        total[:, :-1] += gathered[r][:, :-1]
+        total[:, -1] = torch.maximum(total[:, -1], gathered[r][:, -1])
+    return total
+
+
+def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg: torch.Tensor,
+                          sh_degree: int, loss_grad_fn: Callable, render_fn: Optional[Callable] = None,
+                          group=None, gather_images: bool = False):
+    """One training-style step over `cameras` (the global list, identical on every rank).
+
+    params        replicated leaf tensors: means3D, shs, opacities, scales, rotations
+    loss_grad_fn  (view_index, color, depth, alpha) -> (dL/dcolor, dL/ddepth, dL/dalpha)
+    render_fn     (camera, params, means2D, bg, sh_degree) -> (color, radii, depth, alpha);
+                  defaults to the HIP rasterizer.
+    Returns (grads dict summed over ALL views, radii max over all views, local outputs).
+    """
+    if render_fn is None:
+        render_fn = hip_render_fn
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    mine = shard_views(len(cameras), rank, world)
+    leaves = {k: params[k].detach().requires_grad_(True) for k in
+              ("means3D", "shs", "opacities", "scales", "rotations")}
+    P = leaves["means3D"].shape[0]
+    acc = {k: torch.zeros_like(leaves[k]) for k in leaves}
+    acc["means2D"] = torch.zeros_like(leaves["means3D"])
+    radii_max = torch.zeros(P, dtype=torch.int32, device=leaves["means3D"].device)
+    outputs = []
+    for v in mine:
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        color, radii, depth, alpha = render_fn(cameras[v], leaves, means2D, bg, sh_degree)
+        gc, gd, ga = loss_grad_fn(v, color.detach(), depth.detach(), alpha.detach())
+        tens = [leaves[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")] + [means2D]
+        outs, gouts = [], []
+        for o, g in ((color, gc), (depth, gd), (alpha, ga)):
+            if g is not None:
+                outs.append(o); gouts.append(g)
+        gl = torch.autograd.grad(outs, tens, gouts, allow_unused=True)
+        for k, g in zip(("means3D", "shs", "opacities", "scales", "rotations", "means2D"), gl):
+            if g is not None:
+                acc[k] += g
+        radii_max = torch.maximum(radii_max, radii)
+        outputs.append((v, color.detach(), depth.detach(), alpha.detach()))
+    shapes = {k: acc[k].shape for k in GRAD_KEYS}
+    total = allgather_reduce(pack_contribution(acc, radii_max), group)
+    grads, radii_all = unpack_contribution(total, shapes)
+    if gather_images and world > 1:
+        outputs = gather_view_images(outputs, len(cameras), group)
+    return grads, radii_all, outputs
+
+
+def gather_view_images(outputs, num_views: int, group=None):
+    """Optional forward collective: all-gather the [color|depth|alpha] slab (5,H,W) of each
+    rank's views so every rank holds all views (only needed when the consumer is not
+    view-separable; the SDS loss is)."""
+    world = dist.get_world_size(group)
+    per_rank = (num_views + world - 1) // world
+    v0, c0, d0, a0 = outputs[0]
+    slab = torch.zeros((per_rank, 5) + tuple(c0.shape[1:]), dtype=c0.dtype, device=c0.device)
+    for i, (_, c, d, a) in enumerate(outputs):
+        slab[i, :3], slab[i, 3:4], slab[i, 4:5] = c, d, a
+    allslab = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
+    dist.all_gather_into_tensor(allslab, slab, group=group)
+    res = []
+    for v in range(num_views):
+        s = allslab[v % world, v // world]
+        res.append((v, s[:3], s[3:4], s[4:5]))
+    return res
+
+
+def hip_render_fn(cam, leaves, means2D, bg, sh_degree):
+    """Default render_fn: the HIP rasterizer behind the reference API."""
+    import math
+    from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    rs = GaussianRasterizationSettings(
+        int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx * 0.5),
+        math.tan(cam.FoVy * 0.5), bg, 1.0, cam.world_view_transform, cam.full_proj_transform,
+        sh_degree, cam.camera_center, False, False)
+    return GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=means2D, shs=leaves["shs"],
+                                  opacities=leaves["opacities"], scales=leaves["scales"],
+                                  rotations=leaves["rotations"])

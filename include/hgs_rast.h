@@ -71,6 +71,13 @@ size_t hgs_bin_bytes(int64_t entry_capacity);
 size_t hgs_img_bytes(int32_t image_height, int32_t image_width);
 size_t hgs_bwd_scratch_bytes(int64_t num_rendered);
 
+/* Optional per-stage timing (measurement only; pass NULL in production): `stage_events`
+ * is a HOST array of hipEvent_t handles; entry k (if non-NULL) is recorded on `stream`
+ * after stage k.  Forward: 0 start, 1 preprocess, 2 scan, 3 fill, 4 sort, 5 blend.
+ * Backward: 0 start, 1 blend backward, 2 preprocess backward. */
+#define HGS_FWD_STAGES 6
+#define HGS_BWD_STAGES 3
+
 /* ---- forward: replaces _C.rasterize_gaussians --------------------------------------
  * Exactly one of shs / colors_precomp and exactly one of {scales,rotations} /
  * cov3D_precomp must be non-NULL (HGS_ESHAPE otherwise), matching the fork's Python
@@ -85,7 +92,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 void* geom, void* bin, int64_t entry_capacity, void* img,
                 int32_t store_bwd_state, hgs_status* status_host,
-                void* stream);
+                void* const* stage_events, void* stream);
 
 /* ---- backward: replaces _C.rasterize_gaussians_backward ----------------------------
  * `status` is a HOST copy of what hgs_forward reported (read after the stream has passed
@@ -105,7 +112,7 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                  float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                  float* dL_drotations, float* dL_dcov3D_precomp,
-                 void* stream);
+                 void* const* stage_events, void* stream);
 
 /* ---- frustum test: replaces _C.mark_visible ----------------------------------------
  * present[i] = 1 iff the view-space depth of means3D[i] exceeds 0.2. */

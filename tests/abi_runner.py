@@ -71,7 +71,7 @@ class RawCall:
                              _p(self.cov3D), _p(self.color), _p(self.depth), _p(self.alpha),
                              _p(self.radii), _p(self.geom), _p(self.bin), self.capacity,
                              _p(self.img), 1 if self.store else 0,
-                             ctypes.c_void_p(self.status_host.data_ptr()),
+                             ctypes.c_void_p(self.status_host.data_ptr()), None,
                              ctypes.c_void_p(stream.cuda_stream))
         stream.synchronize()
         self.rc = rc
@@ -105,7 +105,7 @@ class RawCall:
                               _p(self.img), ctypes.byref(st), _p(scratch), _p(out["means3D"]),
                               _p(out["means2D"]), _p(out["shs"]), _p(out["colors_precomp"]),
                               _p(out["opacities"]), _p(out["scales"]), _p(out["rotations"]),
-                              _p(out["cov3D_precomp"]), ctypes.c_void_p(stream.cuda_stream))
+                              _p(out["cov3D_precomp"]), None, ctypes.c_void_p(stream.cuda_stream))
         stream.synchronize()
         assert rc == 0, rc
         return {k: (None if v is None else v.cpu()) for k, v in out.items()}
