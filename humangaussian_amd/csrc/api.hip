@@ -16,10 +16,12 @@
 namespace {
 
 constexpr size_t ALIGN = 256;
+constexpr size_t HGS_LDS_BINS_MAX = 16384;   // T*4 bytes of LDS <= 64 KB
+constexpr int HGS_MAX_BIN_WGS = 256;
 
 struct GeomCarve {
   size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
-      tile_wgstart, tile_maxcontrib, status, total;
+      tile_wgstart, tile_maxcontrib, hist, status, total;
 };
 
 inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
@@ -39,6 +41,7 @@ GeomCarve carve_geom(int P, int H, int W) {
   c.tile_bstart = take((T + 1) * 4);
   c.tile_wgstart = take((T + 1) * 4);
   c.tile_maxcontrib = take(T * 4);
+  c.hist = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_MAX_BIN_WGS * T * 4 : 0);
   c.status = take(sizeof(hgs_status));
   c.total = off;
   return c;
@@ -73,6 +76,7 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.tile_bstart = reinterpret_cast<uint32_t*>(gp + g.tile_bstart);
   L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
   L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
+  L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
@@ -100,6 +104,10 @@ View make_view(const hgs_settings* s, int P, int M, int64_t cap) {
   v.M = M;
   v.D = s->sh_degree;
   v.nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  v.lds_bins = (size_t)v.T <= HGS_LDS_BINS_MAX ? 1 : 0;
+  v.cpw = v.lds_bins ? (v.nblk + HGS_MAX_BIN_WGS - 1) / HGS_MAX_BIN_WGS : 1;
+  if (v.cpw < 1) v.cpw = 1;
+  v.nwg = (v.nblk + v.cpw - 1) / v.cpw;
   v.entry_capacity = (uint32_t)(cap < 0 ? 0 : (cap > 0xffffffffll ? 0xffffffffll : cap));
   return v;
 }
@@ -171,20 +179,38 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
       reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(P, v.H, v.W).status);
 
   HGS_STAGE(0);
-  hipError_t e = hipMemsetAsync(L.tile_count, 0, (size_t)v.T * 4, stream);
-  if (e != hipSuccess) return hip_rc(e);
+  hipError_t e = hipSuccess;
+  const size_t lds_bytes = (size_t)v.T * 4;
+  if (!v.lds_bins) {
+    e = hipMemsetAsync(L.tile_count, 0, (size_t)v.T * 4, stream);
+    if (e != hipSuccess) return hip_rc(e);
+  }
   if (v.nblk > 0) {
-    hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
-                       means3D, shs, colors_precomp, opacities, scales, rotations,
-                       cov3D_precomp, radii);
+    if (v.lds_bins)
+      hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v,
+                         L, means3D, shs, colors_precomp, opacities, scales, rotations,
+                         cov3D_precomp, radii);
+    else
+      hipLaunchKernelGGL(hgs_k_preprocess_fwd_ga, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
+                         means3D, shs, colors_precomp, opacities, scales, rotations,
+                         cov3D_precomp, radii);
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(1);
+  if (v.lds_bins) {
+    hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256), dim3(256), 0, stream, v, L);
+    HGS_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
   if (v.nblk > 0 && entry_capacity > 0) {
-    hipLaunchKernelGGL(hgs_k_fill, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, status_dev);
+    if (v.lds_bins)
+      hipLaunchKernelGGL(hgs_k_fill, dim3(v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v, L,
+                         status_dev);
+    else
+      hipLaunchKernelGGL(hgs_k_fill_ga, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
+                         status_dev);
     HGS_LAUNCH_CHECK();
     HGS_STAGE(3);
     // tiles are ordered heavy-first, so a class with more than LO entries per tile can only
@@ -205,10 +231,10 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
   HGS_STAGE(4);
   if (store_bwd_state)
     hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T), dim3(256), 0, stream, v, L, status_dev,
-                       out_color, out_depth, out_alpha);
+                       L.recs, L.bstate, out_color, out_depth, out_alpha);
   else
     hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T), dim3(256), 0, stream, v, L,
-                       status_dev, out_color, out_depth, out_alpha);
+                       status_dev, L.recs, L.bstate, out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(5);
   if (status_host) {
@@ -250,10 +276,11 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
   HGS_STAGE(0);
   if (status->bwd_groups > 0) {
     hipLaunchKernelGGL(hgs_k_render_bwd, dim3(status->bwd_groups), dim3(256), 0, stream, v, L,
-                       out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
+                       L.recs, L.bstate, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
                        dL_dout_alpha, rows);
     HGS_LAUNCH_CHECK();
   }
+  HGS_STAGE(1);
   hipLaunchKernelGGL(hgs_k_preprocess_bwd, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, rows,
                      means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans3D,
                      dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales,

@@ -106,8 +106,69 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
 }
 
 // ---------------------------------------------------------------------------- 2. fill
+// LDS path, part 1: per tile, exclusive scan of the per-workgroup histogram column
+// (hist[g][t] -> number of entries of tile t owned by workgroups < g) and the tile total.
+extern "C" __global__ void __launch_bounds__(256)
+hgs_k_colscan(View v, Layout L) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= v.T) return;
+  uint32_t run = 0;
+  uint32_t* col = L.hist + t;
+  int g = 0;
+  for (; g + 4 <= v.nwg; g += 4) {
+    const uint32_t c0 = col[(size_t)(g + 0) * v.T], c1 = col[(size_t)(g + 1) * v.T];
+    const uint32_t c2 = col[(size_t)(g + 2) * v.T], c3 = col[(size_t)(g + 3) * v.T];
+    col[(size_t)(g + 0) * v.T] = run; run += c0;
+    col[(size_t)(g + 1) * v.T] = run; run += c1;
+    col[(size_t)(g + 2) * v.T] = run; run += c2;
+    col[(size_t)(g + 3) * v.T] = run; run += c3;
+  }
+  for (; g < v.nwg; ++g) {
+    const uint32_t c = col[(size_t)g * v.T];
+    col[(size_t)g * v.T] = run;
+    run += c;
+  }
+  L.tile_count[t] = run;
+}
+
+// LDS path, part 2: same workgroup -> chunk ownership as hgs_k_preprocess_fwd.  Slot of an
+// entry = tile_start[t] + hist[g][t] (entries of earlier workgroups) + an LDS cursor.
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
 hgs_k_fill(View v, Layout L, const hgs_status* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
+  __shared__ uint32_t wtot[HGS_BLOCK / 64];
+  if (status->overflow) return;
+  const uint32_t* __restrict__ base_row = L.hist + (size_t)blockIdx.x * v.T;
+  for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_cur[t] = L.tile_start[t] + base_row[t];
+  __syncthreads();
+  for (int c = 0; c < v.cpw; ++c) {
+    const int chunk = blockIdx.x * v.cpw + c;
+    if (chunk >= v.nblk) break;
+    const int i = chunk * HGS_BLOCK + threadIdx.x;
+    uint32_t lo = 0, hi = 0, depth_bits = 0;
+    if (i < v.P) {
+      const uint4 q2 = reinterpret_cast<const uint4*>(&L.geom[i])[2];   // b, depth, rect_lo, rect_hi
+      depth_bits = q2.y; lo = q2.z; hi = q2.w;
+    }
+    const int minx = lo & 0xffffu, miny = lo >> 16, maxx = hi & 0xffffu, maxy = hi >> 16;
+    const uint32_t tt = (uint32_t)((maxx - minx) * (maxy - miny));
+    uint32_t total;
+    const uint32_t ex = hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
+    if (i < v.P) {
+      L.geom[i].offset = L.block_base[chunk] + ex;
+      const unsigned long long key_hi = (unsigned long long)depth_bits << 32;
+      for (int ty = miny; ty < maxy; ++ty)
+        for (int tx = minx; tx < maxx; ++tx) {
+          const uint32_t slot = atomicAdd(&lds_cur[ty * v.grid_x + tx], 1u);
+          L.keys[slot] = key_hi | (uint32_t)i;
+        }
+    }
+  }
+}
+
+// Fallback (global atomics) for T*4 > 64 KB.
+extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
+hgs_k_fill_ga(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
   if (status->overflow) return;
   const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
@@ -139,6 +200,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
                                                uint32_t start, uint32_t n,
                                                const unsigned long long* sorted, int nt) {
   const int tx = t % v.grid_x, ty = t / v.grid_x;
+  const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
   for (uint32_t k = threadIdx.x; k < n; k += nt) {
     const uint32_t idx = (uint32_t)sorted[k];
     const uint4* gp = reinterpret_cast<const uint4*>(&L.geom[idx]);
@@ -146,10 +208,37 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
     // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | g3: offset radius ..
     const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
     const uint32_t entry = g3.x + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+    const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
+    const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
+    const float op = __uint_as_float(g1.y);
+    // Conservative quadrant cull: a pixel can only pass alpha >= 1/255 inside the ellipse
+    // d^T Sigma^-1 d <= tau, tau = 2 ln(255 op); its bounding box has half extents
+    // sqrt(tau * Sigma_xx), sqrt(tau * Sigma_yy) with Sigma = conic^-1.  Margins absorb
+    // rounding; a set bit never changes results, a cleared bit must be provably empty.
+    uint32_t mask = 0;
+    const float a255 = 255.0f * op;
+    if (a255 >= 0.999f) {
+      const float tau = 2.0f * __logf(fmaxf(a255, 1.0f)) * 1.001f + 0.01f;
+      const float detc = ca * cc - cb * cb;
+      if (detc > 0.0f && cc > 0.0f && ca > 0.0f) {
+        const float ex = sqrtf(tau * cc / detc) * 1.001f + 0.01f;
+        const float ey = sqrtf(tau * ca / detc) * 1.001f + 0.01f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float qx0 = x0 + (float)((q & 1) * 8), qy0 = y0 + (float)((q >> 1) * 8);
+          const bool hit = (mx + ex >= qx0) && (mx - ex <= qx0 + 7.0f) && (my + ey >= qy0) &&
+                           (my - ey <= qy0 + 7.0f);
+          mask |= hit ? (1u << q) : 0u;
+        }
+      } else {
+        mask = 0xfu;   // degenerate conic: never cull
+      }
+    }
     uint4* dst = reinterpret_cast<uint4*>(&L.recs[start + k]);
-    dst[0] = g0;
-    dst[1] = g1;
-    dst[2] = make_uint4(g2.x, g2.y, entry, idx);
+    const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
+    dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
+    dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
+    dst[2] = make_uint4(g2.x, g2.y, entry, (idx & 0x0fffffffu) | (mask << 28));
   }
 }
 

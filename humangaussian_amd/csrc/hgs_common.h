@@ -13,6 +13,7 @@
 //   uint32   tile_bstart[T+1] (bucket-state prefix)        bwd scratch: float grad_rows[R][12]
 //   uint32   tile_wgstart[T+1](backward WG prefix)
 //   uint32   tile_maxcontrib[T]
+//   uint32   hist[NWG][T]      (per-binning-workgroup tile histograms, T <= 16384)
 //
 // wave = 64 lanes everywhere; a "bucket" is 64 consecutive entries of one tile's list.
 #pragma once
@@ -48,10 +49,13 @@ struct __attribute__((aligned(16))) GeomRec {   // 64 B, one per Gaussian
 };
 
 struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian) entry
-  float mx, my, ca, cb, cc, op, r, g, b, depth;
+  float mx, my;         // pixel-space mean
+  float qa, qb, qc;     // conic folded for exp2: qa=-0.5*ca*log2e, qb=-cb*log2e, qc=-0.5*cc*log2e
+  float op, r, g, b, depth;
   uint32_t entry;       // entry id = geom.offset + position of the tile in the rect
-  uint32_t idx;         // Gaussian index
+  uint32_t idx_mask;    // Gaussian index (low 28 bits) | quadrant cull mask << 28
 };
+#define HGS_LOG2E 1.4426950408889634f
 
 struct Layout {          // pointers carved out of the caller's buffers
   GeomRec* geom;
@@ -63,6 +67,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* tile_bstart;
   uint32_t* tile_wgstart;
   uint32_t* tile_maxcontrib;
+  uint32_t* hist;          // [nwg][T] per-workgroup tile histograms -> exclusive bases
   unsigned long long* keys;
   SortRec* recs;
   float* bstate;
@@ -77,6 +82,7 @@ struct View {            // per-call constants, passed by value to every kernel
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int32_t W, H, grid_x, grid_y, T;
   int32_t P, M, D, nblk;
+  int32_t cpw, nwg, lds_bins;   // chunks per binning workgroup, #binning workgroups, LDS path?
   uint32_t entry_capacity;
 };
 
@@ -91,14 +97,18 @@ __device__ __forceinline__ void hgs_fwd_thread_pixel(int tid, int& lx, int& ly) 
 }
 
 // The one place alpha is evaluated, shared by forward and backward so both take the
-// identical instruction sequence (skip decisions must agree).  Returns false when the
-// pair is skipped (power > 0 or alpha < 1/255).
-__device__ __forceinline__ bool hgs_eval_alpha(float dx, float dy, float ca, float cb,
-                                               float cc, float op, float& G, float& alpha) {
-  const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
-  G = __expf(power);
+// identical instruction sequence (skip decisions must agree).  q* are the folded conic of
+// SortRec; p2 = log2(e) * power.  Returns false when the pair is skipped (power > 0 or
+// alpha < 1/255).  m2 = qa*dx + qb*dy and m3 = qc*dy are handed back for the backward.
+__device__ __forceinline__ bool hgs_eval_alpha(float dx, float dy, float qa, float qb,
+                                               float qc, float op, float& G, float& alpha,
+                                               float& m2, float& m3) {
+  m2 = __builtin_fmaf(qa, dx, qb * dy);
+  m3 = qc * dy;
+  const float p2 = __builtin_fmaf(dx, m2, m3 * dy);
+  G = __builtin_amdgcn_exp2f(p2);
   alpha = fminf(HGS_ALPHA_MAX, op * G);
-  return (power <= 0.0f) && (alpha >= HGS_ALPHA_MIN);
+  return (p2 <= 0.0f) && (alpha >= HGS_ALPHA_MIN);
 }
 
 __device__ __forceinline__ uint32_t hgs_wave_incl_scan(uint32_t v) {

@@ -144,99 +144,156 @@ __device__ __forceinline__ void eval_sh(int deg, const float* __restrict__ sh, f
 }  // namespace
 
 // ------------------------------------------------------------------------------ forward
-// One thread per Gaussian.  Also counts per-tile list lengths (one atomic per touched
-// tile) and emits the workgroup's sum of tiles_touched for the offset scan.
+namespace {
+
+// Everything stage F1 computes for Gaussian i.  Returns tiles_touched.
+__device__ __forceinline__ uint32_t preprocess_one(
+    const View& v, int i, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, GeomRec& rec) {
+  const float* __restrict__ V = v.viewmatrix;
+  const float* __restrict__ PM = v.projmatrix;
+  rec.mx = rec.my = rec.ca = rec.cb = rec.cc = rec.op = 0.f;
+  rec.r = rec.g = rec.b = rec.depth = 0.f;
+  rec.rect_lo = rec.rect_hi = rec.offset = 0u;
+  rec.radius = 0;
+  rec.clamped = rec.flags = 0u;
+  const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+  Proj2D pj;
+  view_point(V, x, y, z, pj.tx0, pj.ty0, pj.tz);
+  if (!(pj.tz > HGS_NEAR_Z)) return 0;
+  const float hx = PM[0] * x + PM[4] * y + PM[8] * z + PM[12];
+  const float hy = PM[1] * x + PM[5] * y + PM[9] * z + PM[13];
+  const float hw = PM[3] * x + PM[7] * y + PM[11] * z + PM[15];
+  const float pw = 1.0f / (hw + 0.0000001f);
+  const float projx = hx * pw, projy = hy * pw;
+  Cov3 s;
+  if (cov3D_precomp) {
+    const float* c = cov3D_precomp + 6 * (size_t)i;
+    s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
+  } else {
+    s = cov3d_from(make_rotscale(scales, rotations, i, v.scale_modifier));
+  }
+  project_cov(v, V, s, pj);
+  if (pj.det == 0.0f) return 0;
+  const float det_inv = 1.0f / pj.det;
+  const float mid = 0.5f * (pj.a + pj.c);
+  const float root = sqrtf(fmaxf(0.1f, mid * mid - pj.det));
+  const float lam = fmaxf(mid + root, mid - root);
+  const float radf = ceilf(3.0f * sqrtf(lam));
+  const float mx = ((projx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
+  const float my = ((projy + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+  const int gxm = v.grid_x, gym = v.grid_y;
+  const int rminx = min(gxm, max(0, (int)((mx - radf) / 16.0f)));
+  const int rminy = min(gym, max(0, (int)((my - radf) / 16.0f)));
+  const int rmaxx = min(gxm, max(0, (int)((mx + radf + 15.0f) / 16.0f)));
+  const int rmaxy = min(gym, max(0, (int)((my + radf + 15.0f) / 16.0f)));
+  const int area = (rmaxx - rminx) * (rmaxy - rminy);
+  if (area <= 0) return 0;
+  rec.mx = mx; rec.my = my;
+  rec.ca = pj.c * det_inv; rec.cb = -pj.b * det_inv; rec.cc = pj.a * det_inv;
+  rec.op = opacities[i];
+  rec.depth = pj.tz;
+  rec.rect_lo = (uint32_t)rminx | ((uint32_t)rminy << 16);
+  rec.rect_hi = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
+  rec.radius = (int)radf;
+  rec.flags = (pj.clx ? 1u : 0u) | (pj.cly ? 2u : 0u);
+  if (colors_precomp) {
+    rec.r = colors_precomp[3 * i + 0];
+    rec.g = colors_precomp[3 * i + 1];
+    rec.b = colors_precomp[3 * i + 2];
+  } else {
+    const float* cp = v.campos;
+    const float ddx = x - cp[0], ddy = y - cp[1], ddz = z - cp[2];
+    const float n = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+    float col[3];
+    eval_sh(v.D, shs + (size_t)i * v.M * 3, ddx / n, ddy / n, ddz / n, col);
+    uint32_t cl = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      col[ch] = col[ch] + 0.5f;
+      if (col[ch] < 0.0f) { cl |= (1u << ch); col[ch] = 0.0f; }
+    }
+    rec.r = col[0]; rec.g = col[1]; rec.b = col[2];
+    rec.clamped = cl;
+  }
+  return (uint32_t)area;
+}
+
+__device__ __forceinline__ void store_geom(GeomRec* dstp, const GeomRec& rec) {
+  uint4* dst = reinterpret_cast<uint4*>(dstp);
+  const uint4* src = reinterpret_cast<const uint4*>(&rec);
+  dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+}
+
+}  // namespace
+
+// LDS-histogram variant (T*4 bytes of dynamic LDS <= 64 KB).  Workgroup g owns the
+// Gaussian chunks [g*cpw, (g+1)*cpw) (256 Gaussians each); it counts its tile hits with
+// LDS atomics and writes its histogram ROW hist[g][0..T) - no global atomics at all.
+// Also emits each chunk's sum of tiles_touched for the entry-id scan.
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
 hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
                      const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                      const float* __restrict__ opacities, const float* __restrict__ scales,
                      const float* __restrict__ rotations,
                      const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
-  const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
-  const float* __restrict__ V = v.viewmatrix;
-  const float* __restrict__ PM = v.projmatrix;
-
-  GeomRec rec;
-  rec.mx = rec.my = rec.ca = rec.cb = rec.cc = rec.op = 0.f;
-  rec.r = rec.g = rec.b = rec.depth = 0.f;
-  rec.rect_lo = rec.rect_hi = rec.offset = 0u;
-  rec.radius = 0;
-  rec.clamped = rec.flags = 0u;
-  uint32_t tt = 0;
-
-  if (i < v.P) {
-    const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
-    Proj2D pj;
-    view_point(V, x, y, z, pj.tx0, pj.ty0, pj.tz);
-    if (pj.tz > HGS_NEAR_Z) {
-      const float hx = PM[0] * x + PM[4] * y + PM[8] * z + PM[12];
-      const float hy = PM[1] * x + PM[5] * y + PM[9] * z + PM[13];
-      const float hw = PM[3] * x + PM[7] * y + PM[11] * z + PM[15];
-      const float pw = 1.0f / (hw + 0.0000001f);
-      const float projx = hx * pw, projy = hy * pw;
-      Cov3 s;
-      if (cov3D_precomp) {
-        const float* c = cov3D_precomp + 6 * (size_t)i;
-        s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
-      } else {
-        s = cov3d_from(make_rotscale(scales, rotations, i, v.scale_modifier));
-      }
-      project_cov(v, V, s, pj);
-      if (pj.det != 0.0f) {
-        const float det_inv = 1.0f / pj.det;
-        const float mid = 0.5f * (pj.a + pj.c);
-        const float root = sqrtf(fmaxf(0.1f, mid * mid - pj.det));
-        const float lam = fmaxf(mid + root, mid - root);
-        const float radf = ceilf(3.0f * sqrtf(lam));
-        const float mx = ((projx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
-        const float my = ((projy + 1.0f) * (float)v.H - 1.0f) * 0.5f;
-        const int gxm = v.grid_x, gym = v.grid_y;
-        const int rminx = min(gxm, max(0, (int)((mx - radf) / 16.0f)));
-        const int rminy = min(gym, max(0, (int)((my - radf) / 16.0f)));
-        const int rmaxx = min(gxm, max(0, (int)((mx + radf + 15.0f) / 16.0f)));
-        const int rmaxy = min(gym, max(0, (int)((my + radf + 15.0f) / 16.0f)));
-        const int area = (rmaxx - rminx) * (rmaxy - rminy);
-        if (area > 0) {
-          tt = (uint32_t)area;
-          rec.mx = mx; rec.my = my;
-          rec.ca = pj.c * det_inv; rec.cb = -pj.b * det_inv; rec.cc = pj.a * det_inv;
-          rec.op = opacities[i];
-          rec.depth = pj.tz;
-          rec.rect_lo = (uint32_t)rminx | ((uint32_t)rminy << 16);
-          rec.rect_hi = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
-          rec.radius = (int)radf;
-          rec.flags = (pj.clx ? 1u : 0u) | (pj.cly ? 2u : 0u);
-          if (colors_precomp) {
-            rec.r = colors_precomp[3 * i + 0];
-            rec.g = colors_precomp[3 * i + 1];
-            rec.b = colors_precomp[3 * i + 2];
-          } else {
-            const float* cp = v.campos;
-            const float ddx = x - cp[0], ddy = y - cp[1], ddz = z - cp[2];
-            const float n = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-            float col[3];
-            eval_sh(v.D, shs + (size_t)i * v.M * 3, ddx / n, ddy / n, ddz / n, col);
-            uint32_t cl = 0;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-              col[ch] = col[ch] + 0.5f;
-              if (col[ch] < 0.0f) { cl |= (1u << ch); col[ch] = 0.0f; }
-            }
-            rec.r = col[0]; rec.g = col[1]; rec.b = col[2];
-            rec.clamped = cl;
-          }
-          // per-tile list lengths
-          for (int ty = rminy; ty < rmaxy; ++ty)
-            for (int tx = rminx; tx < rmaxx; ++tx)
-              atomicAdd(&L.tile_count[ty * gxm + tx], 1u);
-        }
+  for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_hist[t] = 0u;
+  __syncthreads();
+  const int gxm = v.grid_x;
+  for (int c = 0; c < v.cpw; ++c) {
+    const int chunk = blockIdx.x * v.cpw + c;
+    if (chunk >= v.nblk) break;
+    const int i = chunk * HGS_BLOCK + threadIdx.x;
+    uint32_t tt = 0;
+    if (i < v.P) {
+      GeomRec rec;
+      tt = preprocess_one(v, i, means3D, shs, colors_precomp, opacities, scales, rotations,
+                          cov3D_precomp, rec);
+      radii[i] = rec.radius;
+      store_geom(&L.geom[i], rec);
+      if (tt) {
+        const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;
+        const int maxx = rec.rect_hi & 0xffffu, maxy = rec.rect_hi >> 16;
+        for (int ty = miny; ty < maxy; ++ty)
+          for (int tx = minx; tx < maxx; ++tx) atomicAdd(&lds_hist[ty * gxm + tx], 1u);
       }
     }
+    uint32_t total;
+    (void)hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
+    if (threadIdx.x == 0) L.block_sums[chunk] = total;
+  }
+  __syncthreads();
+  uint32_t* row = L.hist + (size_t)blockIdx.x * v.T;
+  for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) row[t] = lds_hist[t];
+}
+
+// Fallback for very large images (T*4 > 64 KB): one chunk per workgroup, one global
+// atomic per touched tile.
+extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
+hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
+                        const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+                        const float* __restrict__ opacities, const float* __restrict__ scales,
+                        const float* __restrict__ rotations,
+                        const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
+  __shared__ uint32_t wtot[HGS_BLOCK / 64];
+  const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  uint32_t tt = 0;
+  if (i < v.P) {
+    GeomRec rec;
+    tt = preprocess_one(v, i, means3D, shs, colors_precomp, opacities, scales, rotations,
+                        cov3D_precomp, rec);
     radii[i] = rec.radius;
-    uint4* dst = reinterpret_cast<uint4*>(&L.geom[i]);
-    const uint4* src = reinterpret_cast<const uint4*>(&rec);
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+    store_geom(&L.geom[i], rec);
+    if (tt) {
+      const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;
+      const int maxx = rec.rect_hi & 0xffffu, maxy = rec.rect_hi >> 16;
+      for (int ty = miny; ty < maxy; ++ty)
+        for (int tx = minx; tx < maxx; ++tx) atomicAdd(&L.tile_count[ty * v.grid_x + tx], 1u);
+    }
   }
   uint32_t total;
   (void)hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);

@@ -38,13 +38,14 @@ __device__ __forceinline__ float wave_shift_in(float prev_out, float first) {
 }  // namespace
 
 extern "C" __global__ void __launch_bounds__(256)
-hgs_k_render_bwd(View v, Layout L, const float* __restrict__ out_color,
+hgs_k_render_bwd(View v, Layout L, const SortRec* __restrict__ recs_all,
+                 const float* __restrict__ bstate, const float* __restrict__ out_color,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                  const float* __restrict__ dL_dalpha, float* __restrict__ grad_rows) {
-  // pixel constants, row-major inside the tile (p = y*16 + x)
-  __shared__ float s_gc0[256], s_gc1[256], s_gc2[256], s_gd[256], s_ga[256], s_fp[256];
-  __shared__ uint32_t s_nc[256];
+  // per-pixel constants, row-major inside the tile (p = y*16 + x), two float4 per pixel:
+  //   [gC0 gC1 gC2 gD] [gA F' n_contrib(bits) pixel_x]
+  __shared__ float4 s_pix[2 * 256];
   __shared__ float s_T0[HGS_BWD_WAVES][256], s_F0[HGS_BWD_WAVES][256];
 
   // ---- which (tile, bucket group) is this workgroup?  binary search the WG prefix
@@ -61,9 +62,10 @@ hgs_k_render_bwd(View v, Layout L, const float* __restrict__ out_color,
   const uint32_t maxc = L.tile_maxcontrib[t];
   const int tile_x = t % v.grid_x, tile_y = t / v.grid_x;
   const int tid = threadIdx.x;
+  const int tx0 = tile_x * HGS_TILE, ty0 = tile_y * HGS_TILE;
 
   {  // pixel constants: thread tid <-> row-major pixel tid
-    const int px = tile_x * HGS_TILE + (tid & 15), py = tile_y * HGS_TILE + (tid >> 4);
+    const int px = tx0 + (tid & 15), py = ty0 + (tid >> 4);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, gd = 0.f, ga = 0.f, fp = 0.f;
     uint32_t nc = 0;
     if (px < v.W && py < v.H) {
@@ -75,25 +77,26 @@ hgs_k_render_bwd(View v, Layout L, const float* __restrict__ out_color,
            out_depth[pix] * gd + out_alpha[pix] * ga;
       nc = L.n_contrib[pix];
     }
-    s_gc0[tid] = c0; s_gc1[tid] = c1; s_gc2[tid] = c2; s_gd[tid] = gd; s_ga[tid] = ga;
-    s_fp[tid] = fp; s_nc[tid] = nc;
+    s_pix[2 * tid + 0] = make_float4(c0, c1, c2, gd);
+    s_pix[2 * tid + 1] = make_float4(ga, fp, __uint_as_float(nc), (float)px);
   }
   __syncthreads();
 
-  const int w = tid >> 6, lane = tid & 63;
-  const uint32_t b = grp * HGS_BWD_WAVES + w;          // bucket inside the tile
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const uint32_t b = grp * HGS_BWD_WAVES + (uint32_t)w;          // bucket inside the tile
   const uint32_t q0 = b * HGS_BUCKET;
   if (q0 >= n) return;                                  // no such bucket (wave-uniform)
   const uint32_t q = q0 + lane;
   const bool valid = q < n;
 
-  float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
+  float mx = 0.f, my = 0.f, qa = 0.f, qb = 0.f, qc = 0.f, op = 0.f;
   float cr = 0.f, cg = 0.f, cbl = 0.f, dep = 0.f;
   uint32_t entry = 0;
   if (valid) {
-    const float4* src = reinterpret_cast<const float4*>(&L.recs[start + q]);
+    const float4* src = reinterpret_cast<const float4*>(recs_all + start + q);
     const float4 r0 = src[0], r1 = src[1], r2 = src[2];
-    mx = r0.x; my = r0.y; ca = r0.z; cb = r0.w; cc = r1.x; op = r1.y;
+    mx = r0.x; my = r0.y; qa = r0.z; qb = r0.w; qc = r1.x; op = r1.y;
     cr = r1.z; cg = r1.w; cbl = r2.x; dep = r2.y;
     entry = __float_as_uint(r2.z);
   }
@@ -107,9 +110,11 @@ hgs_k_render_bwd(View v, Layout L, const float* __restrict__ out_color,
     return;
   }
 
-  // ---- pipeline entry state for the 256 pixels (4 per lane), row-major order
+  // ---- pipeline entry state for the 256 pixels (4 per lane), row-major order.  A pixel
+  // whose n_contrib <= q0 finished before this bucket (its forward wave may have exited
+  // without storing the state): it can never be active here, give it a finite dummy state.
   {
-    const float* bs = (b > 0) ? L.bstate + (size_t)(L.tile_bstart[t] + b - 1) * HGS_BSTATE_FLOATS
+    const float* bs = (b > 0) ? bstate + (size_t)(L.tile_bstart[t] + b - 1) * HGS_BSTATE_FLOATS
                               : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -117,11 +122,12 @@ hgs_k_render_bwd(View v, Layout L, const float* __restrict__ out_color,
       int lx, ly;
       hgs_fwd_thread_pixel(pf, lx, ly);
       const int p = ly * 16 + lx;                   // row-major pixel
+      const float4 pa = s_pix[2 * p + 0], pb = s_pix[2 * p + 1];
       float T0 = 1.0f, F0 = 0.0f;
-      if (bs) {
+      if (bs && __float_as_uint(pb.z) > q0) {
         T0 = bs[0 * 256 + pf];
-        F0 = bs[1 * 256 + pf] * s_gc0[p] + bs[2 * 256 + pf] * s_gc1[p] +
-             bs[3 * 256 + pf] * s_gc2[p] + bs[4 * 256 + pf] * s_gd[p] + bs[5 * 256 + pf] * s_ga[p];
+        F0 = bs[1 * 256 + pf] * pa.x + bs[2 * 256 + pf] * pa.y + bs[3 * 256 + pf] * pa.z +
+             bs[4 * 256 + pf] * pa.w + bs[5 * 256 + pf] * pb.x;
       }
       s_T0[w][p] = T0;
       s_F0[w][p] = F0;
@@ -130,9 +136,11 @@ hgs_k_render_bwd(View v, Layout L, const float* __restrict__ out_color,
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  const int tx0 = tile_x * HGS_TILE, ty0 = tile_y * HGS_TILE;
-  const uint32_t m = min((uint32_t)HGS_BUCKET, n - q0);   // valid lanes in this bucket
+  const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)HGS_BUCKET, n - q0));
   const int nsteps = 256 + (int)m - 1;
+  const float ty0f = (float)ty0;
+  const float* __restrict__ T0w = s_T0[w];
+  const float* __restrict__ F0w = s_F0[w];
 
   float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f;
   float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
@@ -140,43 +148,49 @@ hgs_k_render_bwd(View v, Layout L, const float* __restrict__ out_color,
 
   for (int s = 0; s < nsteps; ++s) {
     const int pe = min(s, 255);
-    const float T_in = wave_shift_in(T_out, s_T0[w][pe]);
-    const float F_in = wave_shift_in(F_out, s_F0[w][pe]);
+    const float T_in = wave_shift_in(T_out, T0w[pe]);
+    const float F_in = wave_shift_in(F_out, F0w[pe]);
     const int p = s - lane;
-    const bool inrange = (p >= 0) && (p < 256);
     const int pc = min(max(p, 0), 255);
-    const float g0 = s_gc0[pc], g1 = s_gc1[pc], g2 = s_gc2[pc], gd = s_gd[pc], ga = s_ga[pc];
-    const float fp = s_fp[pc];
-    const uint32_t nc = s_nc[pc];
-    // same expression as the forward (absolute pixel centre) so skip decisions agree
-    const float dx = mx - (float)(tx0 + (pc & 15)), dy = my - (float)(ty0 + (pc >> 4));
-    float G, alpha;
-    const bool keep = hgs_eval_alpha(dx, dy, ca, cb, cc, op, G, alpha);
-    const bool act = keep && inrange && (q < nc);
+    const float4 pa = s_pix[2 * pc + 0];      // gC0 gC1 gC2 gD
+    const float4 pb = s_pix[2 * pc + 1];      // gA F' n_contrib pixel_x
+    // same dx/dy expressions as the forward (absolute pixel centre) so skip decisions agree
+    const float dx = mx - pb.w;
+    const float dy = my - (ty0f + (float)(pc >> 4));
+    float G, alpha, m2, m3;
+    const bool keep = hgs_eval_alpha(dx, dy, qa, qb, qc, op, G, alpha, m2, m3);
+    const bool act = keep && ((uint32_t)p < 256u) && (q < __float_as_uint(pb.z));
     const float a = act ? alpha : 0.0f;
+    const float Gm = act ? G : 0.0f;
     const float wgt = a * T_in;
-    const float S = cr * g0 + cg * g1 + cbl * g2 + dep * gd + ga;
-    const float F_new = F_in + wgt * S;
+    const float S = __builtin_fmaf(cr, pa.x, __builtin_fmaf(cg, pa.y, __builtin_fmaf(cbl, pa.z,
+                    __builtin_fmaf(dep, pa.w, pb.x))));
+    const float F_new = __builtin_fmaf(wgt, S, F_in);
     const float om = 1.0f - a;
     T_out = T_in * om;
     F_out = F_new;
-    // om >= 0.01, so dLda is always finite; inactive pairs are removed by zeroing G
-    const float dLda = T_in * S - (fp - F_new) * __frcp_rn(om);
-    const float Gm = act ? G : 0.0f;
-    a_r += wgt * g0; a_g += wgt * g1; a_b += wgt * g2; a_d += wgt * gd;
-    a_op += Gm * dLda;
-    const float dLdG = op * dLda;
-    const float gdx = Gm * dx, gdy = Gm * dy;
-    a_mx += dLdG * (-gdx * ca - gdy * cb);
-    a_my += dLdG * (-gdy * cc - gdx * cb);
-    a_ca += -0.5f * gdx * dx * dLdG;
-    a_cb += -gdx * dy * dLdG;
-    a_cc += -0.5f * gdy * dy * dLdG;
+    // om >= 0.01, so dLda is always finite; inactive pairs are removed through Gm = 0
+    const float dLda = __builtin_fmaf(T_in, S, -((pb.y - F_new) * __builtin_amdgcn_rcpf(om)));
+    a_r = __builtin_fmaf(wgt, pa.x, a_r);
+    a_g = __builtin_fmaf(wgt, pa.y, a_g);
+    a_b = __builtin_fmaf(wgt, pa.z, a_b);
+    a_d = __builtin_fmaf(wgt, pa.w, a_d);
+    a_op = __builtin_fmaf(Gm, dLda, a_op);
+    const float k = op * dLda * Gm;                       // dL/dG * G
+    // d(p2)/d(dx) = 2 qa dx + qb dy = m2 + qa dx ;  d(p2)/d(dy) = qb dx + 2 qc dy
+    a_mx = __builtin_fmaf(k, __builtin_fmaf(qa, dx, m2), a_mx);
+    a_my = __builtin_fmaf(k, __builtin_fmaf(qb, dx, m3 + m3), a_my);
+    const float kdx = k * dx, kdy = k * dy;
+    a_ca = __builtin_fmaf(kdx, dx, a_ca);
+    a_cb = __builtin_fmaf(kdx, dy, a_cb);
+    a_cc = __builtin_fmaf(kdy, dy, a_cc);
   }
 
   if (valid) {
-    row[0] = make_float4(a_mx, a_my, a_ca, a_cb);
-    row[1] = make_float4(a_cc, a_op, a_r, a_g);
+    // undo the exp2 folding (d power = d p2 / log2e) and apply the conic factors
+    const float il = 1.0f / HGS_LOG2E;
+    row[0] = make_float4(a_mx * il, a_my * il, -0.5f * a_ca, -a_cb);
+    row[1] = make_float4(-0.5f * a_cc, a_op, a_r, a_g);
     row[2] = make_float4(a_b, a_d, 0.f, 0.f);
   }
 }

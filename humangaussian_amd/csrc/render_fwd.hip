@@ -1,30 +1,73 @@
 // render_fwd.hip - per-tile front-to-back alpha blending (stage F6).
 //
-// One 256-thread workgroup (4 wave64) per 16x16 tile; wave w owns the 8x8 pixel block
-// (w&1, w>>1).  The tile's depth-sorted 48-byte records are streamed from HBM with
-// coalesced 16 B/lane loads into LDS in batches of 256 and broadcast-read by every lane.
-// Workgroups are issued heavy-tile-first (tile_order) so the long lists start early.
-// When the call needs a backward, the running per-pixel state (T, C, D, W) is stored at
-// every 64-entry bucket boundary: the backward kernel is parallel over buckets.
+// One 256-thread workgroup per 16x16 tile; its four wave64 are INDEPENDENT (no barriers):
+// wave w owns the 8x8 pixel quadrant (w&1, w>>1) and walks the tile's depth-sorted 48-byte
+// record list in buckets of 64:
+//   1. each lane loads one record of the bucket with coalesced 16 B/lane loads (the loads
+//      for the NEXT bucket are issued before the current one is blended);
+//   2. wavefront ballot + prefix popcount COMPACT the bucket to the records whose
+//      conservative cull mask (computed at sort time) says they can reach alpha >= 1/255
+//      somewhere in this wave's quadrant - typically about half - into a wave-private
+//      3 KB LDS slice, each carrying its original list position;
+//   3. a branch-free, 4x unrolled, software-pipelined loop broadcasts the compacted
+//      records from LDS (ds_read_b128, same address in every lane) and blends them with
+//      per-lane predication; the only loop-carried dependency is the transmittance T.
+// Workgroups are issued heavy-tile-first (tile_order).  When the call needs a backward,
+// the running per-pixel state (T, C, D, W) is stored at every 64-entry bucket boundary.
 //
 // Semantics follow upstream's renderCUDA of the ashawkey fork exactly (skip rules, the
-// terminating Gaussian is not blended, depth not normalised, out_alpha = sum of weights).
-// Roofline: VALU/LDS-latency bound (about 25 flop per pixel-Gaussian pair); HBM traffic is
-// 48 B/entry in + 24 B/pixel out (+ 24 B/pixel/bucket state when storing).
+// terminating Gaussian is not blended, depth not normalised, out_alpha = sum of weights,
+// n_contrib = list position of the last blended Gaussian).
+// Roofline: VALU-bound (about 24 VALU per kept pixel-Gaussian pair); HBM traffic is
+// 48 B/entry/wave in (L2-served after the first wave) + 24 B/pixel out
+// (+ 24 B/pixel/bucket state when storing).
 #include "hgs_common.h"
+
+namespace {
+
+struct PixState {
+  float T, C0, C1, C2, D, Wt;
+  uint32_t last;
+  bool done;
+};
+
+// Blend one compacted record into the lane's pixel, fully predicated.  r2.w carries the
+// record's 1-based position in the tile list; `valid` is wave-uniform (tail of a group).
+__device__ __forceinline__ void blend_one(PixState& s, float pxf, float pyf, const float4 r0,
+                                          const float4 r1, const float4 r2, bool valid) {
+  float G, alpha, m2, m3;
+  const bool keep = hgs_eval_alpha(r0.x - pxf, r0.y - pyf, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
+  const bool live = keep && valid && !s.done;
+  const float test_T = s.T * (1.0f - alpha);
+  const bool stop = live && (test_T < HGS_T_EPS);
+  const bool upd = live && !stop;
+  s.done = s.done || stop;
+  const float wgt = upd ? alpha * s.T : 0.0f;
+  s.C0 = __builtin_fmaf(r1.z, wgt, s.C0);
+  s.C1 = __builtin_fmaf(r1.w, wgt, s.C1);
+  s.C2 = __builtin_fmaf(r2.x, wgt, s.C2);
+  s.D = __builtin_fmaf(r2.y, wgt, s.D);
+  s.Wt += wgt;
+  s.T = upd ? test_T : s.T;
+  s.last = upd ? __float_as_uint(r2.w) : s.last;
+}
+
+}  // namespace
 
 template <bool STORE>
 __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
-                                                const hgs_status* status,
+                                                const hgs_status* __restrict__ status,
+                                                const SortRec* __restrict__ recs_all,
+                                                float* __restrict__ bstate,
                                                 float* __restrict__ out_color,
                                                 float* __restrict__ out_depth,
                                                 float* __restrict__ out_alpha) {
-  __shared__ float4 batch[3 * 256];        // 12 KB: records as 3 x float4
-  __shared__ uint32_t max_contrib_s;
-
+  __shared__ float4 s_rec[4][3 * HGS_BUCKET];     // wave-private compacted buckets (12 KB)
   const bool overflow = status->overflow != 0;
   const int t = overflow ? (int)blockIdx.x : (int)L.tile_order[blockIdx.x];
   const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
   const int tile_x = t % v.grid_x, tile_y = t / v.grid_x;
   int lx, ly;
   hgs_fwd_thread_pixel(tid, lx, ly);
@@ -35,87 +78,107 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
   const uint32_t start = overflow ? 0u : L.tile_start[t];
   const uint32_t n = overflow ? 0u : (L.tile_start[t + 1] - start);
   const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
+  const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
+  const uint32_t wbit = 1u << (28 + w);
+  float4* __restrict__ srec = s_rec[w];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  if (tid == 0) max_contrib_s = 0;
+  PixState s;
+  s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
+  s.last = 0;
+  s.done = !inside;
 
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, Wt = 0.f;
-  uint32_t last = 0;
-  bool done = !inside;
+  // records of the first bucket
+  float4 c0 = zero4, c1 = zero4, c2 = zero4;
+  if ((uint32_t)lane < n) { c0 = recs[3 * lane + 0]; c1 = recs[3 * lane + 1]; c2 = recs[3 * lane + 2]; }
 
-  for (uint32_t base = 0; base < n; base += 256) {
-    if (__syncthreads_and(done)) break;
-    const uint32_t m = min(256u, n - base);
-    if ((uint32_t)tid < m) {
-      const float4* src = reinterpret_cast<const float4*>(&L.recs[start + base + tid]);
-      batch[3 * tid + 0] = src[0];
-      batch[3 * tid + 1] = src[1];
-      batch[3 * tid + 2] = src[2];
+  for (uint32_t j0 = 0; j0 < n; j0 += HGS_BUCKET) {
+    if (__ballot(!s.done) == 0ull) break;            // every pixel of this wave is finished
+    if (STORE && j0 > 0) {
+      float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
+      bs[0 * 256 + tid] = s.T;
+      bs[1 * 256 + tid] = s.C0;
+      bs[2 * 256 + tid] = s.C1;
+      bs[3 * 256 + tid] = s.C2;
+      bs[4 * 256 + tid] = s.D;
+      bs[5 * 256 + tid] = s.Wt;
     }
-    __syncthreads();
-    for (uint32_t jb = 0; jb < m; jb += HGS_BUCKET) {
-      if (STORE && (base + jb) > 0) {
-        float* bs = L.bstate + (size_t)(bstart + (base + jb) / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
-        bs[0 * 256 + tid] = T;
-        bs[1 * 256 + tid] = C0;
-        bs[2 * 256 + tid] = C1;
-        bs[3 * 256 + tid] = C2;
-        bs[4 * 256 + tid] = D;
-        bs[5 * 256 + tid] = Wt;
+    // issue the next bucket's loads now; they land while this bucket is blended
+    const uint32_t qn = j0 + HGS_BUCKET + lane;
+    float4 n0 = zero4, n1 = zero4, n2 = zero4;
+    if (qn < n) { n0 = recs[3 * qn + 0]; n1 = recs[3 * qn + 1]; n2 = recs[3 * qn + 2]; }
+
+    // ballot + prefix popcount compaction of the records that can touch this quadrant
+    const bool hit = (j0 + lane < n) && ((__float_as_uint(c2.w) & wbit) != 0u);
+    const unsigned long long ball = __ballot(hit);
+    const uint32_t cnt = (uint32_t)__popcll(ball);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+    __builtin_amdgcn_wave_barrier();                 // previous bucket's reads are done
+    if (hit) {
+      srec[3 * pos + 0] = c0;
+      srec[3 * pos + 1] = c1;
+      srec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float(j0 + lane + 1));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    if (cnt > 0) {
+      const uint32_t lastk = cnt - 1;
+      float4 ra[4], rb[4], rc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t k = min((uint32_t)u, lastk);
+        ra[u] = srec[3 * k + 0]; rb[u] = srec[3 * k + 1]; rc[u] = srec[3 * k + 2];
       }
-      const uint32_t je = min(m, jb + HGS_BUCKET);
-      for (uint32_t j = jb; j < je; ++j) {
-        const float4 r0 = batch[3 * j + 0];   // mx my ca cb
-        const float4 r1 = batch[3 * j + 1];   // cc op r g
-        const float4 r2 = batch[3 * j + 2];   // b depth entry idx
-        float G, alpha;
-        const bool keep = hgs_eval_alpha(r0.x - pxf, r0.y - pyf, r0.z, r0.w, r1.x, r1.y, G, alpha);
-        if (done || !keep) continue;
-        const float test_T = T * (1.0f - alpha);
-        if (test_T < HGS_T_EPS) { done = true; continue; }
-        const float wgt = alpha * T;
-        C0 += r1.z * wgt;
-        C1 += r1.w * wgt;
-        C2 += r2.x * wgt;
-        D += r2.y * wgt;
-        Wt += wgt;
-        T = test_T;
-        last = base + j + 1;
+      for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
+        float4 na[4], nb[4], nc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                // prefetch the next group (clamped)
+          const uint32_t k = min(k0 + 4 + u, lastk);
+          na[u] = srec[3 * k + 0]; nb[u] = srec[3 * k + 1]; nc[u] = srec[3 * k + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          blend_one(s, pxf, pyf, ra[u], rb[u], rc[u], k0 + u < cnt);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
       }
     }
+    c0 = n0; c1 = n1; c2 = n2;
   }
 
   if (inside) {
     const size_t pix = (size_t)py * v.W + px;
     const size_t HW = (size_t)v.H * v.W;
-    out_color[0 * HW + pix] = C0 + T * v.bg[0];
-    out_color[1 * HW + pix] = C1 + T * v.bg[1];
-    out_color[2 * HW + pix] = C2 + T * v.bg[2];
-    out_depth[pix] = D;
-    out_alpha[pix] = Wt;
-    L.n_contrib[pix] = last;
+    out_color[0 * HW + pix] = s.C0 + s.T * v.bg[0];
+    out_color[1 * HW + pix] = s.C1 + s.T * v.bg[1];
+    out_color[2 * HW + pix] = s.C2 + s.T * v.bg[2];
+    out_depth[pix] = s.D;
+    out_alpha[pix] = s.Wt;
+    L.n_contrib[pix] = s.last;
   }
   if (STORE && !overflow) {
     // tile-wide max of n_contrib: buckets at or beyond it are skipped by the backward
-    uint32_t mx = last;
+    uint32_t mx = s.last;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    __syncthreads();
-    if ((tid & 63) == 0) atomicMax(&max_contrib_s, mx);
-    __syncthreads();
-    if (tid == 0) L.tile_maxcontrib[t] = max_contrib_s;
+    if ((tid & 63) == 0 && mx > 0) atomicMax(&L.tile_maxcontrib[t], mx);
   }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_render_fwd_store(View v, Layout L, const hgs_status* __restrict__ status,
+                       const SortRec* __restrict__ recs, float* __restrict__ bstate,
                        float* __restrict__ out_color, float* __restrict__ out_depth,
                        float* __restrict__ out_alpha) {
-  render_fwd_body<true>(v, L, status, out_color, out_depth, out_alpha);
+  render_fwd_body<true>(v, L, status, recs, bstate, out_color, out_depth, out_alpha);
 }
 
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_render_fwd_nostore(View v, Layout L, const hgs_status* __restrict__ status,
+                         const SortRec* __restrict__ recs, float* __restrict__ bstate,
                          float* __restrict__ out_color, float* __restrict__ out_depth,
                          float* __restrict__ out_alpha) {
-  render_fwd_body<false>(v, L, status, out_color, out_depth, out_alpha);
+  render_fwd_body<false>(v, L, status, recs, bstate, out_color, out_depth, out_alpha);
 }
