@@ -96,8 +96,8 @@ def test_preprocess_records_bitwise():
     """Per-Gaussian quantities agree with the fp32 oracle bit-for-bit (same op order,
     contraction off) - so ceil()/==/int() decisions can never flake."""
     sc = make_scene(P=2000, sh_degree=3, seed=3, H=128, W=96, spread=0.6)
-    rc = RawCall(sc)
-    assert rc.forward() == 0
+    rc = RawCall(sc, capacity=1 << 17)
+    assert rc.forward() == 0 and not rc.status[4]
     rec = rc.geom_records()
     pre = oracle.preprocess(sc["means3D"], None, sc["shs"], None, sc["opacities"], sc["scales"],
                             sc["rotations"], None, oracle_settings(sc))
