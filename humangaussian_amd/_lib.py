@@ -15,7 +15,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.path.join(_PKG_DIR, "libhgs_rast.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared"]
@@ -47,7 +47,7 @@ EXPORTS = {
     "hgs_img_bytes": (c_size_t, [c_int32, c_int32]),
     "hgs_bwd_scratch_bytes": (c_size_t, [c_int64]),
     "hgs_forward": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32] + [c_void_p] * 7
-                    + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32,
+                    + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
                                         c_void_p, c_void_p, c_void_p]),
     "hgs_backward": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32] + [c_void_p] * 8
                      + [c_void_p] * 6 + [c_void_p] * 3 + [POINTER(HgsStatus), c_void_p]

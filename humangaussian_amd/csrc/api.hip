@@ -21,7 +21,7 @@ constexpr int HGS_MAX_BIN_WGS = 256;
 
 struct GeomCarve {
   size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
-      tile_wgstart, tile_maxcontrib, hist, status, total;
+      tile_wgstart, tile_maxcontrib, hist, tile_grp, status, total;
 };
 
 inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
@@ -42,6 +42,7 @@ GeomCarve carve_geom(int P, int H, int W) {
   c.tile_wgstart = take((T + 1) * 4);
   c.tile_maxcontrib = take(T * 4);
   c.hist = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_MAX_BIN_WGS * T * 4 : 0);
+  c.tile_grp = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
   c.status = take(sizeof(hgs_status));
   c.total = off;
   return c;
@@ -77,6 +78,7 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
   L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
+  L.tile_grp = reinterpret_cast<uint32_t*>(gp + g.tile_grp);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
@@ -84,7 +86,7 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   return L;
 }
 
-View make_view(const hgs_settings* s, int P, int M, int64_t cap) {
+View make_view(const hgs_settings* s, int P, int M, int64_t cap, int max_tile_hint = 0) {
   View v;
   v.viewmatrix = s->viewmatrix;
   v.projmatrix = s->projmatrix;
@@ -109,6 +111,7 @@ View make_view(const hgs_settings* s, int P, int M, int64_t cap) {
   if (v.cpw < 1) v.cpw = 1;
   v.nwg = (v.nblk + v.cpw - 1) / v.cpw;
   v.entry_capacity = (uint32_t)(cap < 0 ? 0 : (cap > 0xffffffffll ? 0xffffffffll : cap));
+  v.max_tile_hint = max_tile_hint;
   return v;
 }
 
@@ -138,7 +141,7 @@ bool settings_ok(const hgs_settings* s) {
 
 extern "C" {
 
-int hgs_abi_version(void) { return 2; }
+int hgs_abi_version(void) { return 3; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;
@@ -158,8 +161,8 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                 const float* scales, const float* rotations, const float* cov3D_precomp,
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 void* geom, void* bin, int64_t entry_capacity, void* img,
-                int32_t store_bwd_state, hgs_status* status_host, void* const* stage_events,
-                void* stream_) {
+                int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
+                void* const* stage_events, void* stream_) {
   if (!settings_ok(s) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
     return HGS_EINVAL;
@@ -173,7 +176,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     if (entry_capacity > 0 && !bin) return HGS_EINVAL;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const View v = make_view(s, P, M, entry_capacity);
+  const View v = make_view(s, P, M, entry_capacity, max_tile_entries_hint > 0 ? max_tile_entries_hint : 0);
   const Layout L = make_layout(geom, bin, img, P, v.H, v.W, entry_capacity);
   hgs_status* status_dev =
       reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(P, v.H, v.W).status);
@@ -198,7 +201,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
   }
   HGS_STAGE(1);
   if (v.lds_bins) {
-    hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256), dim3(256), 0, stream, v, L);
+    hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256, HGS_ROW_GROUPS), dim3(256), 0, stream, v, L);
     HGS_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev);
@@ -219,12 +222,21 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
       const int64_t g = entry_capacity / lo + 1;
       return (unsigned)(g < v.T ? g : v.T);
     };
-    hipLaunchKernelGGL(hgs_k_sort_huge, dim3(class_grid(16384)), dim3(1024), 0, stream, v, L, status_dev);
-    HGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
-    HGS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hgs_k_sort_medium, dim3(class_grid(1024)), dim3(512), 0, stream, v, L, status_dev);
-    HGS_LAUNCH_CHECK();
+    // the caller's hint (longest tile list it has seen, with margin) lets us skip launching
+    // sort classes that cannot occur; a wrong hint is caught on the device (overflow bit 2)
+    const int hint = v.max_tile_hint;
+    if (hint <= 0 || hint > 16384) {
+      hipLaunchKernelGGL(hgs_k_sort_huge, dim3(class_grid(16384)), dim3(1024), 0, stream, v, L, status_dev);
+      HGS_LAUNCH_CHECK();
+    }
+    if (hint <= 0 || hint > 4096) {
+      hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
+      HGS_LAUNCH_CHECK();
+    }
+    if (hint <= 0 || hint > 1024) {
+      hipLaunchKernelGGL(hgs_k_sort_medium, dim3(class_grid(1024)), dim3(512), 0, stream, v, L, status_dev);
+      HGS_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(hgs_k_sort_small, dim3(v.T), dim3(256), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
   }

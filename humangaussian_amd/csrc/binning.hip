@@ -19,19 +19,48 @@
 
 namespace {
 constexpr int SCAN_NT = 1024;
+constexpr int SCAN_ITEMS = 4;      // tiles per thread per pass
+
+// exclusive scan of three counters at once over the workgroup (one barrier pair)
+__device__ __forceinline__ void block_excl_scan3(uint32_t v0, uint32_t v1, uint32_t v2,
+                                                 uint32_t (*wtot)[3], uint32_t ex[3],
+                                                 uint32_t tot[3]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t i0 = hgs_wave_incl_scan(v0), i1 = hgs_wave_incl_scan(v1),
+                 i2 = hgs_wave_incl_scan(v2);
+  __syncthreads();
+  if (lane == 63) { wtot[w][0] = i0; wtot[w][1] = i1; wtot[w][2] = i2; }
+  __syncthreads();
+  uint32_t b0 = 0, b1 = 0, b2 = 0, t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_NT / 64; ++k) {
+    const uint32_t x0 = wtot[k][0], x1 = wtot[k][1], x2 = wtot[k][2];
+    if (k < w) { b0 += x0; b1 += x1; b2 += x2; }
+    t0 += x0; t1 += x1; t2 += x2;
+  }
+  ex[0] = b0 + i0 - v0; ex[1] = b1 + i1 - v1; ex[2] = b2 + i2 - v2;
+  tot[0] = t0; tot[1] = t1; tot[2] = t2;
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------- 1. scan
+// One workgroup.  LDS-bin path: the per-tile count is the sum of the HGS_ROW_GROUPS group
+// totals hgs_k_colscan left in tile_grp[rg][t]; this kernel turns them into ABSOLUTE
+// bases tile_start[t] + (entries of earlier row groups).
 extern "C" __global__ void __launch_bounds__(SCAN_NT)
 hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
   __shared__ uint32_t wtot[SCAN_NT / 64];
+  __shared__ uint32_t wtot3[SCAN_NT / 64][3];
   __shared__ uint32_t carry_s;
+  __shared__ uint32_t carry3[3];
   __shared__ uint32_t cls_hist[33];
   __shared__ uint32_t cls_base[33];
+  __shared__ uint32_t max_n_s;
   const int tid = threadIdx.x;
 
-  // (a) exclusive scan of per-workgroup tiles_touched sums -> block_base
-  if (tid == 0) carry_s = 0;
+  // (a) exclusive scan of per-chunk tiles_touched sums -> block_base
+  if (tid == 0) { carry_s = 0; carry3[0] = carry3[1] = carry3[2] = 0; max_n_s = 0; }
+  if (tid < 33) cls_hist[tid] = 0;
   __syncthreads();
   for (int base = 0; base < v.nblk; base += SCAN_NT) {
     const int k = base + tid;
@@ -45,34 +74,66 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
     __syncthreads();
   }
   const uint32_t R = carry_s;
-  __syncthreads();
 
   // (b) tile_start / bucket-state prefix / backward-workgroup prefix; class histogram
-  if (tid < 33) cls_hist[tid] = 0;
-  __shared__ uint32_t carry3[3];
-  if (tid == 0) { carry3[0] = carry3[1] = carry3[2] = 0; }
-  __syncthreads();
-  for (int base = 0; base < v.T; base += SCAN_NT) {
-    const int t = base + tid;
-    const uint32_t n = (t < v.T) ? L.tile_count[t] : 0u;
-    const uint32_t nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
-    const uint32_t nbs = nb > 0 ? nb - 1 : 0;                          // stored bucket states
-    const uint32_t nwg = (nb + HGS_BWD_WAVES - 1) / HGS_BWD_WAVES;     // backward workgroups
-    uint32_t tot0, tot1, tot2;
-    const uint32_t e0 = hgs_block_excl_scan<SCAN_NT>(n, wtot, tot0);
-    const uint32_t e1 = hgs_block_excl_scan<SCAN_NT>(nbs, wtot, tot1);
-    const uint32_t e2 = hgs_block_excl_scan<SCAN_NT>(nwg, wtot, tot2);
-    const uint32_t c0 = carry3[0], c1 = carry3[1], c2 = carry3[2];
-    if (t < v.T) {
-      L.tile_start[t] = c0 + e0;
-      L.tile_bstart[t] = c1 + e1;
-      L.tile_wgstart[t] = c2 + e2;
-      L.tile_count[t] = 0;            // becomes the fill cursor
-      L.tile_maxcontrib[t] = 0;
-      atomicAdd(&cls_hist[n ? 32 - __clz(n) : 0], 1u);
+  for (int base = 0; base < v.T; base += SCAN_NT * SCAN_ITEMS) {
+    const int t0 = base + tid * SCAN_ITEMS;
+    uint32_t n[SCAN_ITEMS], grp[HGS_ROW_GROUPS][SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      const int t = t0 + k;
+      n[k] = 0;
+      if (t < v.T) {
+        if (v.lds_bins) {
+#pragma unroll
+          for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
+            grp[rg][k] = L.tile_grp[(size_t)rg * v.T + t];
+            n[k] += grp[rg][k];
+          }
+        } else {
+          n[k] = L.tile_count[t];
+        }
+      }
     }
+    uint32_t l0 = 0, l1 = 0, l2 = 0, mx = 0;
+    uint32_t p0[SCAN_ITEMS], p1[SCAN_ITEMS], p2[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      const uint32_t nb = (n[k] + HGS_BUCKET - 1) / HGS_BUCKET;
+      p0[k] = l0; p1[k] = l1; p2[k] = l2;
+      l0 += n[k];
+      l1 += nb > 0 ? nb - 1 : 0;                               // stored bucket states
+      l2 += (nb + HGS_BWD_WAVES - 1) / HGS_BWD_WAVES;          // backward workgroups
+      mx = max(mx, n[k]);
+    }
+    uint32_t ex[3], tot[3];
+    block_excl_scan3(l0, l1, l2, wtot3, ex, tot);
+    const uint32_t c0 = carry3[0], c1 = carry3[1], c2 = carry3[2];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      const int t = t0 + k;
+      if (t < v.T) {
+        const uint32_t ts = c0 + ex[0] + p0[k];
+        L.tile_start[t] = ts;
+        L.tile_bstart[t] = c1 + ex[1] + p1[k];
+        L.tile_wgstart[t] = c2 + ex[2] + p2[k];
+        L.tile_maxcontrib[t] = 0;
+        if (v.lds_bins) {
+          uint32_t acc = ts;
+#pragma unroll
+          for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
+            L.tile_grp[(size_t)rg * v.T + t] = acc;
+            acc += grp[rg][k];
+          }
+        } else {
+          L.tile_count[t] = 0;            // becomes the fill cursor
+        }
+        atomicAdd(&cls_hist[n[k] ? 32 - __clz(n[k]) : 0], 1u);
+      }
+    }
+    if (mx) atomicMax(&max_n_s, mx);
     __syncthreads();
-    if (tid == 0) { carry3[0] = c0 + tot0; carry3[1] = c1 + tot1; carry3[2] = c2 + tot2; }
+    if (tid == 0) { carry3[0] = c0 + tot[0]; carry3[1] = c1 + tot[1]; carry3[2] = c2 + tot[2]; }
     __syncthreads();
   }
   if (tid == 0) {
@@ -88,8 +149,10 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
     st.num_buckets = carry3[1];
     st.bwd_groups = carry3[2];
     st.overflow = (R > v.entry_capacity) ? 1u : 0u;
+    if (v.max_tile_hint > 0 && max_n_s > (uint32_t)v.max_tile_hint) st.overflow |= 2u;
     st.reserved[0] = v.entry_capacity;   // carve key for hgs_backward
-    st.reserved[1] = st.reserved[2] = 0;
+    st.reserved[1] = max_n_s;            // longest tile list
+    st.reserved[2] = 0;
     *status = st;
   }
   __syncthreads();
@@ -106,29 +169,30 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
 }
 
 // ---------------------------------------------------------------------------- 2. fill
-// LDS path, part 1: per tile, exclusive scan of the per-workgroup histogram column
-// (hist[g][t] -> number of entries of tile t owned by workgroups < g) and the tile total.
+// LDS path, part 1: grid (T/256, HGS_ROW_GROUPS).  Thread (t, rg) scans the rows of row group
+// rg of histogram column t in place (hist[g][t] -> entries of tile t owned by earlier
+// workgroups OF THE SAME GROUP) and leaves the group's total in tile_grp[rg][t].
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_colscan(View v, Layout L) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= v.T) return;
+  const int rg = blockIdx.y;
+  const int rpg = (v.nwg + HGS_ROW_GROUPS - 1) / HGS_ROW_GROUPS;
+  const int g0 = rg * rpg, g1 = min(v.nwg, g0 + rpg);
   uint32_t run = 0;
   uint32_t* col = L.hist + t;
-  int g = 0;
-  for (; g + 4 <= v.nwg; g += 4) {
-    const uint32_t c0 = col[(size_t)(g + 0) * v.T], c1 = col[(size_t)(g + 1) * v.T];
-    const uint32_t c2 = col[(size_t)(g + 2) * v.T], c3 = col[(size_t)(g + 3) * v.T];
-    col[(size_t)(g + 0) * v.T] = run; run += c0;
-    col[(size_t)(g + 1) * v.T] = run; run += c1;
-    col[(size_t)(g + 2) * v.T] = run; run += c2;
-    col[(size_t)(g + 3) * v.T] = run; run += c3;
+  constexpr int B = 16;
+  for (int g = g0; g < g1; g += B) {
+    uint32_t c[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) c[k] = (g + k < g1) ? col[(size_t)(g + k) * v.T] : 0u;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      if (g + k < g1) col[(size_t)(g + k) * v.T] = run;
+      run += c[k];
+    }
   }
-  for (; g < v.nwg; ++g) {
-    const uint32_t c = col[(size_t)g * v.T];
-    col[(size_t)g * v.T] = run;
-    run += c;
-  }
-  L.tile_count[t] = run;
+  L.tile_grp[(size_t)rg * v.T + t] = run;
 }
 
 // LDS path, part 2: same workgroup -> chunk ownership as hgs_k_preprocess_fwd.  Slot of an
@@ -139,7 +203,9 @@ hgs_k_fill(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
   if (status->overflow) return;
   const uint32_t* __restrict__ base_row = L.hist + (size_t)blockIdx.x * v.T;
-  for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_cur[t] = L.tile_start[t] + base_row[t];
+  const int rpg = (v.nwg + HGS_ROW_GROUPS - 1) / HGS_ROW_GROUPS;
+  const uint32_t* __restrict__ grp_row = L.tile_grp + (size_t)(blockIdx.x / rpg) * v.T;
+  for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_cur[t] = grp_row[t] + base_row[t];
   __syncthreads();
   for (int c = 0; c < v.cpw; ++c) {
     const int chunk = blockIdx.x * v.cpw + c;

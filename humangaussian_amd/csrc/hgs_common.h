@@ -27,6 +27,7 @@
 #define HGS_BLOCK 256          // Gaussians per preprocess / fill workgroup
 #define HGS_BUCKET 64          // entries per backward bucket (= one wave)
 #define HGS_BWD_WAVES 4        // buckets per backward workgroup
+#define HGS_ROW_GROUPS 4       // histogram row groups scanned in parallel by hgs_k_colscan
 #define HGS_NEAR_Z 0.2f
 #define HGS_ALPHA_MIN (1.0f / 255.0f)
 #define HGS_ALPHA_MAX 0.99f
@@ -68,6 +69,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* tile_wgstart;
   uint32_t* tile_maxcontrib;
   uint32_t* hist;          // [nwg][T] per-workgroup tile histograms -> exclusive bases
+  uint32_t* tile_grp;      // [HGS_ROW_GROUPS][T] row-group totals -> absolute group bases
   unsigned long long* keys;
   SortRec* recs;
   float* bstate;
@@ -84,6 +86,7 @@ struct View {            // per-call constants, passed by value to every kernel
   int32_t P, M, D, nblk;
   int32_t cpw, nwg, lds_bins;   // chunks per binning workgroup, #binning workgroups, LDS path?
   uint32_t entry_capacity;
+  int32_t max_tile_hint;        // >0: caller promises no tile list is longer (else overflow bit 2)
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

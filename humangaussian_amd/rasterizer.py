@@ -44,6 +44,7 @@ class _DeviceState:
 
     def __init__(self):
         self.capacity = 0
+        self.tile_hint = 0          # longest tile list seen (x1.5); 0 = unknown
         self.status_pinned = torch.zeros(8, dtype=torch.int32).pin_memory()
 
 
@@ -167,35 +168,53 @@ class _RasterizeGaussians(torch.autograd.Function):
             st = _state(device)
             stream = torch.cuda.current_stream(device)
             cap = max(st.capacity, _round_capacity(4 * P)) if P > 0 else 0
+            hint = st.tile_hint
             status = None
-            for _ in range(3):
+            bwd = None
+            for _ in range(4):
                 binbuf = torch.empty(lib.hgs_bin_bytes(cap), dtype=torch.uint8, device=device)
                 rc = lib.hgs_forward(
                     ctypes.byref(settings), P, M, _ptr(m3), _ptr(sh_), _ptr(cp_), _ptr(op_),
                     _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(color), _ptr(depth), _ptr(alpha),
                     _ptr(radii), _ptr(geom), _ptr(binbuf), cap, _ptr(img),
-                    1 if want_grad else 0, ctypes.c_void_p(st.status_pinned.data_ptr()),
+                    1 if want_grad else 0, hint, ctypes.c_void_p(st.status_pinned.data_ptr()),
                     _stage_events["fwd"], ctypes.c_void_p(stream.cuda_stream))
                 if rc == -2:
                     raise RuntimeError("inconsistent optional inputs (shs/colors_precomp, "
                                        "scales+rotations/cov3D_precomp)")
                 _check(rc, "hgs_forward")
+                # Host work that does not depend on the result runs HERE, while the GPU is
+                # busy with the forward: everything the backward call will need.
+                if want_grad and bwd is None:
+                    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)  # noqa: E731
+                    bwd = dict(
+                        d_means3D=new(P, 3), d_means2D=new(P, 3), d_opac=new(*opacities.shape),
+                        d_sh=new(P, M, 3) if sh_ is not None else None,
+                        d_cp=new(P, 3) if cp_ is not None else None,
+                        d_sc=new(P, 3) if sc_ is not None else None,
+                        d_ro=new(P, 4) if sc_ is not None else None,
+                        d_cv=new(P, 6) if cv_ is not None else None)
                 # one host sync per forward, like upstream's blocking read of num_rendered
                 stream.synchronize()
                 status = [int(x) & 0xFFFFFFFF for x in st.status_pinned.tolist()]
                 if not status[4]:
                     break
-                cap = _round_capacity(int(status[0] * 1.25) + 1)   # overflow: grow, re-run
+                if status[4] & 1:                     # R exceeded the capacity: grow, re-run
+                    cap = _round_capacity(int(status[0] * 1.25) + 1)
+                if status[4] & 2:                     # a tile list outgrew the hint
+                    hint = 0
             else:
                 raise RuntimeError("libhgs_rast: entry capacity did not converge")
             st.capacity = max(st.capacity, cap)
+            st.tile_hint = max(1024, int(status[6] * 1.5) + 64)
 
         ctx.raster_settings = raster_settings
         ctx.status = status
         ctx.P, ctx.M = P, M
         ctx.has = (sh_ is not None, cp_ is not None, sc_ is not None, cv_ is not None)
-        ctx.in_shapes = (tuple(means3D.shape), tuple(opacities.shape))
         if want_grad:
+            ctx.bwd = bwd
+            ctx.scratch_cap = cap
             ctx.save_for_backward(m3, sh_ if sh_ is not None else m3.new_empty(0),
                                   cp_ if cp_ is not None else m3.new_empty(0), op_,
                                   sc_ if sc_ is not None else m3.new_empty(0),
@@ -219,15 +238,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             gc = None if grad_color is None else _f32c(grad_color, device)
             gd = None if grad_depth is None else _f32c(grad_depth, device)
             ga = None if grad_alpha is None else _f32c(grad_alpha, device)
-            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)  # noqa: E731
-            d_means3D = new(P, 3)
-            d_means2D = new(P, 3)
-            d_opac = new(*ctx.in_shapes[1])
-            d_sh = new(P, M, 3) if has_sh else None
-            d_cp = new(P, 3) if has_cp else None
-            d_sc = new(P, 3) if has_sr else None
-            d_ro = new(P, 4) if has_sr else None
-            d_cv = new(P, 6) if has_cv else None
+            b = ctx.bwd
             st = HgsStatus()
             (st.num_rendered, st.active_tiles, st.num_buckets, st.bwd_groups,
              st.overflow) = ctx.status[:5]
@@ -241,11 +252,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _ptr(ro_ if has_sr else None), _ptr(cv_ if has_cv else None), _ptr(radii),
                 _ptr(color), _ptr(depth), _ptr(alpha), _ptr(gc), _ptr(gd), _ptr(ga),
                 _ptr(geom), _ptr(binbuf), _ptr(img), ctypes.byref(st), _ptr(scratch),
-                _ptr(d_means3D), _ptr(d_means2D), _ptr(d_sh), _ptr(d_cp), _ptr(d_opac),
-                _ptr(d_sc), _ptr(d_ro), _ptr(d_cv), _stage_events["bwd"],
-                ctypes.c_void_p(stream.cuda_stream))
+                _ptr(b["d_means3D"]), _ptr(b["d_means2D"]), _ptr(b["d_sh"]), _ptr(b["d_cp"]),
+                _ptr(b["d_opac"]), _ptr(b["d_sc"]), _ptr(b["d_ro"]), _ptr(b["d_cv"]),
+                _stage_events["bwd"], ctypes.c_void_p(stream.cuda_stream))
             _check(rc, "hgs_backward")
-        return (d_means3D, d_means2D, d_sh, d_cp, d_opac, d_sc, d_ro, d_cv, None, None)
+        ctx.bwd = None
+        return (b["d_means3D"], b["d_means2D"], b["d_sh"], b["d_cp"], b["d_opac"], b["d_sc"],
+                b["d_ro"], b["d_cv"], None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

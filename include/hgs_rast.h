@@ -56,9 +56,11 @@ typedef struct hgs_status {
   uint32_t active_tiles;   /* tiles with a non-empty list                              */
   uint32_t num_buckets;    /* 64-Gaussian bucket states the forward stored             */
   uint32_t bwd_groups;     /* workgroups hgs_backward launches for the blend backward  */
-  uint32_t overflow;       /* != 0: R exceeded entry_capacity; outputs are INVALID,    */
-                           /*       call again with entry_capacity >= num_rendered     */
-  uint32_t reserved[3];    /* [0] = entry_capacity the bin buffer was carved with       */
+  uint32_t overflow;       /* != 0: outputs are INVALID.  bit0: R exceeded              */
+                           /* entry_capacity (retry with >= num_rendered); bit1: a tile */
+                           /* list exceeded max_tile_entries_hint (retry with hint 0)   */
+  uint32_t reserved[3];    /* [0] = entry_capacity the bin buffer was carved with,      */
+                           /* [1] = longest tile list                                   */
 } hgs_status;
 
 /* ---- buffer sizing (host-side arithmetic, no device work) --------------------------
@@ -84,6 +86,9 @@ size_t hgs_bwd_scratch_bytes(int64_t num_rendered);
  * checks.  shs is (P, M, 3); M = max coefficient count of the tensor.
  * out_color (3,H,W), out_depth (1,H,W), out_alpha (1,H,W), radii (P) int32.
  * store_bwd_state = 0 skips the bucket-state stores (no-grad / inference calls).
+ * max_tile_entries_hint: 0 = unknown; > 0 = the caller promises no tile list is longer
+ * (lets the library skip launching sort classes that cannot occur); a broken promise is
+ * detected on the device and reported as overflow bit 1 (value 2) - call again with 0.
  * P == 0 writes background / zeros and reports num_rendered = 0. */
 int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
                 const float* means3D, const float* shs, const float* colors_precomp,
@@ -91,8 +96,8 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
                 const float* cov3D_precomp,
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 void* geom, void* bin, int64_t entry_capacity, void* img,
-                int32_t store_bwd_state, hgs_status* status_host,
-                void* const* stage_events, void* stream);
+                int32_t store_bwd_state, int32_t max_tile_entries_hint,
+                hgs_status* status_host, void* const* stage_events, void* stream);
 
 /* ---- backward: replaces _C.rasterize_gaussians_backward ----------------------------
  * `status` is a HOST copy of what hgs_forward reported (read after the stream has passed

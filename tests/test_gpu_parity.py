@@ -277,3 +277,14 @@ def test_backward_is_deterministic_and_linear():
         if a[k] is not None:
             ref = a[k] + c[k]
             assert (s[k] - ref).abs().max() <= 1e-4 * max(1e-9, ref.abs().max()), k
+
+
+def test_sort_class_hint_violation_is_reported_and_valid_hint_is_exact():
+    sc = make_scene(P=3000, seed=9, H=32, W=32, spread=0.02, scale=0.01)
+    rc = RawCall(sc, capacity=1 << 17, max_tile_hint=1024)
+    assert rc.forward() == 0
+    assert rc.status[4] & 2 and rc.status[6] > 1024        # longest list reported
+    rc2 = RawCall(sc, capacity=1 << 17, max_tile_hint=rc.status[6])
+    assert rc2.forward() == 0 and rc2.status[4] == 0
+    oc, orad, od, oa, _, _ = oracle_forward(sc)
+    check_images(rc2, oc, od, oa)
