@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--points", type=int, default=P_POINTS)
     ap.add_argument("--variant", default="mid", choices=["mid", "init"])
+    ap.add_argument("--async-mode", action="store_true",
+                    help="opt-in: no host sync per forward (rasterizer.set_async)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +96,9 @@ def main():
     gc = (torch.randn(3, RES, RES, generator=g) * 1e-3).to(dev)
     gd = (torch.randn(1, RES, RES, generator=g) * 1e-3).to(dev)
     ga = (torch.randn(1, RES, RES, generator=g) * 1e-3).to(dev)
+
+    if args.async_mode:
+        _rast.set_async(True)
 
     def step():
         for t in leaves.values():
@@ -146,7 +151,7 @@ def main():
             acc[k] += bwd_ev[i].elapsed_time(bwd_ev[i + 1])
     _rast.set_stage_events(None, None)
     stage_us = {k: v / nprof * 1e3 for k, v in acc.items()}
-    R = _rast._state(dev).status_pinned[0].item() & 0xFFFFFFFF
+    R = int(_rast._state(dev).max_R)
     npix, T = RES * RES, (RES // 16) ** 2
     dom = max(stage_us, key=stage_us.get)
     dom_bytes = algorithmic_bytes(dom, P, M, R, npix, T)
@@ -192,6 +197,8 @@ def main():
                                    f"state, SH degree {SH_DEGREE}), one 1024x1024 orbit view per GPU "
                                    "(elev 10, azim 30+45*rank, dist 1.75, fovy 55), fwd+bwd",
                        "views_per_step": world, "num_rendered_R": int(R),
+                       "host_mode": "async (opt-in, no per-forward sync)" if args.async_mode
+                       else "sync (one host sync per forward, as upstream)",
                        "parallelism": f"view-parallel x{world}" + (", 1 all-gather/step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -15,7 +15,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.path.join(_PKG_DIR, "libhgs_rast.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared"]
@@ -50,7 +50,7 @@ EXPORTS = {
                     + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
                                         c_void_p, c_void_p, c_void_p]),
     "hgs_backward": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32] + [c_void_p] * 8
-                     + [c_void_p] * 6 + [c_void_p] * 3 + [POINTER(HgsStatus), c_void_p]
+                     + [c_void_p] * 6 + [c_void_p] * 3 + [POINTER(HgsStatus), c_int64, c_void_p]
                      + [c_void_p] * 8 + [c_void_p, c_void_p]),
     "hgs_mark_visible": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_void_p, c_void_p,
                                         c_void_p]),

@@ -141,7 +141,7 @@ bool settings_ok(const hgs_settings* s) {
 
 extern "C" {
 
-int hgs_abi_version(void) { return 3; }
+int hgs_abi_version(void) { return 4; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;
@@ -263,37 +263,43 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
                  const float* out_alpha, const float* dL_dout_color,
                  const float* dL_dout_depth, const float* dL_dout_alpha, const void* geom,
                  const void* bin, const void* img, const hgs_status* status,
-                 void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                 int64_t entry_capacity, void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                  float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                  float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
                  void* stream_) {
   (void)opacities; (void)radii;
-  if (!settings_ok(s) || P < 0 || !status || !geom || !img) return HGS_EINVAL;
-  if (status->overflow) return HGS_EINVAL;
+  if (!settings_ok(s) || P < 0 || !geom || !img || entry_capacity < 0) return HGS_EINVAL;
+  if (status && status->overflow) return HGS_EINVAL;
+  if (status && (int64_t)status->reserved[0] != entry_capacity) return HGS_EINVAL;
   if (P == 0) return HGS_OK;
   if (!means3D || !out_color || !out_depth || !out_alpha) return HGS_EINVAL;
   if ((shs != nullptr) == (colors_precomp != nullptr)) return HGS_ESHAPE;
   if ((scales != nullptr) != (rotations != nullptr)) return HGS_ESHAPE;
   if ((scales != nullptr) == (cov3D_precomp != nullptr)) return HGS_ESHAPE;
   if (shs && !dL_dshs) return HGS_EINVAL;
-  if (status->num_rendered > 0 && (!bin || !bwd_scratch)) return HGS_EINVAL;
+  const bool maybe_entries = status ? status->num_rendered > 0 : entry_capacity > 0;
+  if (maybe_entries && (!bin || !bwd_scratch)) return HGS_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  // entry_capacity only fixes the carve offsets of keys/recs/bstate: the caller must pass
-  // the same bin buffer, and the capacity travels in reserved[0] of the status block.
-  const int64_t cap = (int64_t)status->reserved[0];
+  const int64_t cap = entry_capacity;
   const View v = make_view(s, P, M, cap);
   const Layout L = make_layout(const_cast<void*>(geom), const_cast<void*>(bin),
                                const_cast<void*>(img), P, v.H, v.W, cap);
+  const hgs_status* status_dev = reinterpret_cast<const hgs_status*>(
+      static_cast<const char*>(geom) + carve_geom(P, v.H, v.W).status);
+  // host status known: exact grid.  Unknown: capacity bound, surplus workgroups exit.
+  const uint32_t groups = status ? status->bwd_groups
+                                 : (maybe_entries ? (uint32_t)(cap / 256 + v.T) : 0u);
   float* rows = static_cast<float*>(bwd_scratch);
   HGS_STAGE(0);
-  if (status->bwd_groups > 0) {
-    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(status->bwd_groups), dim3(256), 0, stream, v, L,
+  if (groups > 0) {
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(groups), dim3(256), 0, stream, v, L, status_dev,
                        L.recs, L.bstate, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
                        dL_dout_alpha, rows);
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(1);
-  hipLaunchKernelGGL(hgs_k_preprocess_bwd, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, rows,
+  hipLaunchKernelGGL(hgs_k_preprocess_bwd, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
+                     status_dev, rows,
                      means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans3D,
                      dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales,
                      dL_drotations, dL_dcov3D_precomp);

@@ -305,7 +305,8 @@ hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
 // => deterministic), then chains through conic -> cov2D -> (cov3D, mean), projection,
 // depth, SH and Sigma = R S^2 R^T.  Every output element is written exactly once.
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
-hgs_k_preprocess_bwd(View v, Layout L, const float* __restrict__ grad_rows,
+hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
+                     const float* __restrict__ grad_rows,
                      const float* __restrict__ means3D, const float* __restrict__ shs,
                      const float* __restrict__ colors_precomp,
                      const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -327,7 +328,7 @@ hgs_k_preprocess_bwd(View v, Layout L, const float* __restrict__ grad_rows,
   float drot[4] = {0.f, 0.f, 0.f, 0.f};
   float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float draw[3] = {0.f, 0.f, 0.f};     // gradient wrt the pre-clamp colour
-  const bool vis = g.radius > 0;
+  const bool vis = (g.radius > 0) && (status->overflow == 0);
 
   if (vis) {
     const int rw = (int)(g.rect_hi & 0xffffu) - (int)(g.rect_lo & 0xffffu);

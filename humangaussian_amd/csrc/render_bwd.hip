@@ -38,7 +38,8 @@ __device__ __forceinline__ float wave_shift_in(float prev_out, float first) {
 }  // namespace
 
 extern "C" __global__ void __launch_bounds__(256)
-hgs_k_render_bwd(View v, Layout L, const SortRec* __restrict__ recs_all,
+hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
+                 const SortRec* __restrict__ recs_all,
                  const float* __restrict__ bstate, const float* __restrict__ out_color,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
@@ -50,6 +51,7 @@ hgs_k_render_bwd(View v, Layout L, const SortRec* __restrict__ recs_all,
 
   // ---- which (tile, bucket group) is this workgroup?  binary search the WG prefix
   const uint32_t g = blockIdx.x;
+  if (status->overflow || g >= L.tile_wgstart[v.T]) return;   // surplus workgroup
   int lo = 0, hi = v.T;                       // invariant: wgstart[lo] <= g < wgstart[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;

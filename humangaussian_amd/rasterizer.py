@@ -13,6 +13,7 @@ There is no CPU path: non-HIP tensors raise.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -39,16 +40,50 @@ class GaussianRasterizationSettings(NamedTuple):
 
 # ---------------------------------------------------------------------------- plumbing
 
+class _Pending:
+    """An async forward whose status has not been inspected yet."""
+    __slots__ = ("event", "slot", "cap", "hint")
+
+
 class _DeviceState:
-    """Per-device grow-only estimate of the entry capacity (R) + a pinned status mirror."""
+    """Per-device grow-only estimates (entry capacity R, longest tile list) and a small ring
+    of pinned status mirrors."""
+    RING = 8
 
     def __init__(self):
         self.capacity = 0
-        self.tile_hint = 0          # longest tile list seen (x1.5); 0 = unknown
-        self.status_pinned = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.tile_hint = 0          # longest tile list seen (with margin); 0 = unknown
+        self.max_R = 0
+        self.max_tile = 0
+        self.status_ring = torch.zeros(self.RING, 8, dtype=torch.int32).pin_memory()
+        self.ring_pos = 0
+        self.pending: list = []
+        self.synced_calls = 0
+
+    def next_slot(self):
+        i = self.ring_pos
+        self.ring_pos = (i + 1) % self.RING
+        return i
+
+    def observe(self, status):
+        self.max_R = max(self.max_R, status[0])
+        self.max_tile = max(self.max_tile, status[6])
 
 
 _device_state: dict = {}
+_async_mode = [os.environ.get("HGS_ASYNC", "0") not in ("", "0")]
+
+
+def set_async(enabled: bool):
+    """Opt-in asynchronous mode.  Default (False) mirrors upstream: one host sync per
+    forward to read num_rendered, overflow handled transparently by re-running.  With
+    async enabled a forward that needs gradients returns WITHOUT synchronising once the
+    workload is known (two synchronous calls first): buffers are sized with a 2x margin over
+    the largest R seen, the backward needs nothing from the host, and the status words of
+    earlier calls are inspected lazily - an overflow (R more than doubled between
+    consecutive calls) is then reported as a RuntimeError on a later call, after that
+    call's outputs were already handed out.  Use for steady-state training loops."""
+    _async_mode[0] = bool(enabled)
 
 
 def _state(device: torch.device) -> _DeviceState:
@@ -123,6 +158,31 @@ def _round_capacity(n: int) -> int:
     return max(1 << 16, (int(n) + 0xFFFF) & ~0xFFFF)
 
 
+def _read_status(st: _DeviceState, slot: int):
+    return [int(x) & 0xFFFFFFFF for x in st.status_ring[slot].tolist()]
+
+
+def _drain_pending(st: _DeviceState, block: bool = False):
+    """Inspect the status of earlier async forwards whose copy has landed."""
+    while st.pending:
+        p = st.pending[0]
+        if block:
+            p.event.synchronize()
+        elif not p.event.query():
+            break
+        st.pending.pop(0)
+        status = _read_status(st, p.slot)
+        st.observe(status)
+        if status[4]:
+            st.capacity = max(st.capacity, _round_capacity(2 * status[0]))
+            st.tile_hint = 0
+            raise RuntimeError(
+                "humangaussian_amd (async mode): an earlier render overflowed its buffers "
+                f"(num_rendered={status[0]}, capacity={p.cap}, longest tile list={status[6]}, "
+                f"hint={p.hint}); its outputs and gradients were invalid.  Capacity has been "
+                "raised; re-run the step (or disable async mode).")
+
+
 # ------------------------------------------------------------------------ autograd node
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -158,26 +218,33 @@ class _RasterizeGaussians(torch.autograd.Function):
             if sh_ is not None and (sh_.dim() != 3 or sh_.shape[0] != P or sh_.shape[2] != 3):
                 raise RuntimeError("shs must have dimensions (num_points, M, 3)")
 
-            color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-            depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
-            alpha = torch.empty((1, H, W), dtype=torch.float32, device=device)
+            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)  # noqa: E731
+            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=device)  # noqa: E731
+            color, depth, alpha = new(3, H, W), new(1, H, W), new(1, H, W)
             radii = torch.empty((P,), dtype=torch.int32, device=device)
-            geom = torch.empty(lib.hgs_geom_bytes(P, H, W), dtype=torch.uint8, device=device)
-            img = torch.empty(lib.hgs_img_bytes(H, W), dtype=torch.uint8, device=device)
+            geom = u8(lib.hgs_geom_bytes(P, H, W))
+            img = u8(lib.hgs_img_bytes(H, W))
 
             st = _state(device)
             stream = torch.cuda.current_stream(device)
-            cap = max(st.capacity, _round_capacity(4 * P)) if P > 0 else 0
-            hint = st.tile_hint
+            _drain_pending(st)
+            go_async = bool(_async_mode[0] and want_grad and P > 0 and st.synced_calls >= 2)
+            if go_async:
+                cap = max(st.capacity, _round_capacity(2 * st.max_R))
+                hint = max(1024, 2 * st.max_tile + 64)
+            else:
+                cap = max(st.capacity, _round_capacity(4 * P)) if P > 0 else 0
+                hint = st.tile_hint
             status = None
             bwd = None
             for _ in range(4):
-                binbuf = torch.empty(lib.hgs_bin_bytes(cap), dtype=torch.uint8, device=device)
+                binbuf = u8(lib.hgs_bin_bytes(cap))
+                slot = st.next_slot()
                 rc = lib.hgs_forward(
                     ctypes.byref(settings), P, M, _ptr(m3), _ptr(sh_), _ptr(cp_), _ptr(op_),
                     _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(color), _ptr(depth), _ptr(alpha),
                     _ptr(radii), _ptr(geom), _ptr(binbuf), cap, _ptr(img),
-                    1 if want_grad else 0, hint, ctypes.c_void_p(st.status_pinned.data_ptr()),
+                    1 if want_grad else 0, hint, ctypes.c_void_p(st.status_ring[slot].data_ptr()),
                     _stage_events["fwd"], ctypes.c_void_p(stream.cuda_stream))
                 if rc == -2:
                     raise RuntimeError("inconsistent optional inputs (shs/colors_precomp, "
@@ -186,17 +253,25 @@ class _RasterizeGaussians(torch.autograd.Function):
                 # Host work that does not depend on the result runs HERE, while the GPU is
                 # busy with the forward: everything the backward call will need.
                 if want_grad and bwd is None:
-                    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)  # noqa: E731
                     bwd = dict(
                         d_means3D=new(P, 3), d_means2D=new(P, 3), d_opac=new(*opacities.shape),
                         d_sh=new(P, M, 3) if sh_ is not None else None,
                         d_cp=new(P, 3) if cp_ is not None else None,
                         d_sc=new(P, 3) if sc_ is not None else None,
                         d_ro=new(P, 4) if sc_ is not None else None,
-                        d_cv=new(P, 6) if cv_ is not None else None)
+                        d_cv=new(P, 6) if cv_ is not None else None,
+                        settings=settings, keep=keep, stream=stream)
+                if go_async:
+                    p = _Pending()
+                    p.event, p.slot, p.cap, p.hint = torch.cuda.Event(), slot, cap, hint
+                    p.event.record(stream)
+                    st.pending.append(p)
+                    if len(st.pending) >= st.RING - 1:     # never let the ring wrap
+                        _drain_pending(st, block=True)
+                    break
                 # one host sync per forward, like upstream's blocking read of num_rendered
                 stream.synchronize()
-                status = [int(x) & 0xFFFFFFFF for x in st.status_pinned.tolist()]
+                status = _read_status(st, slot)
                 if not status[4]:
                     break
                 if status[4] & 1:                     # R exceeded the capacity: grow, re-run
@@ -205,16 +280,27 @@ class _RasterizeGaussians(torch.autograd.Function):
                     hint = 0
             else:
                 raise RuntimeError("libhgs_rast: entry capacity did not converge")
-            st.capacity = max(st.capacity, cap)
-            st.tile_hint = max(1024, int(status[6] * 1.5) + 64)
+            if status is not None:
+                st.observe(status)
+                st.synced_calls += 1
+                st.capacity = max(st.capacity, cap)
+                st.tile_hint = max(1024, int(status[6] * 1.5) + 64)
+            if want_grad:
+                bwd["cap"] = cap
+                bwd["scratch"] = u8(lib.hgs_bwd_scratch_bytes(cap if status is None else status[0]))
+                if status is not None:
+                    hs = HgsStatus()
+                    (hs.num_rendered, hs.active_tiles, hs.num_buckets, hs.bwd_groups,
+                     hs.overflow) = status[:5]
+                    hs.reserved[0], hs.reserved[1], hs.reserved[2] = status[5:8]
+                    bwd["status"] = hs
+                else:
+                    bwd["status"] = None
 
-        ctx.raster_settings = raster_settings
-        ctx.status = status
         ctx.P, ctx.M = P, M
         ctx.has = (sh_ is not None, cp_ is not None, sc_ is not None, cv_ is not None)
         if want_grad:
             ctx.bwd = bwd
-            ctx.scratch_cap = cap
             ctx.save_for_backward(m3, sh_ if sh_ is not None else m3.new_empty(0),
                                   cp_ if cp_ is not None else m3.new_empty(0), op_,
                                   sc_ if sc_ is not None else m3.new_empty(0),
@@ -232,30 +318,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         has_sh, has_cp, has_sr, has_cv = ctx.has
         device = m3.device
         P, M = ctx.P, ctx.M
-        keep: list = []
-        with torch.cuda.device(device):
-            settings = _make_settings(ctx.raster_settings, device, keep)
-            gc = None if grad_color is None else _f32c(grad_color, device)
-            gd = None if grad_depth is None else _f32c(grad_depth, device)
-            ga = None if grad_alpha is None else _f32c(grad_alpha, device)
-            b = ctx.bwd
-            st = HgsStatus()
-            (st.num_rendered, st.active_tiles, st.num_buckets, st.bwd_groups,
-             st.overflow) = ctx.status[:5]
-            st.reserved[0], st.reserved[1], st.reserved[2] = ctx.status[5:8]
-            scratch = torch.empty(lib.hgs_bwd_scratch_bytes(st.num_rendered), dtype=torch.uint8,
-                                  device=device)
-            stream = torch.cuda.current_stream(device)
-            rc = lib.hgs_backward(
-                ctypes.byref(settings), P, M, _ptr(m3), _ptr(sh_ if has_sh else None),
-                _ptr(cp_ if has_cp else None), _ptr(op_), _ptr(sc_ if has_sr else None),
-                _ptr(ro_ if has_sr else None), _ptr(cv_ if has_cv else None), _ptr(radii),
-                _ptr(color), _ptr(depth), _ptr(alpha), _ptr(gc), _ptr(gd), _ptr(ga),
-                _ptr(geom), _ptr(binbuf), _ptr(img), ctypes.byref(st), _ptr(scratch),
-                _ptr(b["d_means3D"]), _ptr(b["d_means2D"]), _ptr(b["d_sh"]), _ptr(b["d_cp"]),
-                _ptr(b["d_opac"]), _ptr(b["d_sc"]), _ptr(b["d_ro"]), _ptr(b["d_cv"]),
-                _stage_events["bwd"], ctypes.c_void_p(stream.cuda_stream))
-            _check(rc, "hgs_backward")
+        b = ctx.bwd
+        gc = None if grad_color is None else _f32c(grad_color, device)
+        gd = None if grad_depth is None else _f32c(grad_depth, device)
+        ga = None if grad_alpha is None else _f32c(grad_alpha, device)
+        stream = torch.cuda.current_stream(device)
+        hs = b["status"]
+        rc = lib.hgs_backward(
+            ctypes.byref(b["settings"]), P, M, _ptr(m3), _ptr(sh_ if has_sh else None),
+            _ptr(cp_ if has_cp else None), _ptr(op_), _ptr(sc_ if has_sr else None),
+            _ptr(ro_ if has_sr else None), _ptr(cv_ if has_cv else None), _ptr(radii),
+            _ptr(color), _ptr(depth), _ptr(alpha), _ptr(gc), _ptr(gd), _ptr(ga),
+            _ptr(geom), _ptr(binbuf), _ptr(img), None if hs is None else ctypes.byref(hs),
+            b["cap"], _ptr(b["scratch"]),
+            _ptr(b["d_means3D"]), _ptr(b["d_means2D"]), _ptr(b["d_sh"]), _ptr(b["d_cp"]),
+            _ptr(b["d_opac"]), _ptr(b["d_sc"]), _ptr(b["d_ro"]), _ptr(b["d_cv"]),
+            _stage_events["bwd"], ctypes.c_void_p(stream.cuda_stream))
+        _check(rc, "hgs_backward")
         ctx.bwd = None
         return (b["d_means3D"], b["d_means2D"], b["d_sh"], b["d_cp"], b["d_opac"], b["d_sc"],
                 b["d_ro"], b["d_cv"], None, None)

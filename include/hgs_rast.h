@@ -101,7 +101,13 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
 
 /* ---- backward: replaces _C.rasterize_gaussians_backward ----------------------------
  * `status` is a HOST copy of what hgs_forward reported (read after the stream has passed
- * the forward).  out_* are the forward's outputs (unmodified), dL_dout_* the incoming
+ * the forward), or NULL: then nothing about the forward's result is needed on the host -
+ * the blend backward is launched with the capacity-derived upper bound of workgroups
+ * (entry_capacity/256 + tiles) and every kernel reads the device-side status (an
+ * overflowed forward yields all-zero gradients).  `entry_capacity` must equal the value
+ * given to hgs_forward (it fixes the carve of `bin`), bwd_scratch must hold
+ * hgs_bwd_scratch_bytes(num_rendered) - or (entry_capacity) when status is NULL.
+ * out_* are the forward's outputs (unmodified), dL_dout_* the incoming
  * gradients (any of them may be NULL = zeros).  Every dL_d* output that is non-NULL is
  * fully overwritten (no pre-zeroing needed, no atomics: results are deterministic);
  * dL_dmeans2D is (P,3) in NDC units with z = 0. */
@@ -113,7 +119,7 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M,
                  const float* dL_dout_color, const float* dL_dout_depth,
                  const float* dL_dout_alpha,
                  const void* geom, const void* bin, const void* img,
-                 const hgs_status* status, void* bwd_scratch,
+                 const hgs_status* status, int64_t entry_capacity, void* bwd_scratch,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                  float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                  float* dL_drotations, float* dL_dcov3D_precomp,

@@ -83,7 +83,7 @@ class RawCall:
         raw = self.geom[: self.P * 64].cpu().numpy().tobytes()
         return np.frombuffer(raw, dtype=GEOM_DTYPE)
 
-    def backward(self, g_color, g_depth, g_alpha):
+    def backward(self, g_color, g_depth, g_alpha, use_status=True):
         lib, dev, P, M = self.lib, self.dev, self.P, self.M
         d = lambda t: None if t is None else t.to(dev).float().contiguous()  # noqa: E731
         gc, gd, ga = d(g_color), d(g_depth), d(g_alpha)
@@ -97,13 +97,13 @@ class RawCall:
         st = HgsStatus()
         (st.num_rendered, st.active_tiles, st.num_buckets, st.bwd_groups, st.overflow) = self.status[:5]
         st.reserved[0], st.reserved[1], st.reserved[2] = self.status[5:8]
-        scratch = torch.zeros(int(lib.hgs_bwd_scratch_bytes(st.num_rendered)), dtype=torch.uint8, device=dev)
+        scratch = torch.zeros(int(lib.hgs_bwd_scratch_bytes(st.num_rendered if use_status else self.capacity)), dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev)
         rc = lib.hgs_backward(ctypes.byref(self.settings), P, M, _p(self.means3D), _p(self.shs),
                               _p(self.colors_precomp), _p(self.opac), _p(self.scales), _p(self.rots),
                               _p(self.cov3D), _p(self.radii), _p(self.color), _p(self.depth),
                               _p(self.alpha), _p(gc), _p(gd), _p(ga), _p(self.geom), _p(self.bin),
-                              _p(self.img), ctypes.byref(st), _p(scratch), _p(out["means3D"]),
+                              _p(self.img), (ctypes.byref(st) if use_status else None), self.capacity, _p(scratch), _p(out["means3D"]),
                               _p(out["means2D"]), _p(out["shs"]), _p(out["colors_precomp"]),
                               _p(out["opacities"]), _p(out["scales"]), _p(out["rotations"]),
                               _p(out["cov3D_precomp"]), None, ctypes.c_void_p(stream.cuda_stream))

