@@ -57,8 +57,11 @@ def allgather_reduce(pack: torch.Tensor, group=None) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return pack
     world = dist.get_world_size(group)
-    gathered = torch.empty((world,) + tuple(pack.shape), dtype=pack.dtype, device=pack.device)
-    dist.all_gather_into_tensor(gathered, pack, group=group)
+    # flat (world*P, F) output: the concatenation form is accepted by both RCCL and gloo
+    flat = torch.empty((world * pack.shape[0],) + tuple(pack.shape[1:]), dtype=pack.dtype,
+                       device=pack.device)
+    dist.all_gather_into_tensor(flat, pack, group=group)
+    gathered = flat.view((world,) + tuple(pack.shape))
     total = gathered[0].clone()
     for r in range(1, world):                     # fixed order => deterministic sum
         total[:, :-1] += gathered[r][:, :-1]
@@ -122,8 +125,10 @@ def gather_view_images(outputs, num_views: int, group=None):
     slab = torch.zeros((per_rank, 5) + tuple(c0.shape[1:]), dtype=c0.dtype, device=c0.device)
     for i, (_, c, d, a) in enumerate(outputs):
         slab[i, :3], slab[i, 3:4], slab[i, 4:5] = c, d, a
-    allslab = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype, device=slab.device)
-    dist.all_gather_into_tensor(allslab, slab, group=group)
+    flat = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype,
+                       device=slab.device)
+    dist.all_gather_into_tensor(flat, slab, group=group)
+    allslab = flat.view((world,) + tuple(slab.shape))
     res = []
     for v in range(num_views):
         s = allslab[v % world, v // world]

@@ -339,9 +339,11 @@ def _blend_tile(pxf, pyf, xy, conic, opac, rgb, depth, chunk=4096):
 
 def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
               cov3D_precomp, settings: OracleSettings, dtype=torch.float32,
-              return_aux: bool = False):
+              return_aux: bool = False, tile_stride: int = 1):
     """Full forward (differentiable).  Returns color (3,H,W), radii (P,) int32,
-    depth (1,H,W), alpha (1,H,W) [+ aux dict]."""
+    depth (1,H,W), alpha (1,H,W) [+ aux dict].  tile_stride > 1 blends only every
+    tile_stride-th non-empty tile (the rest stay background): a bounded SAMPLE of the
+    workload for timing the CPU baseline, never used for parity."""
     H, W = int(settings.image_height), int(settings.image_width)
     bg = settings.bg.to(dtype).reshape(3)
     P = means3D.shape[0]
@@ -361,6 +363,9 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
     gx, gy = pre["grid"]
     color_parts, depth_parts, alpha_parts = [], [], []
     active = torch.nonzero(ranges[:, 1] > ranges[:, 0]).reshape(-1).tolist()
+    n_active_total = len(active)
+    if tile_stride > 1:
+        active = active[::tile_stride]
     colors_out = color
     for t in active:
         s, e = int(ranges[t, 0]), int(ranges[t, 1])
@@ -407,5 +412,6 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
     out = (colors_out, pre["radii"], depth, alpha)
     if return_aux:
         return out + ({"n_contrib": n_contrib_img, "final_T": final_T, "pre": pre,
-                       "ranges": ranges, "g_sorted": g_sorted},)
+                       "ranges": ranges, "g_sorted": g_sorted,
+                       "active_tiles": n_active_total, "blended_tiles": len(active)},)
     return out

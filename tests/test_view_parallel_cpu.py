@@ -1,0 +1,104 @@
+"""World-size-2 gloo tests of the view-parallel host logic (runs on CPU: the oracle is
+injected as the rasterizer; the product default is the HIP rasterizer)."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from helpers import make_scene
+from humangaussian_amd import synth
+from humangaussian_amd import view_parallel as vp
+
+NUM_VIEWS = 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_render_fn(cam, leaves, means2D, bg, sh_degree):
+    st = oracle.OracleSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5),
+                               math.tan(cam.FoVy * 0.5), bg, 1.0, cam.world_view_transform,
+                               cam.full_proj_transform, sh_degree, cam.camera_center, False, False)
+    return oracle.rasterize(leaves["means3D"], means2D, leaves["shs"], None, leaves["opacities"],
+                            leaves["scales"], leaves["rotations"], None, st, dtype=torch.float64)
+
+
+def _scene_and_cams():
+    sc = make_scene(P=60, sh_degree=1, seed=5, H=32, W=32, spread=0.3, scale=0.08)
+    cams = [synth.orbit_camera(10.0 * (v - 1), 90.0 * v, 2.0, 50.0, 32, 32) for v in range(NUM_VIEWS)]
+    params = {k: sc[k].double() for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    return sc, cams, params
+
+
+def _loss_grad(v, color, depth, alpha):
+    g = torch.Generator().manual_seed(100 + v)
+    return (torch.randn(color.shape, generator=g, dtype=torch.float64),
+            torch.randn(depth.shape, generator=g, dtype=torch.float64), None)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sc, cams, params = _scene_and_cams()
+    grads, radii, outs = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
+                                                  render_fn=_oracle_render_fn, gather_images=True)
+    q.put((rank, {k: v.clone() for k, v in grads.items()}, radii.clone(),
+           [(v, c.clone()) for v, c, _, _ in outs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_views_round_robin():
+    assert vp.shard_views(8, 0, 8) == [0] and vp.shard_views(8, 7, 8) == [7]
+    assert vp.shard_views(300, 3, 8)[:3] == [3, 11, 19]
+    assert sorted(sum((vp.shard_views(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def test_pack_roundtrip():
+    P, M = 7, 4
+    g = {"means3D": torch.randn(P, 3), "means2D": torch.randn(P, 3), "shs": torch.randn(P, M, 3),
+         "opacities": torch.randn(P, 1), "scales": torch.randn(P, 3), "rotations": torch.randn(P, 4)}
+    r = torch.randint(0, 500, (P,), dtype=torch.int32)
+    pack = vp.pack_contribution(g, r)
+    assert pack.shape == (P, 3 + 3 + 3 * M + 1 + 3 + 4 + 1)
+    g2, r2 = vp.unpack_contribution(pack, {k: v.shape for k, v in g.items()})
+    assert torch.equal(r, r2) and all(torch.equal(g[k], g2[k]) for k in g)
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_reproduce_the_serial_accumulation():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # serial reference = what the single-GPU loop accumulates (GaussianDreamer.py:244-266,385-391)
+    sc, cams, params = _scene_and_cams()
+    ref, rref, _ = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
+                                            render_fn=_oracle_render_fn)
+    for rank, grads, radii, outs in res:
+        assert torch.equal(radii, rref)
+        for k in ref:
+            assert torch.allclose(grads[k], ref[k].float().to(grads[k].dtype), rtol=1e-5, atol=1e-7), k
+        assert [v for v, _ in outs] == list(range(NUM_VIEWS))      # every rank holds all views
+    # both ranks hold bit-identical results (fixed reduction order)
+    for k in ref:
+        assert torch.equal(res[0][1][k], res[1][1][k])
+    for (v0, c0), (v1, c1) in zip(res[0][3], res[1][3]):
+        assert v0 == v1 and torch.equal(c0, c1)
