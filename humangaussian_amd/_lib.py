@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
-LIB_PATH = os.path.join(_PKG_DIR, "libhgs_rast.so")
+LIB_PATH = os.environ.get("HGS_LIB") or os.path.join(_PKG_DIR, "libhgs_rast.so")   # HGS_LIB: A/B experiments only
 ABI_VERSION = 4
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -62,28 +62,48 @@ def sources():
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    target = os.path.join(_PKG_DIR, "libhgs_rast.so")
+    if not os.path.exists(target):
         return True
-    mt = os.path.getmtime(LIB_PATH)
+    mt = os.path.getmtime(target)
     deps = sources() + [os.path.join(_PKG_DIR, "..", "include", "hgs_rast.h")]
     return any(os.path.getmtime(s) > mt for s in deps)
 
 
+# translation units: (source, extra flags)
+UNITS = [("api.hip", []),
+         ("render_bwd.hip", ["-fno-slp-vectorize"])]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/api.hip (single TU including all kernels) for gfx950 with hipcc."""
+    """Compile the translation units for gfx950 with hipcc and link libhgs_rast.so."""
+    target = os.path.join(_PKG_DIR, "libhgs_rast.so")
     if not force and not needs_build():
-        return LIB_PATH
+        return target
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libhgs_rast.so")
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(_CSRC, "api.hip"), "-o", LIB_PATH + ".tmp"]
+    common = [f for f in HIPCC_FLAGS if f != "-shared"]
+    objs = []
+    for src, extra in UNITS:
+        obj = os.path.join(_PKG_DIR, "_build_" + src.replace(".hip", ".o"))
+        cmd = [hipcc] + common + extra + ["-c", os.path.join(_CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    os.replace(target + ".tmp", target)
+    for o in objs:
+        os.remove(o)
+    return target
 
 
 _lib = None

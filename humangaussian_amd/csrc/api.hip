@@ -7,11 +7,17 @@
 // Backward: render_bwd (bucket-parallel) -> preprocess_bwd.
 #include "hgs_common.h"
 
-// Single translation unit: the kernels are included so the launches below bind directly.
+// The forward kernels and the per-Gaussian backward are included here (one translation
+// unit, SLP vectorisation on: the forward blend is latency-bound and profits from v_pk_*).
 #include "preprocess.hip"
 #include "binning.hip"
 #include "render_fwd.hip"
-#include "render_bwd.hip"
+
+// render_bwd.hip is a separate translation unit (different optimisation flags)
+extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*,
+                                            const float*, const float*, const float*,
+                                            const float*, const float*, const float*,
+                                            const float*, float*);
 
 namespace {
 

@@ -7,7 +7,8 @@
 //
 //     step s:  lane l handles pixel p = s - l;  the pixel's running state (T, F) enters
 //              lane 0 from the bucket-boundary state the forward stored, and moves one
-//              lane per step with a single DPP wave-shift.
+//              lane per step (ds_bpermute through the LDS crossbar; a DPP wave_shr:1
+//              variant is kept behind HGS_BWD_DPP_SHIFT).
 //
 // with  S_j   = c_j . g_C + d_j g_D + g_A                 (g_* = incoming pixel gradients)
 //       F_i   = sum_{j<=i} w_j S_j,   w_j = alpha_j T_j   (prefix, flows with T)
@@ -24,15 +25,28 @@
 // entry: 48 B record + 24 B/pixel/bucket state (= 96 B/entry) in, 48 B row out.
 #include "hgs_common.h"
 
+// This file is its own translation unit, built with -fno-slp-vectorize: the kernel is
+// VALU-throughput-bound with ~6 waves per SIMD, where v_pk_* packing (same flop rate as
+// scalar fp32 ops on gfx950, measured with tools/valu_ubench.hip) only adds register moves
+// (207 -> 180 us at config 2).
+
 namespace {
 
 // shift a value one lane up the wave (lane l receives lane l-1); lane 0 receives `first`.
-__device__ __forceinline__ float wave_shift_in(float prev_out, float first) {
+__device__ __forceinline__ float wave_shift_in(float prev_out, float first, int lane) {
+#ifndef HGS_BWD_DPP_SHIFT
+  // through the LDS crossbar (ds_bpermute): measured 174 us vs 180 us for the DPP form at
+  // config 2 - v_mov_dpp wave_shr costs ~8 cycles of VALU issue, the LDS pipe has slack
+  const float up = __shfl_up(prev_out, 1, 64);
+  return lane == 0 ? first : up;
+#else
   // DPP wave_shr:1 (0x138): GFX9-family full-wave shift; lane 0 has no source and keeps
   // `old` (bound_ctrl = 0), which we preload with the value entering the pipeline.
+  (void)lane;
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first),
                                                     __float_as_int(prev_out), 0x138, 0xf, 0xf,
                                                     false));
+#endif
 }
 
 }  // namespace
@@ -149,11 +163,11 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   float T_out = 1.0f, F_out = 0.0f;
 
   for (int s = 0; s < nsteps; ++s) {
-    const int pe = min(s, 255);
-    const float T_in = wave_shift_in(T_out, T0w[pe]);
-    const float F_in = wave_shift_in(F_out, F0w[pe]);
     const int p = s - lane;
     const int pc = min(max(p, 0), 255);
+    const int pe = min(s, 255);
+    const float T_in = wave_shift_in(T_out, T0w[pe], lane);
+    const float F_in = wave_shift_in(F_out, F0w[pe], lane);
     const float4 pa = s_pix[2 * pc + 0];      // gC0 gC1 gC2 gD
     const float4 pb = s_pix[2 * pc + 1];      // gA F' n_contrib pixel_x
     // same dx/dy expressions as the forward (absolute pixel centre) so skip decisions agree
