@@ -147,7 +147,7 @@ bool settings_ok(const hgs_settings* s) {
 
 extern "C" {
 
-int hgs_abi_version(void) { return 4; }
+int hgs_abi_version(void) { return 5; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;
@@ -168,7 +168,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 void* geom, void* bin, int64_t entry_capacity, void* img,
                 int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
-                void* const* stage_events, void* stream_) {
+                void* status_event, void* const* stage_events, void* stream_) {
   if (!settings_ok(s) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
     return HGS_EINVAL;
@@ -213,6 +213,15 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
   hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
+  // the status is final here: publish it now so the host can wait for it alone
+  if (status_host) {
+    e = hipMemcpyAsync(status_host, status_dev, sizeof(hgs_status), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  if (status_event) {
+    e = hipEventRecord(static_cast<hipEvent_t>(status_event), stream);
+    if (e != hipSuccess) return hip_rc(e);
+  }
   if (v.nblk > 0 && entry_capacity > 0) {
     if (v.lds_bins)
       hipLaunchKernelGGL(hgs_k_fill, dim3(v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v, L,
@@ -255,10 +264,6 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                        status_dev, L.recs, L.bstate, out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(5);
-  if (status_host) {
-    e = hipMemcpyAsync(status_host, status_dev, sizeof(hgs_status), hipMemcpyDeviceToHost, stream);
-    if (e != hipSuccess) return hip_rc(e);
-  }
   return HGS_OK;
 }
 

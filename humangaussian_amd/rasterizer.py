@@ -56,6 +56,10 @@ class _DeviceState:
         self.max_R = 0
         self.max_tile = 0
         self.status_ring = torch.zeros(self.RING, 8, dtype=torch.int32).pin_memory()
+        # recorded by the library right behind the status copy (after the scan stage)
+        self.status_event = torch.cuda.Event()
+        self.status_event.record()
+        self.status_event.synchronize()
         self.ring_pos = 0
         self.pending: list = []
         self.synced_calls = 0
@@ -245,6 +249,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(color), _ptr(depth), _ptr(alpha),
                     _ptr(radii), _ptr(geom), _ptr(binbuf), cap, _ptr(img),
                     1 if want_grad else 0, hint, ctypes.c_void_p(st.status_ring[slot].data_ptr()),
+                    None if go_async else ctypes.c_void_p(st.status_event.cuda_event),
                     _stage_events["fwd"], ctypes.c_void_p(stream.cuda_stream))
                 if rc == -2:
                     raise RuntimeError("inconsistent optional inputs (shs/colors_precomp, "
@@ -269,8 +274,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                     if len(st.pending) >= st.RING - 1:     # never let the ring wrap
                         _drain_pending(st, block=True)
                     break
-                # one host sync per forward, like upstream's blocking read of num_rendered
-                stream.synchronize()
+                # One host wait per forward, like upstream's blocking read of num_rendered -
+                # but only for the status (published right after the scan stage): fill, sort
+                # and blend are already enqueued and keep running while the host goes on.
+                st.status_event.synchronize()
                 status = _read_status(st, slot)
                 if not status[4]:
                     break

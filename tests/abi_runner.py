@@ -72,7 +72,7 @@ class RawCall:
                              _p(self.cov3D), _p(self.color), _p(self.depth), _p(self.alpha),
                              _p(self.radii), _p(self.geom), _p(self.bin), self.capacity,
                              _p(self.img), 1 if self.store else 0, self.max_tile_hint,
-                             ctypes.c_void_p(self.status_host.data_ptr()), None,
+                             ctypes.c_void_p(self.status_host.data_ptr()), None, None,
                              ctypes.c_void_p(stream.cuda_stream))
         stream.synchronize()
         self.rc = rc
