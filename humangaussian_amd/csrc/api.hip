@@ -147,7 +147,7 @@ bool settings_ok(const hgs_settings* s) {
 
 extern "C" {
 
-int hgs_abi_version(void) { return 5; }
+int hgs_abi_version(void) { return 6; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;
@@ -168,7 +168,8 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 void* geom, void* bin, int64_t entry_capacity, void* img,
                 int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
-                void* status_event, void* const* stage_events, void* stream_) {
+                int32_t status_host_mapped, void* status_event, void* const* stage_events,
+                void* stream_) {
   if (!settings_ok(s) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
     return HGS_EINVAL;
@@ -210,11 +211,12 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256, HGS_ROW_GROUPS), dim3(256), 0, stream, v, L);
     HGS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev);
+  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev,
+                     status_host_mapped ? status_host : nullptr);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
   // the status is final here: publish it now so the host can wait for it alone
-  if (status_host) {
+  if (status_host && !status_host_mapped) {
     e = hipMemcpyAsync(status_host, status_dev, sizeof(hgs_status), hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return hip_rc(e);
   }

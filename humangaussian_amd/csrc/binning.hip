@@ -48,7 +48,8 @@ __device__ __forceinline__ void block_excl_scan3(uint32_t v0, uint32_t v1, uint3
 // totals hgs_k_colscan left in tile_grp[rg][t]; this kernel turns them into ABSOLUTE
 // bases tile_start[t] + (entries of earlier row groups).
 extern "C" __global__ void __launch_bounds__(SCAN_NT)
-hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
+hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
+           hgs_status* __restrict__ status_host) {
   __shared__ uint32_t wtot[SCAN_NT / 64];
   __shared__ uint32_t wtot3[SCAN_NT / 64][3];
   __shared__ uint32_t carry_s;
@@ -128,8 +129,16 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
         } else {
           L.tile_count[t] = 0;            // becomes the fill cursor
         }
-        atomicAdd(&cls_hist[n[k] ? 32 - __clz(n[k]) : 0], 1u);
+        if (n[k]) atomicAdd(&cls_hist[32 - __clz(n[k])], 1u);
       }
+    }
+    {  // empty tiles are the bulk (80+ %): count them once per wave, not once per tile
+      uint32_t empties = 0;
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; ++k) empties += (t0 + k < v.T && n[k] == 0) ? 1u : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) empties += (uint32_t)__shfl_xor((int)empties, d, 64);
+      if ((tid & 63) == 0 && empties) atomicAdd(&cls_hist[0], empties);
     }
     if (mx) atomicMax(&max_n_s, mx);
     __syncthreads();
@@ -154,15 +163,31 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status) {
     st.reserved[1] = max_n_s;            // longest tile list
     st.reserved[2] = 0;
     *status = st;
+    if (status_host) {            // pinned, device-mapped host memory: no in-stream copy
+      *status_host = st;
+      __threadfence_system();
+    }
   }
   __syncthreads();
-  // (c) tile_order: a permutation of all tiles, heavy first (order inside a class is free)
+  // (c) tile_order: a permutation of all tiles, heavy first (order inside a class is free).
+  // Non-empty tiles take a slot with one LDS atomic each; the empty class is handed out
+  // per wave (ballot + prefix popcount) - thousands of same-address atomics otherwise.
   for (int base = 0; base < v.T; base += SCAN_NT) {
     const int t = base + tid;
+    uint32_t n = 0;
+    if (t < v.T) n = L.tile_start[t + 1] - L.tile_start[t];
+    const bool empty = (t < v.T) && (n == 0);
+    const unsigned long long ball = __ballot(empty);
+    uint32_t wbase = 0;
+    if ((tid & 63) == 0 && ball) wbase = atomicAdd(&cls_base[0], (uint32_t)__popcll(ball));
+    wbase = (uint32_t)__shfl((int)wbase, 0, 64);
     if (t < v.T) {
-      const uint32_t n = L.tile_start[t + 1] - L.tile_start[t];
-      const int c = n ? 32 - __clz(n) : 0;
-      const uint32_t pos = atomicAdd(&cls_base[c], 1u);
+      uint32_t pos;
+      if (empty)
+        pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+      else
+        pos = atomicAdd(&cls_base[32 - __clz(n)], 1u);
       L.tile_order[pos] = (uint32_t)t;
     }
   }

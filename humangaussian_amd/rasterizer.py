@@ -249,6 +249,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(color), _ptr(depth), _ptr(alpha),
                     _ptr(radii), _ptr(geom), _ptr(binbuf), cap, _ptr(img),
                     1 if want_grad else 0, hint, ctypes.c_void_p(st.status_ring[slot].data_ptr()),
+                    1,      # torch pinned memory is device-mapped on ROCm: direct kernel store
                     None if go_async else ctypes.c_void_p(st.status_event.cuda_event),
                     _stage_events["fwd"], ctypes.c_void_p(stream.cuda_stream))
                 if rc == -2:

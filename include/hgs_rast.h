@@ -90,7 +90,10 @@ size_t hgs_bwd_scratch_bytes(int64_t num_rendered);
  * (lets the library skip launching sort classes that cannot occur); a broken promise is
  * detected on the device and reported as overflow bit 1 (value 2) - call again with 0.
  * P == 0 writes background / zeros and reports num_rendered = 0.
- * The status copy to `status_host` is enqueued right after the scan stage (before fill /
+ * status_host_mapped != 0: `status_host` is pinned host memory that the device can address
+ * with the same pointer (hipHostMalloc / torch pin_memory on ROCm); the scan kernel then
+ * stores the status into it directly (system-scope fence) and no copy is enqueued.
+ * Otherwise the status copy to `status_host` is enqueued right after the scan stage (before fill /
  * sort / blend); `status_event` (a hipEvent_t, may be NULL) is recorded right behind it, so a
  * host can wait for just the status - hipEventSynchronize(status_event) - while the rest of
  * the forward is still running, and knows about an overflow before it hands out outputs. */
@@ -101,7 +104,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
                 void* geom, void* bin, int64_t entry_capacity, void* img,
                 int32_t store_bwd_state, int32_t max_tile_entries_hint,
-                hgs_status* status_host, void* status_event,
+                hgs_status* status_host, int32_t status_host_mapped, void* status_event,
                 void* const* stage_events, void* stream);
 
 /* ---- backward: replaces _C.rasterize_gaussians_backward ----------------------------

@@ -24,7 +24,7 @@ class RawCall:
     """One forward (+ optional backward) through the raw ABI on `device`."""
 
     def __init__(self, scene, device="cuda", scale_modifier=1.0, colors_precomp=None,
-                 cov3D_precomp=None, capacity=None, store=True, sh_degree=None, max_tile_hint=0):
+                 cov3D_precomp=None, capacity=None, store=True, sh_degree=None, max_tile_hint=0, mapped=0):
         self.lib = _lib.load()
         dev = torch.device(device)
         cam = scene["cam"]
@@ -53,6 +53,7 @@ class RawCall:
         self.dev = dev
         self.store = store
         self.max_tile_hint = max_tile_hint
+        self.mapped = mapped
         self.capacity = max(1, 8 * self.P) if capacity is None else capacity
 
     def forward(self):
@@ -72,7 +73,7 @@ class RawCall:
                              _p(self.cov3D), _p(self.color), _p(self.depth), _p(self.alpha),
                              _p(self.radii), _p(self.geom), _p(self.bin), self.capacity,
                              _p(self.img), 1 if self.store else 0, self.max_tile_hint,
-                             ctypes.c_void_p(self.status_host.data_ptr()), None, None,
+                             ctypes.c_void_p(self.status_host.data_ptr()), self.mapped, None, None,
                              ctypes.c_void_p(stream.cuda_stream))
         stream.synchronize()
         self.rc = rc

@@ -53,7 +53,7 @@ def test_buffer_sizing(lib):
 
 def test_argument_validation_without_gpu(lib):
     s = _lib.HgsSettings()
-    assert lib.hgs_forward(ctypes.byref(s), 1, 1, *([None] * 13), 0, None, 0, 0, None, None, None, None) == -1
+    assert lib.hgs_forward(ctypes.byref(s), 1, 1, *([None] * 13), 0, None, 0, 0, None, 0, None, None, None) == -1
     assert lib.hgs_mark_visible(None, 1, None, None, None) == -1
 
 

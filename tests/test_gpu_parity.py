@@ -338,3 +338,10 @@ def test_async_mode_python_api_matches_sync_mode():
     finally:
         R.set_async(False)
         R._drain_pending(R._state(dev), block=True)
+
+
+def test_status_via_mapped_pinned_memory_equals_copied_status():
+    sc = make_scene(P=500, seed=81, H=48, W=48)
+    a = RawCall(sc, mapped=0); assert a.forward() == 0
+    b = RawCall(sc, mapped=1); assert b.forward() == 0
+    assert a.status == b.status and a.status[0] > 0
