@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--points", type=int, default=P_POINTS)
+    ap.add_argument("--sh-degree", type=int, default=SH_DEGREE)
     ap.add_argument("--variant", default="mid", choices=["mid", "init"])
     ap.add_argument("--async-mode", action="store_true",
                     help="opt-in: no host sync per forward (rasterizer.set_async)")
@@ -81,7 +82,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     P = args.points
-    cloud = synth.init_cloud(P, SH_DEGREE, args.variant, seed=0)
+    sh_degree = args.sh_degree
+    cloud = synth.init_cloud(P, sh_degree, args.variant, seed=0)
     M = cloud.shs.shape[1]
     cam = camera_for_rank(rank)
     leaves = {k: getattr(cloud, k).to(dev).requires_grad_(True)
@@ -89,7 +91,7 @@ def main():
     bg = torch.zeros(3, device=dev)
     rs = GaussianRasterizationSettings(
         RES, RES, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
-        cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), SH_DEGREE,
+        cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), sh_degree,
         cam.camera_center.to(dev), False, False)
     rasterizer = GaussianRasterizer(rs)
     g = torch.Generator().manual_seed(1 + rank)
@@ -176,7 +178,7 @@ def main():
         torch.set_num_threads(threads)
         stride = 4
         st = oracle.OracleSettings(RES, RES, rs.tanfovx, rs.tanfovy, torch.zeros(3), 1.0,
-                                   cam.world_view_transform, cam.full_proj_transform, SH_DEGREE,
+                                   cam.world_view_transform, cam.full_proj_transform, sh_degree,
                                    cam.camera_center, False, False)
         def oracle_fwd_bwd(tile_stride):
             ins = [getattr(cloud, k).clone().requires_grad_(True)
@@ -211,7 +213,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {P} SMPL-X-like Gaussians ({args.variant}-training "
-                                   f"state, SH degree {SH_DEGREE}), one 1024x1024 orbit view per GPU "
+                                   f"state, SH degree {sh_degree}), one 1024x1024 orbit view per GPU "
                                    "(elev 10, azim 30+45*rank, dist 1.75, fovy 55), fwd+bwd",
                        "views_per_step": world, "num_rendered_R": int(R),
                        "host_mode": "async (opt-in, no per-forward sync)" if args.async_mode
