@@ -336,7 +336,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
 // Bitonic network in its "all comparators ascending" form (first stage of every merge
 // mirrors the upper half), which sorts any n <= npad correctly with VIRTUAL +inf padding:
 // a comparator whose upper index is >= n is a no-op.  Keys are unique, so the result is
-// the unique ascending order.  One __syncthreads() per stage.
+// the unique ascending order.  One __syncthreads() per stage.  Used for the HBM fallback.
 template <int NT>
 __device__ __forceinline__ void bitonic_sort(unsigned long long* keys, uint32_t n) {
   uint32_t npad = 2;
@@ -367,21 +367,129 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* keys, uint32_t 
   }
 }
 
-// Tiles with LO < n <= CAP, keys sorted entirely in LDS.
-template <int CAP, int NT, int LO>
+// ---- register / wave-shuffle / LDS hybrid of the same network -------------------------
+// Thread t owns E consecutive keys (indices t*E .. t*E+E-1) in REGISTERS.  A comparator
+// of stride < E stays inside the thread; stride < 64*E pairs lanes of one wave and goes
+// through ds_bpermute (no barrier); only strides >= 64*E (a handful of the ~50-80 stages)
+// exchange through LDS with barriers.  Padding is explicit (+inf keys).
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64);
+  const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+  return ((u64)hi << 32) | lo;
+}
+
+template <int E>
+__device__ __forceinline__ void reg_stage_xor(u64 (&k)[E], int j) {      // j < E, power of 2
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if ((e & j) == 0) {
+      const u64 a = k[e], c = k[e | j];
+      k[e] = a < c ? a : c;
+      k[e | j] = a < c ? c : a;
+    }
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void reg_stage_mirror(u64 (&k)[E], int kk) {   // kk <= E
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if ((e & (kk >> 1)) == 0) {
+      const int o = e ^ (kk - 1);
+      const u64 a = k[e], c = k[o];
+      k[e] = a < c ? a : c;
+      k[o] = a < c ? c : a;
+    }
+  }
+}
+
+// one stage whose partner lives in another lane of the same wave
+template <int E>
+__device__ __forceinline__ void lane_stage(u64 (&k)[E], int lane_mask, bool mirror, bool keep_min) {
+  u64 o[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) o[e] = shfl_xor_u64(mirror ? k[E - 1 - e] : k[e], lane_mask);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const u64 a = k[e], c = o[e];
+    const u64 mn = a < c ? a : c, mx = a < c ? c : a;
+    k[e] = keep_min ? mn : mx;
+  }
+}
+
+// one stage whose partner lives in another wave: through LDS
+template <int E>
+__device__ __forceinline__ void lds_stage(u64 (&k)[E], u64* lds, uint32_t base, uint32_t xmask,
+                                          bool keep_min) {
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) lds[base + e] = k[e];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const u64 a = k[e], c = lds[(base + e) ^ xmask];
+    const u64 mn = a < c ? a : c, mx = a < c ? c : a;
+    k[e] = keep_min ? mn : mx;
+  }
+}
+
+template <int E, int NT>
+__device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad) {
+  const uint32_t base = threadIdx.x * E;
+  for (uint32_t kk = 2; kk <= npad; kk <<= 1) {
+    // --- mirror stage of span kk: index i pairs with i ^ (kk-1)
+    if (kk <= (uint32_t)E) {
+      if (kk == 2) reg_stage_mirror<E>(k, 2);
+      else if (kk == 4) { if (E >= 4) reg_stage_mirror<E>(k, 4); }
+      else if (kk == 8) { if (E >= 8) reg_stage_mirror<E>(k, 8); }
+      else if (kk == 16) { if (E >= 16) reg_stage_mirror<E>(k, 16); }
+    } else {
+      const bool keep_min = (base & (kk >> 1)) == 0;
+      if (kk <= 64u * E) lane_stage<E>(k, (int)(kk / E - 1), true, keep_min);
+      else lds_stage<E>(k, lds, base, kk - 1, keep_min);
+    }
+    // --- xor stages j = kk/4 .. 1
+    for (uint32_t j = kk >> 2; j > 0; j >>= 1) {
+      if (j < (uint32_t)E) {
+        if (j == 1) reg_stage_xor<E>(k, 1);
+        else if (j == 2) { if (E > 2) reg_stage_xor<E>(k, 2); }
+        else if (j == 4) { if (E > 4) reg_stage_xor<E>(k, 4); }
+        else if (j == 8) { if (E > 8) reg_stage_xor<E>(k, 8); }
+      } else {
+        const bool keep_min = (base & j) == 0;
+        if (j < 64u * E) lane_stage<E>(k, (int)(j / E), false, keep_min);
+        else lds_stage<E>(k, lds, base, j, keep_min);
+      }
+    }
+  }
+}
+
+// Tiles with LO < n <= CAP = NT*E, keys sorted in registers/LDS.
+template <int E, int NT, int LO>
 __device__ __forceinline__ void sort_tiles_lds(const View& v, const Layout& L,
                                                const hgs_status* status,
                                                unsigned long long* keys) {
+  constexpr uint32_t CAP = (uint32_t)E * NT;
   if (status->overflow) return;
   const uint32_t b = blockIdx.x;
   if (b >= status->active_tiles) return;
   const int t = (int)L.tile_order[b];
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_start[t + 1] - start;
-  if (n <= (uint32_t)LO || n > (uint32_t)CAP) return;
-  for (uint32_t k = threadIdx.x; k < n; k += NT) keys[k] = L.keys[start + k];
+  if (n <= (uint32_t)LO || n > CAP) return;
+  uint32_t npad = E;
+  while (npad < n) npad <<= 1;
+  u64 k[E];
+  const uint32_t base = threadIdx.x * E;
+#pragma unroll
+  for (int e = 0; e < E; ++e) k[e] = (base + e < n) ? L.keys[start + base + e] : ~0ull;
+  hybrid_sort<E, NT>(k, keys, npad);
   __syncthreads();
-  bitonic_sort<NT>(keys, n);
+#pragma unroll
+  for (int e = 0; e < E; ++e) keys[base + e] = k[e];
+  __syncthreads();
   gather_records(v, L, t, start, n, keys, NT);
 }
 
@@ -390,17 +498,17 @@ __device__ __forceinline__ void sort_tiles_lds(const View& v, const Layout& L,
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_sort_small(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[1024];
-  sort_tiles_lds<1024, 256, 0>(v, L, status, keys);
+  sort_tiles_lds<4, 256, 0>(v, L, status, keys);
 }
 extern "C" __global__ void __launch_bounds__(512)
 hgs_k_sort_medium(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[4096];
-  sort_tiles_lds<4096, 512, 1024>(v, L, status, keys);
+  sort_tiles_lds<8, 512, 1024>(v, L, status, keys);
 }
 extern "C" __global__ void __launch_bounds__(1024)
 hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[16384];
-  sort_tiles_lds<16384, 1024, 4096>(v, L, status, keys);
+  sort_tiles_lds<16, 1024, 4096>(v, L, status, keys);
 }
 
 // Tiles with n > 16384 (longer than LDS): the same network run in place on the tile's key
