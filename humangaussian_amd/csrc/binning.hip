@@ -466,19 +466,10 @@ __device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad
   }
 }
 
-// Tiles with LO < n <= CAP = NT*E, keys sorted in registers/LDS.
-template <int E, int NT, int LO>
-__device__ __forceinline__ void sort_tiles_lds(const View& v, const Layout& L,
-                                               const hgs_status* status,
-                                               unsigned long long* keys) {
-  constexpr uint32_t CAP = (uint32_t)E * NT;
-  if (status->overflow) return;
-  const uint32_t b = blockIdx.x;
-  if (b >= status->active_tiles) return;
-  const int t = (int)L.tile_order[b];
-  const uint32_t start = L.tile_start[t];
-  const uint32_t n = L.tile_start[t + 1] - start;
-  if (n <= (uint32_t)LO || n > CAP) return;
+// One tile, n <= NT*E keys: load, sort in registers/LDS, gather the records.
+template <int E, int NT>
+__device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, int t,
+                                              uint32_t start, uint32_t n, u64* keys) {
   uint32_t npad = E;
   while (npad < n) npad <<= 1;
   u64 k[E];
@@ -495,20 +486,35 @@ __device__ __forceinline__ void sort_tiles_lds(const View& v, const Layout& L,
 
 }  // namespace
 
+// All tiles with 1..4096 entries in ONE launch (256 threads; 4, 8 or 16 keys per thread by
+// list length): each sort is latency-bound on its own stage chain, so the few long lists
+// overlap with the many short ones instead of running in a second kernel after them.
 extern "C" __global__ void __launch_bounds__(256)
-hgs_k_sort_small(View v, Layout L, const hgs_status* __restrict__ status) {
-  __shared__ unsigned long long keys[1024];
-  sort_tiles_lds<4, 256, 0>(v, L, status, keys);
-}
-extern "C" __global__ void __launch_bounds__(512)
-hgs_k_sort_medium(View v, Layout L, const hgs_status* __restrict__ status) {
+hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[4096];
-  sort_tiles_lds<8, 512, 1024>(v, L, status, keys);
+  if (status->overflow) return;
+  const uint32_t b = blockIdx.x;
+  if (b >= status->active_tiles) return;
+  const int t = (int)L.tile_order[b];
+  const uint32_t start = L.tile_start[t];
+  const uint32_t n = L.tile_start[t + 1] - start;
+  if (n == 0 || n > 4096u) return;
+  if (n <= 1024u) sort_one_tile<4, 256>(v, L, t, start, n, keys);
+  else if (n <= 2048u) sort_one_tile<8, 256>(v, L, t, start, n, keys);
+  else sort_one_tile<16, 256>(v, L, t, start, n, keys);
 }
+
 extern "C" __global__ void __launch_bounds__(1024)
 hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[16384];
-  sort_tiles_lds<16, 1024, 4096>(v, L, status, keys);
+  if (status->overflow) return;
+  const uint32_t b = blockIdx.x;
+  if (b >= status->active_tiles) return;
+  const int t = (int)L.tile_order[b];
+  const uint32_t start = L.tile_start[t];
+  const uint32_t n = L.tile_start[t + 1] - start;
+  if (n <= 4096u || n > 16384u) return;
+  sort_one_tile<16, 1024>(v, L, t, start, n, keys);
 }
 
 // Tiles with n > 16384 (longer than LDS): the same network run in place on the tile's key
