@@ -250,7 +250,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
       hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
       HGS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(hgs_k_sort_lds, dim3(v.T), dim3(256), 0, stream, v, L, status_dev);
+    hipLaunchKernelGGL(hgs_k_sort_lds, dim3(v.T), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(4);
