@@ -80,21 +80,28 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
   for (int base = 0; base < v.T; base += SCAN_NT * SCAN_ITEMS) {
     const int t0 = base + tid * SCAN_ITEMS;
     uint32_t n[SCAN_ITEMS], grp[HGS_ROW_GROUPS][SCAN_ITEMS];
+    // one CU does all of this: 16 B/lane vector accesses (4 consecutive tiles per thread)
+    // keep its memory pipeline to a handful of fully coalesced instructions
+    const bool vec = ((v.T & 3) == 0) && (t0 + SCAN_ITEMS <= v.T);
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-      const int t = t0 + k;
-      n[k] = 0;
-      if (t < v.T) {
-        if (v.lds_bins) {
+    for (int k = 0; k < SCAN_ITEMS; ++k) n[k] = 0;
+    if (v.lds_bins) {
 #pragma unroll
-          for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
-            grp[rg][k] = L.tile_grp[(size_t)rg * v.T + t];
-            n[k] += grp[rg][k];
-          }
+      for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
+        if (vec) {
+          const uint4 q = *reinterpret_cast<const uint4*>(L.tile_grp + (size_t)rg * v.T + t0);
+          grp[rg][0] = q.x; grp[rg][1] = q.y; grp[rg][2] = q.z; grp[rg][3] = q.w;
         } else {
-          n[k] = L.tile_count[t];
+#pragma unroll
+          for (int k = 0; k < SCAN_ITEMS; ++k)
+            grp[rg][k] = (t0 + k < v.T) ? L.tile_grp[(size_t)rg * v.T + t0 + k] : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) n[k] += grp[rg][k];
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; ++k) n[k] = (t0 + k < v.T) ? L.tile_count[t0 + k] : 0u;
     }
     uint32_t l0 = 0, l1 = 0, l2 = 0, mx = 0;
     uint32_t p0[SCAN_ITEMS], p1[SCAN_ITEMS], p2[SCAN_ITEMS];
@@ -110,28 +117,55 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
     uint32_t ex[3], tot[3];
     block_excl_scan3(l0, l1, l2, wtot3, ex, tot);
     const uint32_t c0 = carry3[0], c1 = carry3[1], c2 = carry3[2];
+    uint32_t ts[SCAN_ITEMS], tb[SCAN_ITEMS], tw[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-      const int t = t0 + k;
-      if (t < v.T) {
-        const uint32_t ts = c0 + ex[0] + p0[k];
-        L.tile_start[t] = ts;
-        L.tile_bstart[t] = c1 + ex[1] + p1[k];
-        L.tile_wgstart[t] = c2 + ex[2] + p2[k];
-        L.tile_maxcontrib[t] = 0;
-        if (v.lds_bins) {
-          uint32_t acc = ts;
+      ts[k] = c0 + ex[0] + p0[k];
+      tb[k] = c1 + ex[1] + p1[k];
+      tw[k] = c2 + ex[2] + p2[k];
+    }
+    if (vec) {
+      *reinterpret_cast<uint4*>(L.tile_start + t0) = make_uint4(ts[0], ts[1], ts[2], ts[3]);
+      *reinterpret_cast<uint4*>(L.tile_bstart + t0) = make_uint4(tb[0], tb[1], tb[2], tb[3]);
+      *reinterpret_cast<uint4*>(L.tile_wgstart + t0) = make_uint4(tw[0], tw[1], tw[2], tw[3]);
+      *reinterpret_cast<uint4*>(L.tile_maxcontrib + t0) = make_uint4(0u, 0u, 0u, 0u);
+      if (v.lds_bins) {
+        uint32_t acc[SCAN_ITEMS] = {ts[0], ts[1], ts[2], ts[3]};
 #pragma unroll
-          for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
-            L.tile_grp[(size_t)rg * v.T + t] = acc;
-            acc += grp[rg][k];
-          }
-        } else {
-          L.tile_count[t] = 0;            // becomes the fill cursor
+        for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
+          *reinterpret_cast<uint4*>(L.tile_grp + (size_t)rg * v.T + t0) =
+              make_uint4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+          for (int k = 0; k < SCAN_ITEMS; ++k) acc[k] += grp[rg][k];
         }
-        if (n[k]) atomicAdd(&cls_hist[32 - __clz(n[k])], 1u);
+      } else {
+        *reinterpret_cast<uint4*>(L.tile_count + t0) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int t = t0 + k;
+        if (t < v.T) {
+          L.tile_start[t] = ts[k];
+          L.tile_bstart[t] = tb[k];
+          L.tile_wgstart[t] = tw[k];
+          L.tile_maxcontrib[t] = 0;
+          if (v.lds_bins) {
+            uint32_t acc = ts[k];
+#pragma unroll
+            for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
+              L.tile_grp[(size_t)rg * v.T + t] = acc;
+              acc += grp[rg][k];
+            }
+          } else {
+            L.tile_count[t] = 0;            // becomes the fill cursor
+          }
+        }
       }
     }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+      if (t0 + k < v.T && n[k]) atomicAdd(&cls_hist[32 - __clz(n[k])], 1u);
     {  // empty tiles are the bulk (80+ %): count them once per wave, not once per tile
       uint32_t empties = 0;
 #pragma unroll
