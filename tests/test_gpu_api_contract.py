@@ -1,0 +1,183 @@
+"""Drop-in contract tests: the reference's call sites replayed against the HIP rasterizer.
+
+* `render()`            gaussiansplatting/gaussian_renderer/__init__.py:18-104
+* `Renderer.render()`   gs_renderer.py:923-1028
+* the per-step access pattern of threestudio/systems/GaussianDreamer.py:234-306,378-408
+  (8-view loop, radii max, viewspace_points.grad, densification statistic), and the
+  no-grad validation path (GaussianDreamer.py:410-411).
+The fake camera / model / pipe objects expose exactly the attributes the reference objects
+have (scene/cameras.py:17-67, scene/gaussian_model.py:95-118, arguments/__init__.py:63-68).
+"""
+import math
+
+import pytest
+import torch
+
+import oracle
+from helpers import cov3d_from, make_scene, oracle_settings
+from humangaussian_amd import synth
+from humangaussian_amd.renderer import Renderer, render
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+class FakeCamera:
+    """scene/cameras.py::Camera attribute surface (tensors on the device)."""
+
+    def __init__(self, cam):
+        self.image_height, self.image_width = cam.image_height, cam.image_width
+        self.FoVx, self.FoVy = cam.FoVx, torch.tensor(cam.FoVy, device=DEV)   # FoVy arrives as a device tensor
+        self.world_view_transform = cam.world_view_transform.to(DEV)
+        self.full_proj_transform = cam.full_proj_transform.to(DEV)
+        self.camera_center = cam.camera_center.to(DEV)
+
+
+class FakeGaussianModel:
+    """scene/gaussian_model.py::GaussianModel getters (activations included)."""
+
+    def __init__(self, sc, sh_degree, max_sh_degree=None):
+        self.active_sh_degree = sh_degree
+        self.max_sh_degree = sh_degree if max_sh_degree is None else max_sh_degree
+        p = lambda t: torch.nn.Parameter(t.to(DEV))  # noqa: E731
+        self._xyz = p(sc["means3D"])
+        self._features_dc = p(sc["shs"][:, :1].contiguous())
+        self._features_rest = p(sc["shs"][:, 1:].contiguous())
+        self._scaling = p(torch.log(sc["scales"]))
+        self._rotation = p(sc["rotations"] * 1.7)                      # un-normalised, like training
+        self._opacity = p(torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)))
+
+    @property
+    def get_xyz(self): return self._xyz
+    @property
+    def get_features(self): return torch.cat((self._features_dc, self._features_rest), dim=1)
+    @property
+    def get_opacity(self): return torch.sigmoid(self._opacity)
+    @property
+    def get_scaling(self): return torch.exp(self._scaling)
+    @property
+    def get_rotation(self): return torch.nn.functional.normalize(self._rotation)
+
+    def get_covariance(self, scaling_modifier=1):
+        sc = {"scales": self.get_scaling, "rotations": self.get_rotation}
+        return cov3d_from(sc, scaling_modifier)
+
+    def params(self):
+        return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]
+
+
+def _scene(P=400, deg=1, **kw):
+    sc = make_scene(P=P, sh_degree=deg, seed=17, H=64, W=80, spread=0.3, **kw)
+    return sc, FakeGaussianModel(sc, deg), FakeCamera(sc["cam"])
+
+
+def test_render_dict_contract_and_oracle_values():
+    sc, pc, cam = _scene()
+    bg = sc["bg"].to(DEV)
+    out = render(cam, pc, Pipe(), bg)
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "depth_3dgs", "alpha_3dgs"}
+    assert out["render"].shape == (3, 64, 80) and out["depth_3dgs"].shape == (1, 64, 80)
+    assert out["alpha_3dgs"].shape == (1, 64, 80) and out["radii"].dtype == torch.int32
+    assert out["visibility_filter"].dtype == torch.bool and torch.equal(out["visibility_filter"], out["radii"] > 0)
+    assert out["viewspace_points"].shape == pc.get_xyz.shape and out["viewspace_points"].requires_grad
+    # values: the activated parameters through the oracle
+    st = oracle_settings(sc)
+    oc, orad, od, oa = oracle.rasterize(pc.get_xyz.detach().cpu(), None, pc.get_features.detach().cpu(), None,
+                                        pc.get_opacity.detach().cpu(), pc.get_scaling.detach().cpu(),
+                                        pc.get_rotation.detach().cpu(), None, st)
+    assert torch.equal(out["radii"].cpu(), orad)
+    assert float((out["render"].cpu() - oc).abs().max()) < 1e-4
+    assert float((out["alpha_3dgs"].cpu() - oa).abs().max()) < 1e-4
+    # gradients reach every raw parameter through the activations; means2D.grad is populated
+    loss = out["render"].mean() + 0.1 * out["depth_3dgs"].mean()
+    loss.backward()
+    for p_ in pc.params():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all() and float(p_.grad.abs().max()) > 0
+    g = out["viewspace_points"].grad
+    assert g is not None and g.shape == (400, 3) and float(g[:, 2].abs().max()) == 0 and float(g[:, :2].abs().max()) > 0
+
+
+def test_render_under_no_grad_and_amp_inputs():
+    sc, pc, cam = _scene()
+    bg = sc["bg"].to(DEV)
+    ref = render(cam, pc, Pipe(), bg)
+    with torch.no_grad():                                   # validation / test path
+        out = render(cam, pc, Pipe(), bg)
+    assert not out["render"].requires_grad and torch.equal(out["render"], ref["render"].detach())
+    assert torch.equal(out["radii"], ref["radii"])
+    with torch.autocast("cuda", dtype=torch.float16):       # Lightning 16-mixed: inputs are .float()'ed
+        out16 = render(cam, pc, Pipe(), bg)
+    assert out16["render"].dtype == torch.float32
+    assert float((out16["render"] - ref["render"]).abs().max()) < 1e-4
+
+
+def test_render_optional_branches_override_color_and_python_cov3d():
+    sc, pc, cam = _scene(deg=0)
+    bg = sc["bg"].to(DEV)
+    ref = render(cam, pc, Pipe(), bg)
+    pipe = Pipe(); pipe.compute_cov3D_python = True
+    out = render(cam, pc, pipe, bg)
+    assert torch.equal(out["radii"], ref["radii"]) and float((out["render"] - ref["render"]).abs().max()) < 2e-4
+    colors = torch.rand(400, 3, device=DEV, requires_grad=True)
+    out2 = render(cam, pc, Pipe(), bg, override_color=colors)
+    out2["render"].sum().backward()
+    assert colors.grad is not None and float(colors.grad.abs().max()) > 0
+    pipe2 = Pipe(); pipe2.convert_SHs_python = True
+    out3 = render(cam, pc, pipe2, bg)
+    assert float((out3["render"] - ref["render"]).abs().max()) < 1e-4
+
+
+def test_renderer_class_contract():
+    sc, pc, cam = _scene()
+    r = Renderer(pc, white_background=True, device=DEV)
+    out = r.render(cam)
+    assert set(out) == {"image", "depth", "alpha", "viewspace_points", "visibility_filter", "radii"}
+    assert float(out["image"].min()) >= 0 and float(out["image"].max()) <= 1
+    empty = out["alpha"][0] == 0
+    assert bool(empty.any()) and float((out["image"][:, empty] - 1.0).abs().max()) == 0     # white background
+
+
+def test_gaussiandreamer_step_access_pattern():
+    """8-view loop + on_before_optimizer_step bookkeeping (GaussianDreamer.py:244-266,378-391)."""
+    sc = make_scene(P=600, sh_degree=0, seed=23, H=64, W=64, spread=0.3)
+    pc = FakeGaussianModel(sc, 0)
+    bg = torch.zeros(3, device=DEV)
+    cams = [FakeCamera(synth.orbit_camera(10.0 * (i % 3 - 1), 45.0 * i, 1.8, 50.0, 64, 64)) for i in range(8)]
+    images, depths, viewspace_point_list, radii = [], [], [], None
+    for i, cam in enumerate(cams):
+        pkg = render(cam, pc, Pipe(), bg)
+        viewspace_point_list.append(pkg["viewspace_points"])
+        radii = pkg["radii"] if i == 0 else torch.max(pkg["radii"], radii)
+        images.append(pkg["render"].permute(1, 2, 0)); depths.append(pkg["depth_3dgs"].permute(1, 2, 0))
+    comp_rgb, depth = torch.stack(images, 0), torch.stack(depths, 0)
+    opacity = depth / depth.max().detach()   # (the reference lets the max carry gradient; detached here
+                                             #  so the loss splits exactly into per-view terms below)
+    loss = ((comp_rgb - 0.5) ** 2).mean() + 0.1 * torch.sqrt(opacity ** 2 + 0.01).mean()
+    loss.backward()
+    viewspace_point_tensor_grad = torch.zeros_like(viewspace_point_list[0])
+    for v in viewspace_point_list:
+        assert v.grad is not None
+        viewspace_point_tensor_grad = viewspace_point_tensor_grad + v.grad
+    visibility_filter = radii > 0
+    max_radii2D = torch.zeros(600, device=DEV)                                   # float, like the model's
+    max_radii2D[visibility_filter] = torch.max(max_radii2D[visibility_filter], radii[visibility_filter])
+    stat = torch.norm(viewspace_point_tensor_grad[visibility_filter, :2], dim=-1, keepdim=True)
+    assert torch.isfinite(stat).all() and float(stat.max()) > 0 and int(visibility_filter.sum()) > 300
+    # accumulated parameter gradients = sum of the per-view gradients (autograd accumulation)
+    total = pc._xyz.grad.clone()
+    pc._xyz.grad = None
+    acc = torch.zeros_like(total)
+    for i, cam in enumerate(cams):
+        pkg = render(cam, pc, Pipe(), bg)
+        # same loss restricted to view i (depth.max() is a global constant of the 8-view batch)
+        li = ((pkg["render"].permute(1, 2, 0) - 0.5) ** 2).mean() / 8 + \
+            0.1 * torch.sqrt((pkg["depth_3dgs"].permute(1, 2, 0) / depth.max().detach()) ** 2 + 0.01).mean() / 8
+        g, = torch.autograd.grad(li, pc._xyz)
+        acc += g
+    assert float((acc - total).abs().max()) <= 2e-3 * float(total.abs().max())
