@@ -32,12 +32,12 @@ struct PixState {
 };
 
 // Blend one compacted record into the lane's pixel, fully predicated.  r2.w carries the
-// record's 1-based position in the tile list; `valid` is wave-uniform (tail of a group).
+// record's 1-based position in the tile list (pad records have opacity 0 and never blend).
 __device__ __forceinline__ void blend_one(PixState& s, float pxf, float pyf, const float4 r0,
-                                          const float4 r1, const float4 r2, bool valid) {
+                                          const float4 r1, const float4 r2) {
   float G, alpha, m2, m3;
   const bool keep = hgs_eval_alpha(r0.x - pxf, r0.y - pyf, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
-  const bool live = keep && valid && !s.done;
+  const bool live = keep && !s.done;
   const float test_T = s.T * (1.0f - alpha);
   const bool stop = live && (test_T < HGS_T_EPS);
   const bool upd = live && !stop;
@@ -62,7 +62,9 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
                                                 float* __restrict__ out_color,
                                                 float* __restrict__ out_depth,
                                                 float* __restrict__ out_alpha) {
-  __shared__ float4 s_rec[4][3 * HGS_BUCKET];     // wave-private compacted buckets (12 KB)
+  // wave-private compacted buckets (+4 zero-opacity pad records so the unrolled loop
+  // needs neither index clamps nor a tail predicate)
+  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 4)];
   const bool overflow = status->overflow != 0;
   const int t = overflow ? (int)blockIdx.x : (int)L.tile_order[blockIdx.x];
   const int tid = threadIdx.x;
@@ -120,30 +122,22 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
       srec[3 * pos + 1] = c1;
       srec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float(j0 + lane + 1));
     }
+    if (lane < 4) {                                  // 4 pad records behind the last real one
+      srec[3 * (cnt + lane) + 0] = zero4;
+      srec[3 * (cnt + lane) + 1] = zero4;            // opacity 0 => alpha 0 => skipped
+      srec[3 * (cnt + lane) + 2] = zero4;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    if (cnt > 0) {
-      const uint32_t lastk = cnt - 1;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
       float4 ra[4], rb[4], rc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint32_t k = min((uint32_t)u, lastk);
-        ra[u] = srec[3 * k + 0]; rb[u] = srec[3 * k + 1]; rc[u] = srec[3 * k + 2];
+        ra[u] = srec[3 * (k0 + u) + 0]; rb[u] = srec[3 * (k0 + u) + 1]; rc[u] = srec[3 * (k0 + u) + 2];
       }
-      for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
-        float4 na[4], nb[4], nc[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                // prefetch the next group (clamped)
-          const uint32_t k = min(k0 + 4 + u, lastk);
-          na[u] = srec[3 * k + 0]; nb[u] = srec[3 * k + 1]; nc[u] = srec[3 * k + 2];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          blend_one(s, pxf, pyf, ra[u], rb[u], rc[u], k0 + u < cnt);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
-      }
+      for (int u = 0; u < 4; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
     }
     c0 = n0; c1 = n1; c2 = n2;
   }
