@@ -255,10 +255,10 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
   }
   HGS_STAGE(4);
   if (store_bwd_state)
-    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T), dim3(256), 0, stream, v, L, status_dev,
+    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L, status_dev,
                        L.recs, L.bstate, out_color, out_depth, out_alpha);
   else
-    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T), dim3(256), 0, stream, v, L,
+    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.recs, L.bstate, out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(5);

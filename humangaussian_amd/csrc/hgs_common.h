@@ -91,13 +91,38 @@ struct View {            // per-call constants, passed by value to every kernel
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// pixel of a forward-render thread inside its tile: wave w owns the 8x8 block
-// (w&1, w>>1); lane l is (l&7, l>>3) inside it.
-__device__ __forceinline__ void hgs_fwd_thread_pixel(int tid, int& lx, int& ly) {
-  const int w = tid >> 6, l = tid & 63;
+// Forward pixel ownership.  HGS_FWD_PPL = pixels per lane of the forward blend kernel:
+//   1: four waves per tile, wave w owns the 8x8 quadrant (w&1, w>>1);
+//   2: two waves per tile, wave w owns the 16x8 half (rows 8w..8w+7), each lane two pixels
+//      4 rows apart (two independent T chains per lane).  Measured SLOWER (168 vs 87 us at
+//      config 2: the cull is weaker and the extra ILP does not materialise); kept as a
+//      build-time experiment switch, default 1.
+// `pf` in [0,256) is the index under which the forward stores per-pixel bucket state; the
+// backward maps it back to a pixel with the same function.
+#ifndef HGS_FWD_PPL
+#define HGS_FWD_PPL 1
+#endif
+__device__ __forceinline__ void hgs_fwd_thread_pixel(int pf, int& lx, int& ly) {
+#if HGS_FWD_PPL == 1
+  const int w = pf >> 6, l = pf & 63;
   lx = ((w & 1) << 3) | (l & 7);
   ly = ((w >> 1) << 3) | (l >> 3);
+#else
+  const int w = pf >> 7, k = (pf >> 6) & 1, l = pf & 63;
+  lx = l & 15;
+  ly = (w << 3) + (k << 2) + (l >> 4);
+#endif
 }
+// cull-mask bits (quadrants 0..3 = (x>=8) | (y>=8)<<1) that a forward wave must look at
+__device__ __forceinline__ uint32_t hgs_fwd_wave_cullbits(int w) {
+#if HGS_FWD_PPL == 1
+  return 1u << w;
+#else
+  return w == 0 ? 0x3u : 0xcu;
+#endif
+}
+#define HGS_FWD_WAVES (4 / HGS_FWD_PPL)
+#define HGS_FWD_THREADS (64 * HGS_FWD_WAVES)
 
 // The one place alpha is evaluated, shared by forward and backward so both take the
 // identical instruction sequence (skip decisions must agree).  q* are the folded conic of

@@ -62,56 +62,70 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
                                                 float* __restrict__ out_color,
                                                 float* __restrict__ out_depth,
                                                 float* __restrict__ out_alpha) {
+  constexpr int PPL = HGS_FWD_PPL;
   // wave-private compacted buckets (+4 zero-opacity pad records so the unrolled loop
   // needs neither index clamps nor a tail predicate)
-  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 4)];
+  __shared__ float4 s_rec[HGS_FWD_WAVES][3 * (HGS_BUCKET + 4)];
   const bool overflow = status->overflow != 0;
   const int t = overflow ? (int)blockIdx.x : (int)L.tile_order[blockIdx.x];
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int tile_x = t % v.grid_x, tile_y = t / v.grid_x;
-  int lx, ly;
-  hgs_fwd_thread_pixel(tid, lx, ly);
-  const int px = tile_x * HGS_TILE + lx, py = tile_y * HGS_TILE + ly;
-  const bool inside = (px < v.W) && (py < v.H);
-  const float pxf = (float)px, pyf = (float)py;
+
+  int pf[PPL], px[PPL], py[PPL];
+  float pxf[PPL], pyf[PPL];
+  bool inside[PPL];
+  PixState s[PPL];
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    pf[k] = w * (64 * PPL) + k * 64 + lane;
+    int lx, ly;
+    hgs_fwd_thread_pixel(pf[k], lx, ly);
+    px[k] = tile_x * HGS_TILE + lx; py[k] = tile_y * HGS_TILE + ly;
+    inside[k] = (px[k] < v.W) && (py[k] < v.H);
+    pxf[k] = (float)px[k]; pyf[k] = (float)py[k];
+    s[k].T = 1.0f; s[k].C0 = s[k].C1 = s[k].C2 = s[k].D = s[k].Wt = 0.f;
+    s[k].last = 0;
+    s[k].done = !inside[k];
+  }
 
   const uint32_t start = overflow ? 0u : L.tile_start[t];
   const uint32_t n = overflow ? 0u : (L.tile_start[t + 1] - start);
   const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
-  const uint32_t wbit = 1u << (28 + w);
+  const uint32_t wbits = hgs_fwd_wave_cullbits(w) << 28;
   float4* __restrict__ srec = s_rec[w];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  PixState s;
-  s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
-  s.last = 0;
-  s.done = !inside;
 
   // records of the first bucket
   float4 c0 = zero4, c1 = zero4, c2 = zero4;
   if ((uint32_t)lane < n) { c0 = recs[3 * lane + 0]; c1 = recs[3 * lane + 1]; c2 = recs[3 * lane + 2]; }
 
   for (uint32_t j0 = 0; j0 < n; j0 += HGS_BUCKET) {
-    if (__ballot(!s.done) == 0ull) break;            // every pixel of this wave is finished
+    bool alive = false;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) alive = alive || !s[k].done;
+    if (__ballot(alive) == 0ull) break;              // every pixel of this wave is finished
     if (STORE && j0 > 0) {
       float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
-      bs[0 * 256 + tid] = s.T;
-      bs[1 * 256 + tid] = s.C0;
-      bs[2 * 256 + tid] = s.C1;
-      bs[3 * 256 + tid] = s.C2;
-      bs[4 * 256 + tid] = s.D;
-      bs[5 * 256 + tid] = s.Wt;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        bs[0 * 256 + pf[k]] = s[k].T;
+        bs[1 * 256 + pf[k]] = s[k].C0;
+        bs[2 * 256 + pf[k]] = s[k].C1;
+        bs[3 * 256 + pf[k]] = s[k].C2;
+        bs[4 * 256 + pf[k]] = s[k].D;
+        bs[5 * 256 + pf[k]] = s[k].Wt;
+      }
     }
     // issue the next bucket's loads now; they land while this bucket is blended
     const uint32_t qn = j0 + HGS_BUCKET + lane;
     float4 n0 = zero4, n1 = zero4, n2 = zero4;
     if (qn < n) { n0 = recs[3 * qn + 0]; n1 = recs[3 * qn + 1]; n2 = recs[3 * qn + 2]; }
 
-    // ballot + prefix popcount compaction of the records that can touch this quadrant
-    const bool hit = (j0 + lane < n) && ((__float_as_uint(c2.w) & wbit) != 0u);
+    // ballot + prefix popcount compaction of the records that can touch this wave's pixels
+    const bool hit = (j0 + lane < n) && ((__float_as_uint(c2.w) & wbits) != 0u);
     const unsigned long long ball = __ballot(hit);
     const uint32_t cnt = (uint32_t)__popcll(ball);
     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
@@ -130,38 +144,46 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    for (uint32_t k0 = 0; k0 < cnt; k0 += 4) {
-      float4 ra[4], rb[4], rc[4];
+    constexpr int U = 4 / PPL;                       // records per unrolled group
+    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
+      float4 ra[U], rb[U], rc[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         ra[u] = srec[3 * (k0 + u) + 0]; rb[u] = srec[3 * (k0 + u) + 1]; rc[u] = srec[3 * (k0 + u) + 2];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) blend_one(s[k], pxf[k], pyf[k], ra[u], rb[u], rc[u]);
+      }
     }
     c0 = n0; c1 = n1; c2 = n2;
   }
 
-  if (inside) {
-    const size_t pix = (size_t)py * v.W + px;
-    const size_t HW = (size_t)v.H * v.W;
-    out_color[0 * HW + pix] = s.C0 + s.T * v.bg[0];
-    out_color[1 * HW + pix] = s.C1 + s.T * v.bg[1];
-    out_color[2 * HW + pix] = s.C2 + s.T * v.bg[2];
-    out_depth[pix] = s.D;
-    out_alpha[pix] = s.Wt;
-    L.n_contrib[pix] = s.last;
+  uint32_t mx = 0;
+#pragma unroll
+  for (int k = 0; k < PPL; ++k) {
+    if (inside[k]) {
+      const size_t pix = (size_t)py[k] * v.W + px[k];
+      const size_t HW = (size_t)v.H * v.W;
+      out_color[0 * HW + pix] = s[k].C0 + s[k].T * v.bg[0];
+      out_color[1 * HW + pix] = s[k].C1 + s[k].T * v.bg[1];
+      out_color[2 * HW + pix] = s[k].C2 + s[k].T * v.bg[2];
+      out_depth[pix] = s[k].D;
+      out_alpha[pix] = s[k].Wt;
+      L.n_contrib[pix] = s[k].last;
+    }
+    mx = max(mx, s[k].last);
   }
   if (STORE && !overflow) {
     // tile-wide max of n_contrib: buckets at or beyond it are skipped by the backward
-    uint32_t mx = s.last;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     if ((tid & 63) == 0 && mx > 0) atomicMax(&L.tile_maxcontrib[t], mx);
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
 hgs_k_render_fwd_store(View v, Layout L, const hgs_status* __restrict__ status,
                        const SortRec* __restrict__ recs, float* __restrict__ bstate,
                        float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -169,7 +191,7 @@ hgs_k_render_fwd_store(View v, Layout L, const hgs_status* __restrict__ status,
   render_fwd_body<true>(v, L, status, recs, bstate, out_color, out_depth, out_alpha);
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
 hgs_k_render_fwd_nostore(View v, Layout L, const hgs_status* __restrict__ status,
                          const SortRec* __restrict__ recs, float* __restrict__ bstate,
                          float* __restrict__ out_color, float* __restrict__ out_depth,
