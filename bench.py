@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--points", type=int, default=P_POINTS)
     ap.add_argument("--sh-degree", type=int, default=SH_DEGREE)
     ap.add_argument("--variant", default="mid", choices=["mid", "init"])
+    ap.add_argument("--forward-only", action="store_true",
+                    help="extra measurement (animation path, configs[4]): no-grad forward only")
     ap.add_argument("--async-mode", action="store_true",
                     help="opt-in: no host sync per forward (rasterizer.set_async)")
     args = ap.parse_args()
@@ -103,6 +105,11 @@ def main():
         _rast.set_async(True)
 
     def step():
+        if args.forward_only:
+            with torch.no_grad():
+                return rasterizer(means3D=leaves["means3D"], means2D=leaves["means3D"], shs=leaves["shs"],
+                                  opacities=leaves["opacities"], scales=leaves["scales"],
+                                  rotations=leaves["rotations"])[0]
         for t in leaves.values():
             t.grad = None
         means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
@@ -149,8 +156,9 @@ def main():
         torch.cuda.synchronize()
         for i, k in enumerate(FWD_STAGES):
             acc[k] += fwd_ev[i].elapsed_time(fwd_ev[i + 1])
-        for i, k in enumerate(BWD_STAGES):
-            acc[k] += bwd_ev[i].elapsed_time(bwd_ev[i + 1])
+        if not args.forward_only:
+            for i, k in enumerate(BWD_STAGES):
+                acc[k] += bwd_ev[i].elapsed_time(bwd_ev[i + 1])
     _rast.set_stage_events(None, None)
     stage_us = {k: v / nprof * 1e3 for k, v in acc.items()}
     R = int(_rast._state(dev).max_R)
@@ -206,7 +214,8 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "rasterize fwd+bwd Gaussians/sec @1024^2, 100k pts",
+            "metric": "rasterize fwd+bwd Gaussians/sec @1024^2, 100k pts" if not args.forward_only
+            else "rasterize fwd-only Gaussians/sec @1024^2 (extra measurement)",
             "value": P * world * args.steps / elapsed,
             "unit": "Gaussians/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

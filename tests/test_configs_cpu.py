@@ -1,0 +1,57 @@
+"""BASELINE.json configs[0]: '~10k Gaussians PLY, single 512^2 view, PyTorch-CPU reference
+render path (plumbing, no GPU)'.  content/sample.ply is missing from the reference mount
+(.MISSING_LARGE_BLOBS), so a synthetic stand-in goes through the reference's PLY schema
+(scene/gaussian_model.py:187-266) and the CPU oracle."""
+import math
+import os
+
+import numpy as np
+import torch
+
+import oracle
+from humangaussian_amd import ply_io, synth
+
+
+def test_ply_roundtrip_is_byte_stable_and_schema_matches_reference(tmp_path):
+    cl = synth.init_cloud(500, 2, "mid", seed=3)
+    raw = dict(xyz=cl.means3D.numpy(), features_dc=cl.shs[:, :1].numpy(), features_rest=cl.shs[:, 1:].numpy(),
+               opacity=torch.logit(cl.opacities).numpy(), scaling=torch.log(cl.scales).numpy(),
+               rotation=cl.rotations.numpy())
+    p1, p2 = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    ply_io.save_ply(p1, **raw)
+    got = ply_io.load_ply(p1, max_sh_degree=2)
+    for k, v in raw.items():
+        assert np.array_equal(got[k], np.asarray(v, np.float32).reshape(got[k].shape)), k
+    ply_io.save_ply(p2, **{k: got[k] for k in raw})
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    head = open(p1, "rb").read(2000).split(b"end_header\n")[0].decode().splitlines()
+    assert head[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 500"]
+    props = [ln.split()[2] for ln in head if ln.startswith("property float")]
+    assert props == ply_io.attribute_names(3 * 9 - 3) and len(props) == 6 + 3 + 24 + 1 + 3 + 4
+    # channel-major SH layout: f_rest_0..7 are the 8 non-DC coefficients of channel 0
+    rows = np.frombuffer(open(p1, "rb").read().split(b"end_header\n", 1)[1], "<f4").reshape(500, -1)
+    assert np.array_equal(rows[:, 9:17], raw["features_rest"][:, :, 0])
+
+
+def test_config1_ply_to_cpu_render_512(tmp_path):
+    P = 10_000
+    cl = synth.init_cloud(P, 0, "mid", seed=0)
+    path = str(tmp_path / "sample.ply")
+    ply_io.save_ply(path, cl.means3D.numpy(), cl.shs[:, :1].numpy(), cl.shs[:, 1:].numpy(),
+                    torch.logit(cl.opacities).numpy(), torch.log(cl.scales).numpy(), cl.rotations.numpy())
+    g = ply_io.load_ply(path, max_sh_degree=0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    xyz, shs = t(g["xyz"]), torch.cat([t(g["features_dc"]), t(g["features_rest"])], 1)
+    opac, scales = torch.sigmoid(t(g["opacity"])), torch.exp(t(g["scaling"]))
+    rots = torch.nn.functional.normalize(t(g["rotation"]))
+    cam = synth.orbit_camera(15.0, 30.0, 2.0, 70.0, 512, 512)          # uncond.py eval defaults
+    st = oracle.OracleSettings(512, 512, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.zeros(3), 1.0,
+                               cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center, False, False)
+    with torch.no_grad():
+        c, r, d, a = oracle.rasterize(xyz, None, shs, None, opac, scales, rots, None, st)
+    assert c.shape == (3, 512, 512) and r.dtype == torch.int32
+    assert int((r > 0).sum()) > 0.95 * P                 # the whole body is in view
+    cover = (a[0] > 0.5).float().mean().item()
+    assert 0.02 < cover < 0.5                            # a person in the middle of the frame
+    ys, xs = torch.nonzero(a[0] > 0.5, as_tuple=True)
+    assert float(ys.max() - ys.min()) > float(xs.max() - xs.min())    # standing upright (taller than wide)... 

@@ -136,3 +136,54 @@ def test_zoom_in_camera_large_radii():
                                             cloud.rotations, None, st)
     assert torch.equal(r, orad)
     assert int(((c - oc).abs() > 1e-4).sum()) <= 64 and int(((a - oa).abs() > 1e-4).sum()) <= 64
+
+
+def test_config5_animation_frames_forward_only():
+    """configs[4]: pretrained-avatar animation, fwd-only 1024^2, frames sharded over ranks.
+    SMPL-X is unavailable: per frame only xyz moves (animation.py:384-403), here by a smooth
+    displacement field; frames i -> rank i mod 8 (view_parallel.shard_views)."""
+    from humangaussian_amd import view_parallel as vp
+    from humangaussian_amd.renderer import Renderer
+    dev, cloud, cam0, rs = _setup(100_000, 0)
+
+    class Model:
+        active_sh_degree = 0
+        max_sh_degree = 0
+        def __init__(self, xyz): self.xyz = xyz
+        @property
+        def get_xyz(self): return self.xyz
+        @property
+        def get_features(self): return cloud.shs.to(dev)
+        @property
+        def get_opacity(self): return cloud.opacities.to(dev)
+        @property
+        def get_scaling(self): return cloud.scales.to(dev)
+        @property
+        def get_rotation(self): return cloud.rotations.to(dev)
+
+    class Cam:
+        pass
+
+    frames = list(range(16))
+    mine = vp.shard_views(len(frames), 3, 8)
+    assert mine == [3, 11]
+    base = cloud.means3D.to(dev)
+    prev = None
+    with torch.no_grad():
+        for i in frames[:6]:
+            ph = 2 * math.pi * i / 136.0
+            xyz = base + 0.03 * torch.stack([torch.sin(3 * base[:, 2] + ph), torch.cos(2 * base[:, 0] + ph),
+                                             torch.zeros_like(base[:, 0])], 1)
+            c = synth.orbit_camera(0.0, float(i % 360), 2.0, 50.0, RES, RES)
+            cam = Cam()
+            cam.image_height = cam.image_width = RES
+            cam.FoVx, cam.FoVy = c.FoVx, c.FoVy
+            cam.world_view_transform, cam.full_proj_transform = c.world_view_transform.to(dev), c.full_proj_transform.to(dev)
+            cam.camera_center = c.camera_center.to(dev)
+            out = Renderer(Model(xyz), white_background=False, device=dev).render(cam)
+            img = out["image"]
+            assert img.shape == (3, RES, RES) and not img.requires_grad and torch.isfinite(img).all()
+            assert float(img.min()) >= 0 and float(img.max()) <= 1 and int((out["radii"] > 0).sum()) > 90_000
+            if prev is not None:
+                assert float((img - prev).abs().mean()) > 1e-5          # the avatar actually moves
+            prev = img
