@@ -60,8 +60,10 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const float* __restrict__ dL_dalpha, float* __restrict__ grad_rows) {
   // per-pixel constants, row-major inside the tile (p = y*16 + x), two float4 per pixel:
   //   [gC0 gC1 gC2 gD] [gA F' n_contrib(bits) pixel_x]
-  __shared__ float4 s_pix[2 * 256];
-  __shared__ float s_T0[HGS_BWD_WAVES][256], s_F0[HGS_BWD_WAVES][256];
+  // 64 dummy pixels (n_contrib = 0) pad both ends, so the systolic loop indexes with
+  // p + 64 and needs neither a clamp nor a range test for the lanes still outside 0..255
+  __shared__ float4 s_pix[2 * (256 + 128)];
+  __shared__ float s_T0[HGS_BWD_WAVES][256 + 128], s_F0[HGS_BWD_WAVES][256 + 128];
 
   // ---- which (tile, bucket group) is this workgroup?  binary search the WG prefix
   const uint32_t g = blockIdx.x;
@@ -93,8 +95,13 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
            out_depth[pix] * gd + out_alpha[pix] * ga;
       nc = L.n_contrib[pix];
     }
-    s_pix[2 * tid + 0] = make_float4(c0, c1, c2, gd);
-    s_pix[2 * tid + 1] = make_float4(ga, fp, __uint_as_float(nc), (float)px);
+    s_pix[2 * (tid + 64) + 0] = make_float4(c0, c1, c2, gd);
+    s_pix[2 * (tid + 64) + 1] = make_float4(ga, fp, __uint_as_float(nc), (float)px);
+    if (tid < 128) {                                   // the two pads: never active
+      const int d = tid < 64 ? tid : tid + 256;
+      s_pix[2 * d + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      s_pix[2 * d + 1] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
+    }
   }
   __syncthreads();
 
@@ -138,15 +145,15 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       int lx, ly;
       hgs_fwd_thread_pixel(pf, lx, ly);
       const int p = ly * 16 + lx;                   // row-major pixel
-      const float4 pa = s_pix[2 * p + 0], pb = s_pix[2 * p + 1];
+      const float4 pa = s_pix[2 * (p + 64) + 0], pb = s_pix[2 * (p + 64) + 1];
       float T0 = 1.0f, F0 = 0.0f;
       if (bs && __float_as_uint(pb.z) > q0) {
         T0 = bs[0 * 256 + pf];
         F0 = bs[1 * 256 + pf] * pa.x + bs[2 * 256 + pf] * pa.y + bs[3 * 256 + pf] * pa.z +
              bs[4 * 256 + pf] * pa.w + bs[5 * 256 + pf] * pb.x;
       }
-      s_T0[w][p] = T0;
-      s_F0[w][p] = F0;
+      s_T0[w][p + 64] = T0;
+      s_F0[w][p + 64] = F0;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -157,27 +164,34 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   const float ty0f = (float)ty0;
   const float* __restrict__ T0w = s_T0[w];
   const float* __restrict__ F0w = s_F0[w];
+  if (lane < 64) {   // pads of the entry-state arrays are read (by lanes > 0) but never used
+    s_T0[w][lane] = 1.0f; s_F0[w][lane] = 0.0f;
+    s_T0[w][lane + 320] = 1.0f; s_F0[w][lane + 320] = 0.0f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 
   float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f;
   float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f;
   float T_out = 1.0f, F_out = 0.0f;
 
   for (int s = 0; s < nsteps; ++s) {
-    const int p = s - lane;
-    const int pc = min(max(p, 0), 255);
-    const int pe = min(s, 255);
-    const float T_in = wave_shift_in(T_out, T0w[pe], lane);
-    const float F_in = wave_shift_in(F_out, F0w[pe], lane);
-    const float4 pa = s_pix[2 * pc + 0];      // gC0 gC1 gC2 gD
-    const float4 pb = s_pix[2 * pc + 1];      // gA F' n_contrib pixel_x
+    const int pi = s - lane + 64;             // padded pixel index, 1 .. 382
+    // lane 0 takes the pipeline entry state of ITS pixel (= pixel s); every lane reads its
+    // own slot (conflict-free) and only lane 0 keeps it
+    const float T_in = wave_shift_in(T_out, T0w[pi], lane);
+    const float F_in = wave_shift_in(F_out, F0w[pi], lane);
+    const float4 pa = s_pix[2 * pi + 0];      // gC0 gC1 gC2 gD
+    const float4 pb = s_pix[2 * pi + 1];      // gA F' n_contrib pixel_x
     // same dx/dy expressions as the forward (absolute pixel centre) so skip decisions agree
     const float dx = mx - pb.w;
-    const float dy = my - (ty0f + (float)(pc >> 4));
+    const float dy = my - (ty0f + (float)((pi - 64) >> 4));
     float G, alpha, m2, m3;
     const bool keep = hgs_eval_alpha(dx, dy, qa, qb, qc, op, G, alpha, m2, m3);
-    const bool act = keep && ((uint32_t)p < 256u) && (q < __float_as_uint(pb.z));
-    const float a = act ? alpha : 0.0f;
-    const float Gm = act ? G : 0.0f;
+    // pad pixels have n_contrib = 0, so `q < n_contrib` also rejects out-of-range steps
+    const bool act = keep && (q < __float_as_uint(pb.z));
+    const float am = act ? op * G : 0.0f;     // un-clamped alpha (= op*G), 0 when inactive
+    const float a = fminf(HGS_ALPHA_MAX, am);
     const float wgt = a * T_in;
     const float S = __builtin_fmaf(cr, pa.x, __builtin_fmaf(cg, pa.y, __builtin_fmaf(cbl, pa.z,
                     __builtin_fmaf(dep, pa.w, pb.x))));
@@ -185,14 +199,14 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     const float om = 1.0f - a;
     T_out = T_in * om;
     F_out = F_new;
-    // om >= 0.01, so dLda is always finite; inactive pairs are removed through Gm = 0
+    // om >= 0.01, so dLda is always finite; inactive pairs are removed through am = 0
     const float dLda = __builtin_fmaf(T_in, S, -((pb.y - F_new) * __builtin_amdgcn_rcpf(om)));
     a_r = __builtin_fmaf(wgt, pa.x, a_r);
     a_g = __builtin_fmaf(wgt, pa.y, a_g);
     a_b = __builtin_fmaf(wgt, pa.z, a_b);
     a_d = __builtin_fmaf(wgt, pa.w, a_d);
-    a_op = __builtin_fmaf(Gm, dLda, a_op);
-    const float k = op * dLda * Gm;                       // dL/dG * G
+    const float k = am * dLda;                            // dL/dG * G  (= op * G * dL/dalpha)
+    a_op += k;                                            // = op * sum G dL/dalpha; /op below
     // d(p2)/d(dx) = 2 qa dx + qb dy = m2 + qa dx ;  d(p2)/d(dy) = qb dx + 2 qc dy
     a_mx = __builtin_fmaf(k, __builtin_fmaf(qa, dx, m2), a_mx);
     a_my = __builtin_fmaf(k, __builtin_fmaf(qb, dx, m3 + m3), a_my);
@@ -201,6 +215,8 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     a_cb = __builtin_fmaf(kdx, dy, a_cb);
     a_cc = __builtin_fmaf(kdy, dy, a_cc);
   }
+  // dL/dopacity = sum G dL/dalpha = a_op / op  (a_op is 0 whenever op is 0: never active)
+  a_op = (op != 0.0f) ? a_op / op : 0.0f;
 
   if (valid) {
     // undo the exp2 folding (d power = d p2 / log2e) and apply the conic factors
