@@ -59,11 +59,13 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                  const float* __restrict__ dL_dalpha, float* __restrict__ grad_rows) {
   // per-pixel constants, row-major inside the tile (p = y*16 + x), two float4 per pixel:
-  //   [gC0 gC1 gC2 gD] [gA F' n_contrib(bits) pixel_x]
+  //   plane A [gC0 gC1 gC2 gD], plane B [gA F' n_contrib(bits) pixel_x]
   // 64 dummy pixels (n_contrib = 0) pad both ends, so the systolic loop indexes with
   // p + 64 and needs neither a clamp nor a range test for the lanes still outside 0..255
-  __shared__ float4 s_pix[2 * (256 + 128)];
-  __shared__ float s_T0[HGS_BWD_WAVES][256 + 128], s_F0[HGS_BWD_WAVES][256 + 128];
+  // Two float4 planes (lane stride 16 B => conflict-free ds_read_b128) and one float2 plane
+  // per wave for the pipeline entry state (one ds_read_b64 per step).
+  __shared__ float4 s_pixA[256 + 128], s_pixB[256 + 128];
+  __shared__ float2 s_TF0[HGS_BWD_WAVES][256 + 128];
 
   // ---- which (tile, bucket group) is this workgroup?  binary search the WG prefix
   const uint32_t g = blockIdx.x;
@@ -95,12 +97,12 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
            out_depth[pix] * gd + out_alpha[pix] * ga;
       nc = L.n_contrib[pix];
     }
-    s_pix[2 * (tid + 64) + 0] = make_float4(c0, c1, c2, gd);
-    s_pix[2 * (tid + 64) + 1] = make_float4(ga, fp, __uint_as_float(nc), (float)px);
+    s_pixA[tid + 64] = make_float4(c0, c1, c2, gd);
+    s_pixB[tid + 64] = make_float4(ga, fp, __uint_as_float(nc), (float)px);
     if (tid < 128) {                                   // the two pads: never active
       const int d = tid < 64 ? tid : tid + 256;
-      s_pix[2 * d + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
-      s_pix[2 * d + 1] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
+      s_pixA[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+      s_pixB[d] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
     }
   }
   __syncthreads();
@@ -145,15 +147,14 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       int lx, ly;
       hgs_fwd_thread_pixel(pf, lx, ly);
       const int p = ly * 16 + lx;                   // row-major pixel
-      const float4 pa = s_pix[2 * (p + 64) + 0], pb = s_pix[2 * (p + 64) + 1];
+      const float4 pa = s_pixA[p + 64], pb = s_pixB[p + 64];
       float T0 = 1.0f, F0 = 0.0f;
       if (bs && __float_as_uint(pb.z) > q0) {
         T0 = bs[0 * 256 + pf];
         F0 = bs[1 * 256 + pf] * pa.x + bs[2 * 256 + pf] * pa.y + bs[3 * 256 + pf] * pa.z +
              bs[4 * 256 + pf] * pa.w + bs[5 * 256 + pf] * pb.x;
       }
-      s_T0[w][p + 64] = T0;
-      s_F0[w][p + 64] = F0;
+      s_TF0[w][p + 64] = make_float2(T0, F0);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -162,11 +163,10 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)HGS_BUCKET, n - q0));
   const int nsteps = 256 + (int)m - 1;
   const float ty0f = (float)ty0;
-  const float* __restrict__ T0w = s_T0[w];
-  const float* __restrict__ F0w = s_F0[w];
-  if (lane < 64) {   // pads of the entry-state arrays are read (by lanes > 0) but never used
-    s_T0[w][lane] = 1.0f; s_F0[w][lane] = 0.0f;
-    s_T0[w][lane + 320] = 1.0f; s_F0[w][lane + 320] = 0.0f;
+  const float2* __restrict__ TF0w = s_TF0[w];
+  {   // pads of the entry-state array are read (by lanes > 0) but never used
+    s_TF0[w][lane] = make_float2(1.0f, 0.0f);
+    s_TF0[w][lane + 320] = make_float2(1.0f, 0.0f);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -179,10 +179,11 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     const int pi = s - lane + 64;             // padded pixel index, 1 .. 382
     // lane 0 takes the pipeline entry state of ITS pixel (= pixel s); every lane reads its
     // own slot (conflict-free) and only lane 0 keeps it
-    const float T_in = wave_shift_in(T_out, T0w[pi], lane);
-    const float F_in = wave_shift_in(F_out, F0w[pi], lane);
-    const float4 pa = s_pix[2 * pi + 0];      // gC0 gC1 gC2 gD
-    const float4 pb = s_pix[2 * pi + 1];      // gA F' n_contrib pixel_x
+    const float2 tf0 = TF0w[pi];
+    const float T_in = wave_shift_in(T_out, tf0.x, lane);
+    const float F_in = wave_shift_in(F_out, tf0.y, lane);
+    const float4 pa = s_pixA[pi];             // gC0 gC1 gC2 gD
+    const float4 pb = s_pixB[pi];             // gA F' n_contrib pixel_x
     // same dx/dy expressions as the forward (absolute pixel centre) so skip decisions agree
     const float dx = mx - pb.w;
     const float dy = my - (ty0f + (float)((pi - 64) >> 4));
