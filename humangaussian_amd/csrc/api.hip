@@ -15,7 +15,7 @@
 
 // render_bwd.hip is a separate translation unit (different optimisation flags)
 extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*,
-                                            const float*, const float*, const float*,
+                                            const float*, const float*, const float*, const float*,
                                             const float*, const float*, const float*,
                                             const float*, float*);
 
@@ -27,7 +27,7 @@ constexpr int HGS_MAX_BIN_WGS = 256;
 
 struct GeomCarve {
   size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
-      tile_wgstart, tile_maxcontrib, hist, tile_grp, status, total;
+      tile_wgstart, tile_maxcontrib, tile_msegstart, pos_segstart, hist, tile_grp, status, total;
 };
 
 inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
@@ -47,6 +47,8 @@ GeomCarve carve_geom(int P, int H, int W) {
   c.tile_bstart = take((T + 1) * 4);
   c.tile_wgstart = take((T + 1) * 4);
   c.tile_maxcontrib = take(T * 4);
+  c.tile_msegstart = take((T + 1) * 4);
+  c.pos_segstart = take((T + 1) * 4);
   c.hist = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_MAX_BIN_WGS * T * 4 : 0);
   c.tile_grp = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
   c.status = take(sizeof(hgs_status));
@@ -54,7 +56,7 @@ GeomCarve carve_geom(int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, bstate, total; };
+struct BinCarve { size_t keys, recs, bstate, segT, segP, total; };
 
 BinCarve carve_bin(int64_t cap) {
   BinCarve c;
@@ -64,6 +66,9 @@ BinCarve carve_bin(int64_t cap) {
   c.keys = take(C * 8);
   c.recs = take(C * sizeof(SortRec));
   c.bstate = take(((C + HGS_BUCKET - 1) / HGS_BUCKET) * HGS_BSTATE_FLOATS * sizeof(float));
+  const size_t nms = 2 * (C / HGS_SEG) + 2;      // bound on segments of multi-segment tiles
+  c.segT = take(nms * HGS_TILE_PIX * sizeof(float));
+  c.segP = take(nms * HGS_SEG_PLANES * HGS_TILE_PIX * sizeof(float));
   c.total = off;
   return c;
 }
@@ -83,11 +88,15 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.tile_bstart = reinterpret_cast<uint32_t*>(gp + g.tile_bstart);
   L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
   L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
+  L.tile_msegstart = reinterpret_cast<uint32_t*>(gp + g.tile_msegstart);
+  L.pos_segstart = reinterpret_cast<uint32_t*>(gp + g.pos_segstart);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.tile_grp = reinterpret_cast<uint32_t*>(gp + g.tile_grp);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
+  L.segT = bp ? reinterpret_cast<float*>(bp + b.segT) : nullptr;
+  L.segP = bp ? reinterpret_cast<float*>(bp + b.segP) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;
 }
@@ -254,13 +263,28 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(4);
+  // list-parallel blend: segment transmittances, segments, combine (grids are capacity
+  // bounds; surplus workgroups exit on the device-side totals)
+  const unsigned seg_bound = (unsigned)(entry_capacity / HGS_SEG + 1);
+  if (entry_capacity >= HGS_SEG) {
+    hipLaunchKernelGGL(hgs_k_fwd_segT, dim3(2 * seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L,
+                       status_dev, L.recs, L.segT);
+    HGS_LAUNCH_CHECK();
+  }
   if (store_bwd_state)
-    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L, status_dev,
-                       L.recs, L.bstate, out_color, out_depth, out_alpha);
+    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T + seg_bound), dim3(HGS_FWD_THREADS), 0, stream,
+                       v, L, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color, out_depth,
+                       out_alpha);
   else
-    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L,
-                       status_dev, L.recs, L.bstate, out_color, out_depth, out_alpha);
+    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T + seg_bound), dim3(HGS_FWD_THREADS), 0,
+                       stream, v, L, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color,
+                       out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
+  if (entry_capacity >= HGS_SEG) {
+    hipLaunchKernelGGL(hgs_k_fwd_combine, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L,
+                       status_dev, L.segP, out_color, out_depth, out_alpha);
+    HGS_LAUNCH_CHECK();
+  }
   HGS_STAGE(5);
   return HGS_OK;
 }
@@ -302,7 +326,7 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
   HGS_STAGE(0);
   if (groups > 0) {
     hipLaunchKernelGGL(hgs_k_render_bwd, dim3(groups), dim3(256), 0, stream, v, L, status_dev,
-                       L.recs, L.bstate, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
+                       L.recs, L.bstate, L.segP, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
                        dL_dout_alpha, rows);
     HGS_LAUNCH_CHECK();
   }

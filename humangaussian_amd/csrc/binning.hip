@@ -22,24 +22,31 @@ constexpr int SCAN_NT = 1024;
 constexpr int SCAN_ITEMS = 4;      // tiles per thread per pass
 
 // exclusive scan of three counters at once over the workgroup (one barrier pair)
-__device__ __forceinline__ void block_excl_scan3(uint32_t v0, uint32_t v1, uint32_t v2,
-                                                 uint32_t (*wtot)[3], uint32_t ex[3],
-                                                 uint32_t tot[3]) {
+constexpr int NSCAN = 4;
+__device__ __forceinline__ void block_excl_scanN(const uint32_t (&v)[NSCAN], uint32_t (*wtot)[NSCAN],
+                                                 uint32_t (&ex)[NSCAN], uint32_t (&tot)[NSCAN]) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t i0 = hgs_wave_incl_scan(v0), i1 = hgs_wave_incl_scan(v1),
-                 i2 = hgs_wave_incl_scan(v2);
-  __syncthreads();
-  if (lane == 63) { wtot[w][0] = i0; wtot[w][1] = i1; wtot[w][2] = i2; }
-  __syncthreads();
-  uint32_t b0 = 0, b1 = 0, b2 = 0, t0 = 0, t1 = 0, t2 = 0;
+  uint32_t inc[NSCAN];
 #pragma unroll
-  for (int k = 0; k < SCAN_NT / 64; ++k) {
-    const uint32_t x0 = wtot[k][0], x1 = wtot[k][1], x2 = wtot[k][2];
-    if (k < w) { b0 += x0; b1 += x1; b2 += x2; }
-    t0 += x0; t1 += x1; t2 += x2;
+  for (int q = 0; q < NSCAN; ++q) inc[q] = hgs_wave_incl_scan(v[q]);
+  __syncthreads();
+  if (lane == 63) {
+#pragma unroll
+    for (int q = 0; q < NSCAN; ++q) wtot[w][q] = inc[q];
   }
-  ex[0] = b0 + i0 - v0; ex[1] = b1 + i1 - v1; ex[2] = b2 + i2 - v2;
-  tot[0] = t0; tot[1] = t1; tot[2] = t2;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NSCAN; ++q) {
+    uint32_t b = 0, t = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_NT / 64; ++k) {
+      const uint32_t x = wtot[k][q];
+      if (k < w) b += x;
+      t += x;
+    }
+    ex[q] = b + inc[q] - v[q];
+    tot[q] = t;
+  }
 }
 }  // namespace
 
@@ -51,16 +58,16 @@ extern "C" __global__ void __launch_bounds__(SCAN_NT)
 hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
            hgs_status* __restrict__ status_host) {
   __shared__ uint32_t wtot[SCAN_NT / 64];
-  __shared__ uint32_t wtot3[SCAN_NT / 64][3];
+  __shared__ uint32_t wtotN[SCAN_NT / 64][NSCAN];
   __shared__ uint32_t carry_s;
-  __shared__ uint32_t carry3[3];
+  __shared__ uint32_t carry3[NSCAN];
   __shared__ uint32_t cls_hist[33];
   __shared__ uint32_t cls_base[33];
   __shared__ uint32_t max_n_s;
   const int tid = threadIdx.x;
 
   // (a) exclusive scan of per-chunk tiles_touched sums -> block_base
-  if (tid == 0) { carry_s = 0; carry3[0] = carry3[1] = carry3[2] = 0; max_n_s = 0; }
+  if (tid == 0) { carry_s = 0; carry3[0] = carry3[1] = carry3[2] = carry3[3] = 0; max_n_s = 0; }
   if (tid < 33) cls_hist[tid] = 0;
   __syncthreads();
   for (int base = 0; base < v.nblk; base += SCAN_NT) {
@@ -103,32 +110,38 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
 #pragma unroll
       for (int k = 0; k < SCAN_ITEMS; ++k) n[k] = (t0 + k < v.T) ? L.tile_count[t0 + k] : 0u;
     }
-    uint32_t l0 = 0, l1 = 0, l2 = 0, mx = 0;
-    uint32_t p0[SCAN_ITEMS], p1[SCAN_ITEMS], p2[SCAN_ITEMS];
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, mx = 0;
+    uint32_t p0[SCAN_ITEMS], p1[SCAN_ITEMS], p2[SCAN_ITEMS], p3[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
       const uint32_t nb = (n[k] + HGS_BUCKET - 1) / HGS_BUCKET;
-      p0[k] = l0; p1[k] = l1; p2[k] = l2;
+      const uint32_t nseg = (n[k] + HGS_SEG - 1) / HGS_SEG;
+      p0[k] = l0; p1[k] = l1; p2[k] = l2; p3[k] = l3;
       l0 += n[k];
       l1 += nb > 0 ? nb - 1 : 0;                               // stored bucket states
       l2 += (nb + HGS_BWD_WAVES - 1) / HGS_BWD_WAVES;          // backward workgroups
+      l3 += nseg > 1 ? nseg : 0;                               // segment planes of long lists
       mx = max(mx, n[k]);
     }
-    uint32_t ex[3], tot[3];
-    block_excl_scan3(l0, l1, l2, wtot3, ex, tot);
+    uint32_t ex[NSCAN], tot[NSCAN];
+    const uint32_t lv[NSCAN] = {l0, l1, l2, l3};
+    block_excl_scanN(lv, wtotN, ex, tot);
     const uint32_t c0 = carry3[0], c1 = carry3[1], c2 = carry3[2];
-    uint32_t ts[SCAN_ITEMS], tb[SCAN_ITEMS], tw[SCAN_ITEMS];
+    const uint32_t c3 = carry3[3];
+    uint32_t ts[SCAN_ITEMS], tb[SCAN_ITEMS], tw[SCAN_ITEMS], tm[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
       ts[k] = c0 + ex[0] + p0[k];
       tb[k] = c1 + ex[1] + p1[k];
       tw[k] = c2 + ex[2] + p2[k];
+      tm[k] = c3 + ex[3] + p3[k];
     }
     if (vec) {
       *reinterpret_cast<uint4*>(L.tile_start + t0) = make_uint4(ts[0], ts[1], ts[2], ts[3]);
       *reinterpret_cast<uint4*>(L.tile_bstart + t0) = make_uint4(tb[0], tb[1], tb[2], tb[3]);
       *reinterpret_cast<uint4*>(L.tile_wgstart + t0) = make_uint4(tw[0], tw[1], tw[2], tw[3]);
       *reinterpret_cast<uint4*>(L.tile_maxcontrib + t0) = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(L.tile_msegstart + t0) = make_uint4(tm[0], tm[1], tm[2], tm[3]);
       if (v.lds_bins) {
         uint32_t acc[SCAN_ITEMS] = {ts[0], ts[1], ts[2], ts[3]};
 #pragma unroll
@@ -150,6 +163,7 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
           L.tile_bstart[t] = tb[k];
           L.tile_wgstart[t] = tw[k];
           L.tile_maxcontrib[t] = 0;
+          L.tile_msegstart[t] = tm[k];
           if (v.lds_bins) {
             uint32_t acc = ts[k];
 #pragma unroll
@@ -176,13 +190,14 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
     }
     if (mx) atomicMax(&max_n_s, mx);
     __syncthreads();
-    if (tid == 0) { carry3[0] = c0 + tot[0]; carry3[1] = c1 + tot[1]; carry3[2] = c2 + tot[2]; }
+    if (tid == 0) { carry3[0] = c0 + tot[0]; carry3[1] = c1 + tot[1]; carry3[2] = c2 + tot[2]; carry3[3] = c3 + tot[3]; }
     __syncthreads();
   }
   if (tid == 0) {
     L.tile_start[v.T] = carry3[0];
     L.tile_bstart[v.T] = carry3[1];
     L.tile_wgstart[v.T] = carry3[2];
+    L.tile_msegstart[v.T] = carry3[3];
     // heavy classes first; class 0 (empty tiles) last
     uint32_t acc = 0;
     for (int c = 32; c >= 0; --c) { cls_base[c] = acc; acc += cls_hist[c]; }
@@ -225,6 +240,29 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
       L.tile_order[pos] = (uint32_t)t;
     }
   }
+  // (d) forward work items: one per segment of HGS_SEG entries, in tile_order (heavy first);
+  // pos_segstart = exclusive prefix of max(1, nseg) over tile_order positions
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < v.T; base += SCAN_NT) {
+    const int pos = base + tid;
+    uint32_t ns = 0;
+    if (pos < v.T) {
+      const uint32_t t = L.tile_order[pos];
+      const uint32_t n = L.tile_start[t + 1] - L.tile_start[t];
+      ns = max(1u, (n + HGS_SEG - 1) / HGS_SEG);
+    }
+    uint32_t total;
+    const uint32_t ex1 = hgs_block_excl_scan<SCAN_NT>(ns, wtot, total);
+    const uint32_t carry = carry_s;
+    if (pos < v.T) L.pos_segstart[pos] = carry + ex1;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (tid == 0) L.pos_segstart[v.T] = carry_s;
 }
 
 // ---------------------------------------------------------------------------- 2. fill

@@ -12,7 +12,8 @@
 //   uint32   tile_order[T]    (heavy first)
 //   uint32   tile_bstart[T+1] (bucket-state prefix)        bwd scratch: float grad_rows[R][12]
 //   uint32   tile_wgstart[T+1](backward WG prefix)
-//   uint32   tile_maxcontrib[T]
+//   uint32   tile_maxcontrib[T]                float segT[2C/SEG][256], segP[2C/SEG][7][256]
+//   uint32   tile_msegstart[T+1], pos_segstart[T+1]   (forward segments of long lists)
 //   uint32   hist[NWG][T]      (per-binning-workgroup tile histograms, T <= 16384)
 //
 // wave = 64 lanes everywhere; a "bucket" is 64 consecutive entries of one tile's list.
@@ -28,6 +29,10 @@
 #define HGS_BUCKET 64          // entries per backward bucket (= one wave)
 #define HGS_BWD_WAVES 4        // buckets per backward workgroup
 #define HGS_ROW_GROUPS 4       // histogram row groups scanned in parallel by hgs_k_colscan
+#ifndef HGS_SEG
+#define HGS_SEG 512            // entries per forward segment (list-parallel blend), multiple of 64
+#endif
+#define HGS_SEG_PLANES 7       // per-segment pixel planes: C0 C1 C2 D W Tend(signed) last(bits)
 #define HGS_NEAR_Z 0.2f
 #define HGS_ALPHA_MIN (1.0f / 255.0f)
 #define HGS_ALPHA_MAX 0.99f
@@ -68,11 +73,15 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* tile_bstart;
   uint32_t* tile_wgstart;
   uint32_t* tile_maxcontrib;
+  uint32_t* tile_msegstart;   // [T+1] prefix of (nseg > 1 ? nseg : 0): index of a tile's segment planes
+  uint32_t* pos_segstart;     // [T+1] prefix of nseg over tile_order positions: forward work items
   uint32_t* hist;          // [nwg][T] per-workgroup tile histograms -> exclusive bases
   uint32_t* tile_grp;      // [HGS_ROW_GROUPS][T] row-group totals -> absolute group bases
   unsigned long long* keys;
   SortRec* recs;
   float* bstate;
+  float* segT;             // [2C/SEG][256]   product of (1-alpha) over a (non-last) segment
+  float* segP;             // [2C/SEG][7][256] per-segment partial sums -> exclusive prefix (base)
   uint32_t* n_contrib;
 };
 
@@ -91,38 +100,18 @@ struct View {            // per-call constants, passed by value to every kernel
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Forward pixel ownership.  HGS_FWD_PPL = pixels per lane of the forward blend kernel:
-//   1: four waves per tile, wave w owns the 8x8 quadrant (w&1, w>>1);
-//   2: two waves per tile, wave w owns the 16x8 half (rows 8w..8w+7), each lane two pixels
-//      4 rows apart (two independent T chains per lane).  Measured SLOWER (168 vs 87 us at
-//      config 2: the cull is weaker and the extra ILP does not materialise); kept as a
-//      build-time experiment switch, default 1.
-// `pf` in [0,256) is the index under which the forward stores per-pixel bucket state; the
-// backward maps it back to a pixel with the same function.
-#ifndef HGS_FWD_PPL
-#define HGS_FWD_PPL 1
-#endif
+// Forward pixel ownership: four waves per tile, wave w owns the 8x8 quadrant (w&1, w>>1),
+// lane l is (l&7, l>>3) inside it.  `pf` in [0,256) (= forward thread index) is the index
+// under which the forward stores per-pixel bucket / segment state; the backward and the
+// combine kernel map it back to a pixel with the same function.
+// (A 2-pixels-per-lane / 2-waves-per-tile variant was measured: 168 vs 87 us - the cull is
+// weaker and the extra ILP does not materialise; removed.)
 __device__ __forceinline__ void hgs_fwd_thread_pixel(int pf, int& lx, int& ly) {
-#if HGS_FWD_PPL == 1
   const int w = pf >> 6, l = pf & 63;
   lx = ((w & 1) << 3) | (l & 7);
   ly = ((w >> 1) << 3) | (l >> 3);
-#else
-  const int w = pf >> 7, k = (pf >> 6) & 1, l = pf & 63;
-  lx = l & 15;
-  ly = (w << 3) + (k << 2) + (l >> 4);
-#endif
 }
-// cull-mask bits (quadrants 0..3 = (x>=8) | (y>=8)<<1) that a forward wave must look at
-__device__ __forceinline__ uint32_t hgs_fwd_wave_cullbits(int w) {
-#if HGS_FWD_PPL == 1
-  return 1u << w;
-#else
-  return w == 0 ? 0x3u : 0xcu;
-#endif
-}
-#define HGS_FWD_WAVES (4 / HGS_FWD_PPL)
-#define HGS_FWD_THREADS (64 * HGS_FWD_WAVES)
+#define HGS_FWD_THREADS 256
 
 // The one place alpha is evaluated, shared by forward and backward so both take the
 // identical instruction sequence (skip decisions must agree).  q* are the folded conic of

@@ -54,7 +54,8 @@ __device__ __forceinline__ float wave_shift_in(float prev_out, float first, int 
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const SortRec* __restrict__ recs_all,
-                 const float* __restrict__ bstate, const float* __restrict__ out_color,
+                 const float* __restrict__ bstate, const float* __restrict__ segP,
+                 const float* __restrict__ out_color,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                  const float* __restrict__ dL_dalpha, float* __restrict__ grad_rows) {
@@ -141,6 +142,11 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   {
     const float* bs = (b > 0) ? bstate + (size_t)(L.tile_bstart[t] + b - 1) * HGS_BSTATE_FLOATS
                               : nullptr;
+    // the forward blends long lists in segments of HGS_SEG entries: bucket states hold C, D, W
+    // relative to the segment start, the combine kernel left the segment's base in segP
+    const uint32_t kseg = q0 / HGS_SEG;
+    const float* base = (kseg > 0) ? segP + (size_t)(L.tile_msegstart[t] + kseg) * HGS_SEG_PLANES * HGS_TILE_PIX
+                                   : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int pf = k * 64 + lane;                 // forward thread index
@@ -151,8 +157,13 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       float T0 = 1.0f, F0 = 0.0f;
       if (bs && __float_as_uint(pb.z) > q0) {
         T0 = bs[0 * 256 + pf];
-        F0 = bs[1 * 256 + pf] * pa.x + bs[2 * 256 + pf] * pa.y + bs[3 * 256 + pf] * pa.z +
-             bs[4 * 256 + pf] * pa.w + bs[5 * 256 + pf] * pb.x;
+        float c0 = bs[1 * 256 + pf], c1 = bs[2 * 256 + pf], c2 = bs[3 * 256 + pf];
+        float d = bs[4 * 256 + pf], wt = bs[5 * 256 + pf];
+        if (base) {
+          c0 += base[0 * 256 + pf]; c1 += base[1 * 256 + pf]; c2 += base[2 * 256 + pf];
+          d += base[3 * 256 + pf]; wt += base[4 * 256 + pf];
+        }
+        F0 = c0 * pa.x + c1 * pa.y + c2 * pa.z + d * pa.w + wt * pb.x;
       }
       s_TF0[w][p + 64] = make_float2(T0, F0);
     }

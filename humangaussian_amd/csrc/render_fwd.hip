@@ -1,27 +1,42 @@
-// render_fwd.hip - per-tile front-to-back alpha blending (stage F6).
+// render_fwd.hip - front-to-back alpha blending (stage F6), list-parallel.
 //
-// One 256-thread workgroup per 16x16 tile; its four wave64 are INDEPENDENT (no barriers):
-// wave w owns the 8x8 pixel quadrant (w&1, w>>1) and walks the tile's depth-sorted 48-byte
-// record list in buckets of 64:
-//   1. each lane loads one record of the bucket with coalesced 16 B/lane loads (the loads
-//      for the NEXT bucket are issued before the current one is blended);
-//   2. wavefront ballot + prefix popcount COMPACT the bucket to the records whose
-//      conservative cull mask (computed at sort time) says they can reach alpha >= 1/255
-//      somewhere in this wave's quadrant - typically about half - into a wave-private
-//      3 KB LDS slice, each carrying its original list position;
-//   3. a branch-free, 4x unrolled, software-pipelined loop broadcasts the compacted
-//      records from LDS (ds_read_b128, same address in every lane) and blends them with
-//      per-lane predication; the only loop-carried dependency is the transmittance T.
-// Workgroups are issued heavy-tile-first (tile_order).  When the call needs a backward,
-// the running per-pixel state (T, C, D, W) is stored at every 64-entry bucket boundary.
+// Upstream runs one thread block per tile and walks the tile's whole depth-sorted list
+// serially; on a human avatar a few tiles hold 1.5k+ entries and that serial chain, not the
+// arithmetic, sets the kernel time.  Here a tile's list is cut into SEGMENTS of HGS_SEG
+// (512) entries that are blended IN PARALLEL by different workgroups:
 //
-// Semantics follow upstream's renderCUDA of the ashawkey fork exactly (skip rules, the
-// terminating Gaussian is not blended, depth not normalised, out_alpha = sum of weights,
-// n_contrib = list position of the last blended Gaussian).
-// Roofline: VALU-bound (about 24 VALU per kept pixel-Gaussian pair); HBM traffic is
-// 48 B/entry/wave in (L2-served after the first wave) + 24 B/pixel out
-// (+ 24 B/pixel/bucket state when storing).
+//   hgs_k_fwd_segT     for every segment that has a successor: P_k = product over the
+//                      segment of (1 - alpha) per pixel (alpha evaluation only, no colours).
+//   hgs_k_fwd_blend    one workgroup per segment (heavy tiles first).  Entry transmittance
+//                      T_in = P_0 * ... * P_(k-1); because T only decreases, "the pixel was
+//                      terminated by T < 1e-4 before this segment" is exactly T_in < 1e-4,
+//                      so upstream's stop rule (the terminating Gaussian is not blended,
+//                      nothing after it counts) is reproduced; inside the segment the blend
+//                      is upstream's sequential loop.  Single-segment tiles write the image
+//                      directly; others write per-segment partial sums.
+//   hgs_k_fwd_combine  per multi-segment tile: sums the partials in segment order
+//                      (deterministic), writes the image, and turns the partials into
+//                      exclusive prefixes (segment bases) for the backward.
+//
+// Inside a segment the four wave64 of a workgroup are INDEPENDENT (no barriers): wave w owns
+// the 8x8 pixel quadrant (w&1, w>>1) and walks the segment in buckets of 64 records:
+//   1. coalesced 16 B/lane loads of the bucket's 48-byte records, issued one bucket ahead;
+//   2. wavefront ballot + prefix popcount COMPACT the bucket to the records whose conservative
+//      cull bit (computed at sort time) says they can reach alpha >= 1/255 in this quadrant
+//      (about half) into a wave-private LDS slice, each carrying its list position;
+//   3. a branch-free, 4x unrolled loop broadcasts the compacted records from LDS and blends
+//      them with per-lane predication; T is the only loop-carried dependency.
+// When a backward will follow, the per-pixel state (T absolute; C, D, W relative to the
+// segment start) is stored at every 64-entry bucket boundary.
+//
+// Roofline: VALU issue (about 37 instructions per kept record per wave); HBM traffic
+// 48 B/entry/wave in (L2-served after the first wave), 24 B/pixel out, 24 B/pixel/bucket
+// state when storing, 32 B/pixel/segment for long lists.
 #include "hgs_common.h"
+
+#ifndef HGS_FWD_UNROLL
+#define HGS_FWD_UNROLL 4      // compacted records per unrolled group (pad records >= this)
+#endif
 
 namespace {
 
@@ -52,80 +67,37 @@ __device__ __forceinline__ void blend_one(PixState& s, float pxf, float pyf, con
   s.last = upd ? __float_as_uint(r2.w) : s.last;
 }
 
-}  // namespace
+// transmittance-only variant (no stop rule): P *= (1 - alpha) for kept pairs
+__device__ __forceinline__ void tprod_one(float& P, float pxf, float pyf, const float4 r0,
+                                          const float4 r1) {
+  float G, alpha, m2, m3;
+  const bool keep = hgs_eval_alpha(r0.x - pxf, r0.y - pyf, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
+  P *= keep ? (1.0f - alpha) : 1.0f;
+}
 
-template <bool STORE>
-__device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
-                                                const hgs_status* __restrict__ status,
-                                                const SortRec* __restrict__ recs_all,
-                                                float* __restrict__ bstate,
-                                                float* __restrict__ out_color,
-                                                float* __restrict__ out_depth,
-                                                float* __restrict__ out_alpha) {
-  constexpr int PPL = HGS_FWD_PPL;
-  // wave-private compacted buckets (+4 zero-opacity pad records so the unrolled loop
-  // needs neither index clamps nor a tail predicate)
-  __shared__ float4 s_rec[HGS_FWD_WAVES][3 * (HGS_BUCKET + 4)];
-  const bool overflow = status->overflow != 0;
-  const int t = overflow ? (int)blockIdx.x : (int)L.tile_order[blockIdx.x];
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
-  const int tile_x = t % v.grid_x, tile_y = t / v.grid_x;
-
-  int pf[PPL], px[PPL], py[PPL];
-  float pxf[PPL], pyf[PPL];
-  bool inside[PPL];
-  PixState s[PPL];
-#pragma unroll
-  for (int k = 0; k < PPL; ++k) {
-    pf[k] = w * (64 * PPL) + k * 64 + lane;
-    int lx, ly;
-    hgs_fwd_thread_pixel(pf[k], lx, ly);
-    px[k] = tile_x * HGS_TILE + lx; py[k] = tile_y * HGS_TILE + ly;
-    inside[k] = (px[k] < v.W) && (py[k] < v.H);
-    pxf[k] = (float)px[k]; pyf[k] = (float)py[k];
-    s[k].T = 1.0f; s[k].C0 = s[k].C1 = s[k].C2 = s[k].D = s[k].Wt = 0.f;
-    s[k].last = 0;
-    s[k].done = !inside[k];
-  }
-
-  const uint32_t start = overflow ? 0u : L.tile_start[t];
-  const uint32_t n = overflow ? 0u : (L.tile_start[t + 1] - start);
-  const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
-  const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
-  const uint32_t wbits = hgs_fwd_wave_cullbits(w) << 28;
-  float4* __restrict__ srec = s_rec[w];
+// Wave-level walk over list entries [q_begin, q_end) of one tile: loads, compaction, and a
+// callback per group of 4 compacted records.  BODY(ra, rb, rc) gets float4[4] arrays;
+// PRE(j0) runs at every bucket start (bucket-state stores); ALIVE() lets the wave stop early.
+template <typename Pre, typename Alive, typename Body>
+__device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, uint32_t q_begin,
+                                             uint32_t q_end, uint32_t wbit, float4* __restrict__ srec,
+                                             int lane, Pre pre, Alive alive, Body body) {
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // records of the first bucket
   float4 c0 = zero4, c1 = zero4, c2 = zero4;
-  if ((uint32_t)lane < n) { c0 = recs[3 * lane + 0]; c1 = recs[3 * lane + 1]; c2 = recs[3 * lane + 2]; }
-
-  for (uint32_t j0 = 0; j0 < n; j0 += HGS_BUCKET) {
-    bool alive = false;
-#pragma unroll
-    for (int k = 0; k < PPL; ++k) alive = alive || !s[k].done;
-    if (__ballot(alive) == 0ull) break;              // every pixel of this wave is finished
-    if (STORE && j0 > 0) {
-      float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        bs[0 * 256 + pf[k]] = s[k].T;
-        bs[1 * 256 + pf[k]] = s[k].C0;
-        bs[2 * 256 + pf[k]] = s[k].C1;
-        bs[3 * 256 + pf[k]] = s[k].C2;
-        bs[4 * 256 + pf[k]] = s[k].D;
-        bs[5 * 256 + pf[k]] = s[k].Wt;
-      }
-    }
-    // issue the next bucket's loads now; they land while this bucket is blended
+  {
+    const uint32_t q = q_begin + lane;
+    if (q < q_end) { c0 = recs[3 * q + 0]; c1 = recs[3 * q + 1]; c2 = recs[3 * q + 2]; }
+  }
+  for (uint32_t j0 = q_begin; j0 < q_end; j0 += HGS_BUCKET) {
+    if (!alive()) break;
+    pre(j0);
+    // issue the next bucket's loads now; they land while this bucket is processed
     const uint32_t qn = j0 + HGS_BUCKET + lane;
     float4 n0 = zero4, n1 = zero4, n2 = zero4;
-    if (qn < n) { n0 = recs[3 * qn + 0]; n1 = recs[3 * qn + 1]; n2 = recs[3 * qn + 2]; }
+    if (qn < q_end) { n0 = recs[3 * qn + 0]; n1 = recs[3 * qn + 1]; n2 = recs[3 * qn + 2]; }
 
-    // ballot + prefix popcount compaction of the records that can touch this wave's pixels
-    const bool hit = (j0 + lane < n) && ((__float_as_uint(c2.w) & wbits) != 0u);
+    // ballot + prefix popcount compaction of the records that can touch this quadrant
+    const bool hit = (j0 + lane < q_end) && ((__float_as_uint(c2.w) & wbit) != 0u);
     const unsigned long long ball = __ballot(hit);
     const uint32_t cnt = (uint32_t)__popcll(ball);
     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
@@ -136,7 +108,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
       srec[3 * pos + 1] = c1;
       srec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float(j0 + lane + 1));
     }
-    if (lane < 4) {                                  // 4 pad records behind the last real one
+    if (lane < 2 * HGS_FWD_UNROLL) {                 // pad records behind the last real one
       srec[3 * (cnt + lane) + 0] = zero4;
       srec[3 * (cnt + lane) + 1] = zero4;            // opacity 0 => alpha 0 => skipped
       srec[3 * (cnt + lane) + 2] = zero4;
@@ -144,39 +116,175 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    constexpr int U = 4 / PPL;                       // records per unrolled group
-    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
-      float4 ra[U], rb[U], rc[U];
+#ifdef HGS_FWD_LDS_PREFETCH
+    // register double buffer: the LDS reads of group g+1 are in flight while group g blends
+    float4 ra[HGS_FWD_UNROLL], rb[HGS_FWD_UNROLL], rc[HGS_FWD_UNROLL];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < HGS_FWD_UNROLL; ++u) {
+      ra[u] = srec[3 * u + 0]; rb[u] = srec[3 * u + 1]; rc[u] = srec[3 * u + 2];
+    }
+    for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_FWD_UNROLL) {
+      float4 na[HGS_FWD_UNROLL], nb[HGS_FWD_UNROLL], nc[HGS_FWD_UNROLL];
+#pragma unroll
+      for (int u = 0; u < HGS_FWD_UNROLL; ++u) {
+        const uint32_t k = k0 + HGS_FWD_UNROLL + u;          // <= cnt + 2U - 1: inside the pads
+        na[u] = srec[3 * k + 0]; nb[u] = srec[3 * k + 1]; nc[u] = srec[3 * k + 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      body(ra, rb, rc);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < HGS_FWD_UNROLL; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
+    }
+#else
+    for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_FWD_UNROLL) {
+      float4 ra[HGS_FWD_UNROLL], rb[HGS_FWD_UNROLL], rc[HGS_FWD_UNROLL];
+#pragma unroll
+      for (int u = 0; u < HGS_FWD_UNROLL; ++u) {
         ra[u] = srec[3 * (k0 + u) + 0]; rb[u] = srec[3 * (k0 + u) + 1]; rc[u] = srec[3 * (k0 + u) + 2];
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int k = 0; k < PPL; ++k) blend_one(s[k], pxf[k], pyf[k], ra[u], rb[u], rc[u]);
-      }
+      body(ra, rb, rc);
     }
+#endif
     c0 = n0; c1 = n1; c2 = n2;
   }
+}
 
-  uint32_t mx = 0;
+// binary search: largest i in [0, n) with prefix[i] <= g   (prefix[0] = 0, prefix[n] = total)
+__device__ __forceinline__ int find_owner(const uint32_t* __restrict__ prefix, int n, uint32_t g) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ segment transmittance
+extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
+hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
+               const SortRec* __restrict__ recs_all, float* __restrict__ segT) {
+  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * HGS_FWD_UNROLL)];
+  const uint32_t ms = blockIdx.x;
+  if (status->overflow || ms >= L.tile_msegstart[v.T]) return;
+  const int t = find_owner(L.tile_msegstart, v.T, ms);
+  const uint32_t k = ms - L.tile_msegstart[t];
+  const uint32_t start = L.tile_start[t];
+  const uint32_t n = L.tile_start[t + 1] - start;
+  const uint32_t nseg = (n + HGS_SEG - 1) / HGS_SEG;
+  if (k + 1 >= nseg) return;                       // the last segment has no successor
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  int lx, ly;
+  hgs_fwd_thread_pixel(tid, lx, ly);
+  const float pxf = (float)((t % v.grid_x) * HGS_TILE + lx), pyf = (float)((t / v.grid_x) * HGS_TILE + ly);
+  const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
+  float P = 1.0f;
+  walk_segment(recs, k * HGS_SEG, (k + 1) * HGS_SEG, 1u << (28 + w), s_rec[w], lane,
+               [](uint32_t) {}, [] { return true; },
+               [&](const float4 (&ra)[HGS_FWD_UNROLL], const float4 (&rb)[HGS_FWD_UNROLL], const float4 (&)[HGS_FWD_UNROLL]) {
 #pragma unroll
-  for (int k = 0; k < PPL; ++k) {
-    if (inside[k]) {
-      const size_t pix = (size_t)py[k] * v.W + px[k];
+                 for (int u = 0; u < HGS_FWD_UNROLL; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
+               });
+  segT[(size_t)ms * HGS_TILE_PIX + tid] = P;
+}
+
+// ---------------------------------------------------------------------------- blend
+template <bool STORE>
+__device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
+                                                const hgs_status* __restrict__ status,
+                                                const SortRec* __restrict__ recs_all,
+                                                float* __restrict__ bstate,
+                                                const float* __restrict__ segT,
+                                                float* __restrict__ segP,
+                                                float* __restrict__ out_color,
+                                                float* __restrict__ out_depth,
+                                                float* __restrict__ out_alpha) {
+  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * HGS_FWD_UNROLL)];
+  const bool overflow = status->overflow != 0;
+  int t;
+  uint32_t k = 0;
+  if (overflow) {                                   // lists are invalid: background only
+    if ((int)blockIdx.x >= v.T) return;
+    t = (int)blockIdx.x;
+  } else {
+    const uint32_t g = blockIdx.x;
+    if (g >= L.pos_segstart[v.T]) return;           // surplus workgroup of the bounded grid
+    const int pos = find_owner(L.pos_segstart, v.T, g);
+    t = (int)L.tile_order[pos];
+    k = g - L.pos_segstart[pos];
+  }
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int tile_x = t % v.grid_x, tile_y = t / v.grid_x;
+  int lx, ly;
+  hgs_fwd_thread_pixel(tid, lx, ly);
+  const int px = tile_x * HGS_TILE + lx, py = tile_y * HGS_TILE + ly;
+  const bool inside = (px < v.W) && (py < v.H);
+  const float pxf = (float)px, pyf = (float)py;
+
+  const uint32_t start = overflow ? 0u : L.tile_start[t];
+  const uint32_t n = overflow ? 0u : (L.tile_start[t + 1] - start);
+  const uint32_t nseg = max(1u, (n + HGS_SEG - 1) / HGS_SEG);
+  const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
+  const uint32_t ms0 = (nseg > 1) ? L.tile_msegstart[t] : 0u;
+  const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
+
+  PixState s;
+  s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
+  s.last = 0;
+  for (uint32_t i = 0; i < k; ++i) s.T *= segT[(size_t)(ms0 + i) * HGS_TILE_PIX + tid];
+  // T only decreases: "terminated before this segment" <=> entry transmittance < 1e-4
+  s.done = !inside || (s.T < HGS_T_EPS);
+
+  walk_segment(
+      recs, k * HGS_SEG, min(n, (k + 1) * HGS_SEG), 1u << (28 + w), s_rec[w], lane,
+      [&](uint32_t j0) {
+        if (STORE && j0 > 0) {
+          float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
+          bs[0 * 256 + tid] = s.T;
+          bs[1 * 256 + tid] = s.C0;
+          bs[2 * 256 + tid] = s.C1;
+          bs[3 * 256 + tid] = s.C2;
+          bs[4 * 256 + tid] = s.D;
+          bs[5 * 256 + tid] = s.Wt;
+        }
+      },
+      [&] { return __ballot(!s.done) != 0ull; },      // stop when every pixel is finished
+      [&](const float4 (&ra)[HGS_FWD_UNROLL], const float4 (&rb)[HGS_FWD_UNROLL], const float4 (&rc)[HGS_FWD_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < HGS_FWD_UNROLL; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
+      });
+
+  if (nseg == 1) {
+    if (inside) {
+      const size_t pix = (size_t)py * v.W + px;
       const size_t HW = (size_t)v.H * v.W;
-      out_color[0 * HW + pix] = s[k].C0 + s[k].T * v.bg[0];
-      out_color[1 * HW + pix] = s[k].C1 + s[k].T * v.bg[1];
-      out_color[2 * HW + pix] = s[k].C2 + s[k].T * v.bg[2];
-      out_depth[pix] = s[k].D;
-      out_alpha[pix] = s[k].Wt;
-      L.n_contrib[pix] = s[k].last;
+      out_color[0 * HW + pix] = s.C0 + s.T * v.bg[0];
+      out_color[1 * HW + pix] = s.C1 + s.T * v.bg[1];
+      out_color[2 * HW + pix] = s.C2 + s.T * v.bg[2];
+      out_depth[pix] = s.D;
+      out_alpha[pix] = s.Wt;
+      L.n_contrib[pix] = s.last;
     }
-    mx = max(mx, s[k].last);
+  } else {
+    // partial sums of this segment; Tend < 0 marks "terminated (or already finished) here"
+    float* sp = segP + (size_t)(ms0 + k) * HGS_SEG_PLANES * HGS_TILE_PIX;
+    sp[0 * 256 + tid] = s.C0;
+    sp[1 * 256 + tid] = s.C1;
+    sp[2 * 256 + tid] = s.C2;
+    sp[3 * 256 + tid] = s.D;
+    sp[4 * 256 + tid] = s.Wt;
+    sp[5 * 256 + tid] = s.done ? -s.T : s.T;
+    sp[6 * 256 + tid] = __uint_as_float(s.last);
   }
   if (STORE && !overflow) {
     // tile-wide max of n_contrib: buckets at or beyond it are skipped by the backward
+    uint32_t mx = s.last;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     if ((tid & 63) == 0 && mx > 0) atomicMax(&L.tile_maxcontrib[t], mx);
@@ -186,15 +294,60 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
 extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
 hgs_k_render_fwd_store(View v, Layout L, const hgs_status* __restrict__ status,
                        const SortRec* __restrict__ recs, float* __restrict__ bstate,
+                       const float* __restrict__ segT, float* __restrict__ segP,
                        float* __restrict__ out_color, float* __restrict__ out_depth,
                        float* __restrict__ out_alpha) {
-  render_fwd_body<true>(v, L, status, recs, bstate, out_color, out_depth, out_alpha);
+  render_fwd_body<true>(v, L, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
 }
 
 extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
 hgs_k_render_fwd_nostore(View v, Layout L, const hgs_status* __restrict__ status,
                          const SortRec* __restrict__ recs, float* __restrict__ bstate,
+                         const float* __restrict__ segT, float* __restrict__ segP,
                          float* __restrict__ out_color, float* __restrict__ out_depth,
                          float* __restrict__ out_alpha) {
-  render_fwd_body<false>(v, L, status, recs, bstate, out_color, out_depth, out_alpha);
+  render_fwd_body<false>(v, L, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
+}
+
+// -------------------------------------------------------------------------- combine
+// One workgroup per tile; only tiles with more than one segment do anything.  Thread = pf.
+extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
+hgs_k_fwd_combine(View v, Layout L, const hgs_status* __restrict__ status,
+                  float* __restrict__ segP, float* __restrict__ out_color,
+                  float* __restrict__ out_depth, float* __restrict__ out_alpha) {
+  if (status->overflow) return;
+  const int t = blockIdx.x;
+  const uint32_t n = L.tile_start[t + 1] - L.tile_start[t];
+  const uint32_t nseg = (n + HGS_SEG - 1) / HGS_SEG;
+  if (nseg <= 1) return;
+  const int tid = threadIdx.x;
+  const uint32_t ms0 = L.tile_msegstart[t];
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, Wt = 0.f, Tf = 1.0f;
+  uint32_t last = 0;
+  bool stopped = false;
+  for (uint32_t k = 0; k < nseg; ++k) {
+    float* sp = segP + (size_t)(ms0 + k) * HGS_SEG_PLANES * HGS_TILE_PIX;
+    const float p0 = sp[0 * 256 + tid], p1 = sp[1 * 256 + tid], p2 = sp[2 * 256 + tid];
+    const float p3 = sp[3 * 256 + tid], p4 = sp[4 * 256 + tid], te = sp[5 * 256 + tid];
+    const uint32_t pl = __float_as_uint(sp[6 * 256 + tid]);
+    // exclusive prefix = what the backward adds to the segment-relative bucket states
+    sp[0 * 256 + tid] = C0; sp[1 * 256 + tid] = C1; sp[2 * 256 + tid] = C2;
+    sp[3 * 256 + tid] = D;  sp[4 * 256 + tid] = Wt;
+    C0 += p0; C1 += p1; C2 += p2; D += p3; Wt += p4;     // later segments add exact zeros once stopped
+    if (!stopped) { Tf = fabsf(te); stopped = te < 0.0f; }
+    last = max(last, pl);
+  }
+  int lx, ly;
+  hgs_fwd_thread_pixel(tid, lx, ly);
+  const int px = (t % v.grid_x) * HGS_TILE + lx, py = (t / v.grid_x) * HGS_TILE + ly;
+  if (px < v.W && py < v.H) {
+    const size_t pix = (size_t)py * v.W + px;
+    const size_t HW = (size_t)v.H * v.W;
+    out_color[0 * HW + pix] = C0 + Tf * v.bg[0];
+    out_color[1 * HW + pix] = C1 + Tf * v.bg[1];
+    out_color[2 * HW + pix] = C2 + Tf * v.bg[2];
+    out_depth[pix] = D;
+    out_alpha[pix] = Wt;
+    L.n_contrib[pix] = last;
+  }
 }
