@@ -321,7 +321,7 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
       static_cast<const char*>(geom) + carve_geom(P, v.H, v.W).status);
   // host status known: exact grid.  Unknown: capacity bound, surplus workgroups exit.
   const uint32_t groups = status ? status->bwd_groups
-                                 : (maybe_entries ? (uint32_t)(cap / 256 + v.T) : 0u);
+                                 : (maybe_entries ? (uint32_t)(cap / HGS_BUCKET + v.T) : 0u);
   float* rows = static_cast<float*>(bwd_scratch);
   HGS_STAGE(0);
   if (groups > 0) {

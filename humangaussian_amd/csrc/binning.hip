@@ -119,7 +119,7 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
       p0[k] = l0; p1[k] = l1; p2[k] = l2; p3[k] = l3;
       l0 += n[k];
       l1 += nb > 0 ? nb - 1 : 0;                               // stored bucket states
-      l2 += (nb + HGS_BWD_WAVES - 1) / HGS_BWD_WAVES;          // backward workgroups
+      l2 += nb;                                                // backward workgroups (1 per bucket)
       l3 += nseg > 1 ? nseg : 0;                               // segment planes of long lists
       mx = max(mx, n[k]);
     }

@@ -111,7 +111,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
  * `status` is a HOST copy of what hgs_forward reported (read after the stream has passed
  * the forward), or NULL: then nothing about the forward's result is needed on the host -
  * the blend backward is launched with the capacity-derived upper bound of workgroups
- * (entry_capacity/256 + tiles) and every kernel reads the device-side status (an
+ * (entry_capacity/64 + tiles) and every kernel reads the device-side status (an
  * overflowed forward yields all-zero gradients).  `entry_capacity` must equal the value
  * given to hgs_forward (it fixes the carve of `bin`), bwd_scratch must hold
  * hgs_bwd_scratch_bytes(num_rendered) - or (entry_capacity) when status is NULL.

@@ -47,7 +47,7 @@ def test_buffer_sizing(lib):
     assert lib.hgs_img_bytes(1024, 1024) == 1024 * 1024 * 4
     b1, b2 = lib.hgs_bin_bytes(1 << 20), lib.hgs_bin_bytes(1 << 21)
     assert b1 >= (1 << 20) * (8 + 48 + 96) and abs(b2 - 2 * b1) <= 65536
-    assert lib.hgs_bin_bytes(0) == 0
+    assert lib.hgs_bin_bytes(0) <= 65536          # only the fixed part of the segment planes
     assert lib.hgs_bwd_scratch_bytes(1000) >= 48000
 
 
