@@ -142,6 +142,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---------------- host/GPU balance (outside the timed region): time the host spends blocked
+    # in the one event wait per forward.  wait ~ 0 means the loop is host-bound.
+    wait_acc = [0.0]
+    _orig_sync = torch.cuda.Event.synchronize
+
+    def _timed_sync(ev):
+        tw = time.perf_counter()
+        _orig_sync(ev)
+        wait_acc[0] += time.perf_counter() - tw
+
+    torch.cuda.Event.synchronize = _timed_sync
+    nhost = 50
+    th = time.perf_counter()
+    for _ in range(nhost):
+        step()
+    torch.cuda.synchronize()
+    th = time.perf_counter() - th
+    torch.cuda.Event.synchronize = _orig_sync
+    host_info = {"step_us": round(th / nhost * 1e6, 1), "event_wait_us": round(wait_acc[0] / nhost * 1e6, 1)}
+
     # ---------------- per-kernel timing (outside the timed region; library-recorded events)
     nprof = 20
     fwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
@@ -237,6 +257,7 @@ def main():
                                   "achieved": path_bytes / (gpu_us * 1e-6) / 1e9,
                                   "frac": path_bytes / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
             "stage_us": stage_us,
+            "host": host_info,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -127,6 +127,11 @@ View make_view(const hgs_settings* s, int P, int M, int64_t cap, int max_tile_hi
   v.nwg = (v.nblk + v.cpw - 1) / v.cpw;
   v.entry_capacity = (uint32_t)(cap < 0 ? 0 : (cap > 0xffffffffll ? 0xffffffffll : cap));
   v.max_tile_hint = max_tile_hint;
+  // list-parallel blending pays for the long tail of tile lists only (same-box sweep, 100k
+  // Gaussians / lists to 1.6k: 83 us with SEG 256 + THRESH 1024, 88 us unsegmented, 91-97 us with
+  // every list cut), so only lists longer than HGS_SEG_THRESH are segmented - a pure function
+  // of the list length; a hint that rules such lists out merely skips the empty launches
+  v.seg_off = (max_tile_hint > 0 && max_tile_hint <= HGS_SEG_THRESH) ? 1 : 0;
   return v;
 }
 
@@ -265,8 +270,9 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
   HGS_STAGE(4);
   // list-parallel blend: segment transmittances, segments, combine (grids are capacity
   // bounds; surplus workgroups exit on the device-side totals)
-  const unsigned seg_bound = (unsigned)(entry_capacity / HGS_SEG + 1);
-  if (entry_capacity >= HGS_SEG) {
+  const bool use_seg = !v.seg_off && entry_capacity > HGS_SEG_THRESH;
+  const unsigned seg_bound = use_seg ? (unsigned)(entry_capacity / HGS_SEG + 1) : 0u;
+  if (use_seg) {
     hipLaunchKernelGGL(hgs_k_fwd_segT, dim3(2 * seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.recs, L.segT);
     HGS_LAUNCH_CHECK();
@@ -280,7 +286,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                        stream, v, L, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color,
                        out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
-  if (entry_capacity >= HGS_SEG) {
+  if (use_seg) {
     hipLaunchKernelGGL(hgs_k_fwd_combine, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.segP, out_color, out_depth, out_alpha);
     HGS_LAUNCH_CHECK();

@@ -115,7 +115,7 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
       const uint32_t nb = (n[k] + HGS_BUCKET - 1) / HGS_BUCKET;
-      const uint32_t nseg = (n[k] + HGS_SEG - 1) / HGS_SEG;
+      const uint32_t nseg = hgs_nseg(n[k]);
       p0[k] = l0; p1[k] = l1; p2[k] = l2; p3[k] = l3;
       l0 += n[k];
       l1 += nb > 0 ? nb - 1 : 0;                               // stored bucket states
@@ -242,6 +242,7 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
   }
   // (d) forward work items: one per segment of HGS_SEG entries, in tile_order (heavy first);
   // pos_segstart = exclusive prefix of max(1, nseg) over tile_order positions
+  if (v.seg_off) return;                           // one work item per tile: tile_order is the list
   __threadfence_block();
   __syncthreads();
   if (tid == 0) carry_s = 0;
@@ -252,7 +253,7 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
     if (pos < v.T) {
       const uint32_t t = L.tile_order[pos];
       const uint32_t n = L.tile_start[t + 1] - L.tile_start[t];
-      ns = max(1u, (n + HGS_SEG - 1) / HGS_SEG);
+      ns = hgs_nseg(n);
     }
     uint32_t total;
     const uint32_t ex1 = hgs_block_excl_scan<SCAN_NT>(ns, wtot, total);

@@ -29,9 +29,9 @@
 #define HGS_BUCKET 64          // entries per backward bucket (= one wave)
 #define HGS_BWD_WAVES 4        // buckets per backward workgroup
 #define HGS_ROW_GROUPS 4       // histogram row groups scanned in parallel by hgs_k_colscan
-#ifndef HGS_SEG
-#define HGS_SEG 512            // entries per forward segment (list-parallel blend), multiple of 64
-#endif
+#define HGS_SEG 256            // entries per forward segment (list-parallel blend), multiple of 64
+#define HGS_SEG_THRESH 1024    // only tile lists longer than this are cut into segments: short
+                               // lists blend faster in one piece (measured)
 #define HGS_SEG_PLANES 7       // per-segment pixel planes: C0 C1 C2 D W Tend(signed) last(bits)
 #define HGS_NEAR_Z 0.2f
 #define HGS_ALPHA_MIN (1.0f / 255.0f)
@@ -96,9 +96,16 @@ struct View {            // per-call constants, passed by value to every kernel
   int32_t cpw, nwg, lds_bins;   // chunks per binning workgroup, #binning workgroups, LDS path?
   uint32_t entry_capacity;
   int32_t max_tile_hint;        // >0: caller promises no tile list is longer (else overflow bit 2)
+  int32_t seg_off;              // 1: the caller's hint proves no list exceeds HGS_SEG_THRESH
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// number of forward segments of a tile list of n entries (a pure function of n, so results do
+// not depend on hints or call history)
+__host__ __device__ __forceinline__ uint32_t hgs_nseg(uint32_t n) {
+  return n > HGS_SEG_THRESH ? (n + HGS_SEG - 1) / HGS_SEG : 1u;
+}
 
 // Forward pixel ownership: four waves per tile, wave w owns the 8x8 quadrant (w&1, w>>1),
 // lane l is (l&7, l>>3) inside it.  `pf` in [0,256) (= forward thread index) is the index

@@ -103,7 +103,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     float d = bs[4 * 256 + tid], wt = bs[5 * 256 + tid];
     // long lists are blended in segments of HGS_SEG entries: C, D, W are relative to the segment
     // start, the combine kernel left the segment's base (exclusive prefix) in segP
-    const uint32_t kseg = q0 / HGS_SEG;
+    const uint32_t kseg = (hgs_nseg(n) > 1) ? q0 / HGS_SEG : 0u;
     if (kseg > 0) {
       const float* base = segP + (size_t)(L.tile_msegstart[t] + kseg) * HGS_SEG_PLANES * HGS_TILE_PIX;
       c0 += base[0 * 256 + tid]; c1 += base[1 * 256 + tid]; c2 += base[2 * 256 + tid];

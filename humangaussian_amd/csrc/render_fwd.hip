@@ -173,7 +173,7 @@ hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
   const uint32_t k = ms - L.tile_msegstart[t];
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_start[t + 1] - start;
-  const uint32_t nseg = (n + HGS_SEG - 1) / HGS_SEG;
+  const uint32_t nseg = hgs_nseg(n);
   if (k + 1 >= nseg) return;                       // the last segment has no successor
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,6 +210,9 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
   if (overflow) {                                   // lists are invalid: background only
     if ((int)blockIdx.x >= v.T) return;
     t = (int)blockIdx.x;
+  } else if (v.seg_off) {                            // one workgroup per tile, heavy first
+    if ((int)blockIdx.x >= v.T) return;
+    t = (int)L.tile_order[blockIdx.x];
   } else {
     const uint32_t g = blockIdx.x;
     if (g >= L.pos_segstart[v.T]) return;           // surplus workgroup of the bounded grid
@@ -229,7 +232,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
 
   const uint32_t start = overflow ? 0u : L.tile_start[t];
   const uint32_t n = overflow ? 0u : (L.tile_start[t + 1] - start);
-  const uint32_t nseg = max(1u, (n + HGS_SEG - 1) / HGS_SEG);
+  const uint32_t nseg = hgs_nseg(n);
   const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
   const uint32_t ms0 = (nseg > 1) ? L.tile_msegstart[t] : 0u;
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
@@ -242,7 +245,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
   s.done = !inside || (s.T < HGS_T_EPS);
 
   walk_segment(
-      recs, k * HGS_SEG, min(n, (k + 1) * HGS_SEG), 1u << (28 + w), s_rec[w], lane,
+      recs, nseg > 1 ? k * HGS_SEG : 0u, nseg > 1 ? min(n, (k + 1) * HGS_SEG) : n, 1u << (28 + w), s_rec[w], lane,
       [&](uint32_t j0) {
         if (STORE && j0 > 0) {
           float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
@@ -318,7 +321,7 @@ hgs_k_fwd_combine(View v, Layout L, const hgs_status* __restrict__ status,
   if (status->overflow) return;
   const int t = blockIdx.x;
   const uint32_t n = L.tile_start[t + 1] - L.tile_start[t];
-  const uint32_t nseg = (n + HGS_SEG - 1) / HGS_SEG;
+  const uint32_t nseg = hgs_nseg(n);
   if (nseg <= 1) return;
   const int tid = threadIdx.x;
   const uint32_t ms0 = L.tile_msegstart[t];

@@ -12,6 +12,7 @@ There is no CPU path: non-HIP tensors raise.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from typing import NamedTuple, Optional
@@ -56,6 +57,8 @@ class _DeviceState:
         self.max_R = 0
         self.max_tile = 0
         self.status_ring = torch.zeros(self.RING, 8, dtype=torch.int32).pin_memory()
+        self.status_np = self.status_ring.numpy()          # host view of the same pinned words
+        self.status_ptr = [self.status_ring[i].data_ptr() for i in range(self.RING)]
         # recorded by the library right behind the status copy (after the scan stage)
         self.status_event = torch.cuda.Event()
         self.status_event.record()
@@ -75,6 +78,7 @@ class _DeviceState:
 
 
 _device_state: dict = {}
+_NULL_CTX = contextlib.nullcontext()
 _async_mode = [os.environ.get("HGS_ASYNC", "0") not in ("", "0")]
 
 
@@ -163,7 +167,24 @@ def _round_capacity(n: int) -> int:
 
 
 def _read_status(st: _DeviceState, slot: int):
-    return [int(x) & 0xFFFFFFFF for x in st.status_ring[slot].tolist()]
+    return [x & 0xFFFFFFFF for x in st.status_np[slot].tolist()]
+
+
+_size_cache: dict = {}
+
+
+def _sizes(lib, P: int, H: int, W: int, cap: int):
+    """(geom, img, bin, scratch) byte sizes, each rounded to 256 B so the four regions can be
+    carved from one allocation.  Cached: four ctypes calls per forward add up."""
+    key = (P, H, W, cap)
+    r = _size_cache.get(key)
+    if r is None:
+        if len(_size_cache) > 256:
+            _size_cache.clear()
+        al = lambda n: (int(n) + 255) & ~255  # noqa: E731
+        r = _size_cache[key] = (al(lib.hgs_geom_bytes(P, H, W)), al(lib.hgs_img_bytes(H, W)),
+                                al(lib.hgs_bin_bytes(cap)), al(lib.hgs_bwd_scratch_bytes(cap)))
+    return r
 
 
 def _drain_pending(st: _DeviceState, block: bool = False):
@@ -207,7 +228,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
 
         keep: list = []
-        with torch.cuda.device(device):
+        # only switch the current device when it is not already the tensors' device
+        switch = torch.cuda.current_device() != (device.index if device.index is not None else 0)
+        guard = torch.cuda.device(device) if switch else _NULL_CTX
+        with guard:
             settings = _make_settings(raster_settings, device, keep)
             m3 = _f32c(means3D, device)
             sh_ = _opt(sh); cp_ = _opt(colors_precomp)
@@ -222,16 +246,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             if sh_ is not None and (sh_.dim() != 3 or sh_.shape[0] != P or sh_.shape[2] != 3):
                 raise RuntimeError("shs must have dimensions (num_points, M, 3)")
 
-            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)  # noqa: E731
-            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=device)  # noqa: E731
-            color, depth, alpha = new(3, H, W), new(1, H, W), new(1, H, W)
+            f32 = torch.float32
+            color = torch.empty((3, H, W), dtype=f32, device=device)
+            depth = torch.empty((1, H, W), dtype=f32, device=device)
+            alpha = torch.empty((1, H, W), dtype=f32, device=device)
             radii = torch.empty((P,), dtype=torch.int32, device=device)
-            geom = u8(lib.hgs_geom_bytes(P, H, W))
-            img = u8(lib.hgs_img_bytes(H, W))
 
             st = _state(device)
-            stream = torch.cuda.current_stream(device)
-            _drain_pending(st)
+            stream_h = torch.cuda.current_stream(device).cuda_stream
+            if st.pending:
+                _drain_pending(st)
             go_async = bool(_async_mode[0] and want_grad and P > 0 and st.synced_calls >= 2)
             if go_async:
                 cap = max(st.capacity, _round_capacity(2 * st.max_R))
@@ -239,19 +263,28 @@ class _RasterizeGaussians(torch.autograd.Function):
             else:
                 cap = max(st.capacity, _round_capacity(4 * P)) if P > 0 else 0
                 hint = st.tile_hint
+            # one allocation for the four opaque regions [geom | img | bin | backward rows]
+            # (the fork keeps three such byte tensors for its backward); a capacity retry
+            # re-allocates only the last two.
+            g_sz, i_sz, b_sz, s_sz = _sizes(lib, P, H, W, cap)
+            work = torch.empty(g_sz + i_sz + b_sz + (s_sz if want_grad else 0), dtype=torch.uint8,
+                               device=device)
+            base = work.data_ptr()
+            geom_p, img_p, bin_p, scr_p = base, base + g_sz, base + g_sz + i_sz, base + g_sz + i_sz + b_sz
+            work2 = None
             status = None
             bwd = None
+            vp = ctypes.c_void_p
             for _ in range(4):
-                binbuf = u8(lib.hgs_bin_bytes(cap))
                 slot = st.next_slot()
                 rc = lib.hgs_forward(
                     ctypes.byref(settings), P, M, _ptr(m3), _ptr(sh_), _ptr(cp_), _ptr(op_),
                     _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(color), _ptr(depth), _ptr(alpha),
-                    _ptr(radii), _ptr(geom), _ptr(binbuf), cap, _ptr(img),
-                    1 if want_grad else 0, hint, ctypes.c_void_p(st.status_ring[slot].data_ptr()),
+                    _ptr(radii), vp(geom_p), vp(bin_p), cap, vp(img_p),
+                    1 if want_grad else 0, hint, vp(st.status_ptr[slot]),
                     1,      # torch pinned memory is device-mapped on ROCm: direct kernel store
-                    None if go_async else ctypes.c_void_p(st.status_event.cuda_event),
-                    _stage_events["fwd"], ctypes.c_void_p(stream.cuda_stream))
+                    None if go_async else vp(st.status_event.cuda_event),
+                    _stage_events["fwd"], vp(stream_h))
                 if rc == -2:
                     raise RuntimeError("inconsistent optional inputs (shs/colors_precomp, "
                                        "scales+rotations/cov3D_precomp)")
@@ -259,6 +292,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 # Host work that does not depend on the result runs HERE, while the GPU is
                 # busy with the forward: everything the backward call will need.
                 if want_grad and bwd is None:
+                    new = lambda *shape: torch.empty(shape, dtype=f32, device=device)  # noqa: E731
                     bwd = dict(
                         d_means3D=new(P, 3), d_means2D=new(P, 3), d_opac=new(*opacities.shape),
                         d_sh=new(P, M, 3) if sh_ is not None else None,
@@ -266,11 +300,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                         d_sc=new(P, 3) if sc_ is not None else None,
                         d_ro=new(P, 4) if sc_ is not None else None,
                         d_cv=new(P, 6) if cv_ is not None else None,
-                        settings=settings, keep=keep, stream=stream)
+                        settings=settings, keep=keep)
                 if go_async:
                     p = _Pending()
                     p.event, p.slot, p.cap, p.hint = torch.cuda.Event(), slot, cap, hint
-                    p.event.record(stream)
+                    p.event.record()
                     st.pending.append(p)
                     if len(st.pending) >= st.RING - 1:     # never let the ring wrap
                         _drain_pending(st, block=True)
@@ -284,6 +318,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                     break
                 if status[4] & 1:                     # R exceeded the capacity: grow, re-run
                     cap = _round_capacity(int(status[0] * 1.25) + 1)
+                    _, _, b_sz, s_sz = _sizes(lib, P, H, W, cap)
+                    work2 = torch.empty(b_sz + (s_sz if want_grad else 0), dtype=torch.uint8,
+                                        device=device)
+                    bin_p = work2.data_ptr()
+                    scr_p = bin_p + b_sz
                 if status[4] & 2:                     # a tile list outgrew the hint
                     hint = 0
             else:
@@ -295,7 +334,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 st.tile_hint = max(1024, int(status[6] * 1.5) + 64)
             if want_grad:
                 bwd["cap"] = cap
-                bwd["scratch"] = u8(lib.hgs_bwd_scratch_bytes(cap if status is None else status[0]))
+                bwd["work"] = (work, work2)           # keeps the regions alive until backward
+                bwd["ptrs"] = (geom_p, bin_p, img_p, scr_p)
                 if status is not None:
                     hs = HgsStatus()
                     (hs.num_rendered, hs.active_tiles, hs.num_buckets, hs.bwd_groups,
@@ -306,42 +346,46 @@ class _RasterizeGaussians(torch.autograd.Function):
                     bwd["status"] = None
 
         ctx.P, ctx.M = P, M
-        ctx.has = (sh_ is not None, cp_ is not None, sc_ is not None, cv_ is not None)
         if want_grad:
             ctx.bwd = bwd
-            ctx.save_for_backward(m3, sh_ if sh_ is not None else m3.new_empty(0),
-                                  cp_ if cp_ is not None else m3.new_empty(0), op_,
-                                  sc_ if sc_ is not None else m3.new_empty(0),
-                                  ro_ if ro_ is not None else m3.new_empty(0),
-                                  cv_ if cv_ is not None else m3.new_empty(0),
-                                  radii, color, depth, alpha, geom, binbuf, img)
+            # inputs and outputs go through save_for_backward (version checks, no reference
+            # cycle through the outputs); opaque work buffers ride in ctx.bwd
+            opt = [t for t in (sh_, cp_, sc_, ro_, cv_) if t is not None]
+            ctx.has = (sh_ is not None, cp_ is not None, sc_ is not None, cv_ is not None)
+            ctx.save_for_backward(m3, op_, radii, color, depth, alpha, *opt)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         lib = _lib.load()
-        (m3, sh_, cp_, op_, sc_, ro_, cv_, radii, color, depth, alpha, geom, binbuf,
-         img) = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        m3, op_, radii, color, depth, alpha = saved[:6]
         has_sh, has_cp, has_sr, has_cv = ctx.has
+        it = iter(saved[6:])
+        sh_ = next(it) if has_sh else None
+        cp_ = next(it) if has_cp else None
+        sc_ = next(it) if has_sr else None
+        ro_ = next(it) if has_sr else None
+        cv_ = next(it) if has_cv else None
         device = m3.device
         P, M = ctx.P, ctx.M
         b = ctx.bwd
         gc = None if grad_color is None else _f32c(grad_color, device)
         gd = None if grad_depth is None else _f32c(grad_depth, device)
         ga = None if grad_alpha is None else _f32c(grad_alpha, device)
-        stream = torch.cuda.current_stream(device)
         hs = b["status"]
+        geom_p, bin_p, img_p, scr_p = b["ptrs"]
+        vp = ctypes.c_void_p
         rc = lib.hgs_backward(
-            ctypes.byref(b["settings"]), P, M, _ptr(m3), _ptr(sh_ if has_sh else None),
-            _ptr(cp_ if has_cp else None), _ptr(op_), _ptr(sc_ if has_sr else None),
-            _ptr(ro_ if has_sr else None), _ptr(cv_ if has_cv else None), _ptr(radii),
+            ctypes.byref(b["settings"]), P, M, _ptr(m3), _ptr(sh_), _ptr(cp_), _ptr(op_),
+            _ptr(sc_), _ptr(ro_), _ptr(cv_), _ptr(radii),
             _ptr(color), _ptr(depth), _ptr(alpha), _ptr(gc), _ptr(gd), _ptr(ga),
-            _ptr(geom), _ptr(binbuf), _ptr(img), None if hs is None else ctypes.byref(hs),
-            b["cap"], _ptr(b["scratch"]),
+            vp(geom_p), vp(bin_p), vp(img_p), None if hs is None else ctypes.byref(hs),
+            b["cap"], vp(scr_p),
             _ptr(b["d_means3D"]), _ptr(b["d_means2D"]), _ptr(b["d_sh"]), _ptr(b["d_cp"]),
             _ptr(b["d_opac"]), _ptr(b["d_sc"]), _ptr(b["d_ro"]), _ptr(b["d_cv"]),
-            _stage_events["bwd"], ctypes.c_void_p(stream.cuda_stream))
+            _stage_events["bwd"], vp(torch.cuda.current_stream(device).cuda_stream))
         _check(rc, "hgs_backward")
         ctx.bwd = None
         return (b["d_means3D"], b["d_means2D"], b["d_sh"], b["d_cp"], b["d_opac"], b["d_sc"],
