@@ -1,8 +1,12 @@
-"""Build + load libhgs_rast.so (the C-ABI HIP library, include/hgs_rast.h) through ctypes.
+"""Build + load the two in-tree shared objects:
 
-The library is built IN-TREE (humangaussian_amd/libhgs_rast.so) by one hipcc command for
-gfx950; there is no JIT cache and no fallback: if the shared object is missing or does not
-export the ABI, importing the rasterizer fails loudly.
+  libhgs_rast.so   the C-ABI HIP library (include/hgs_rast.h), hipcc for gfx950; bound here
+                   through ctypes (`load()`: sizing functions, raw-ABI tests)
+  _hgs_torch.so    the torch binding above it (csrc/torch_binding.cpp, g++, no device code):
+                   the C++ autograd node the Python API calls (`load_binding()`)
+
+There is no JIT cache and no fallback: if a shared object is missing or does not export the
+ABI, importing the rasterizer fails loudly.
 """
 from __future__ import annotations
 
@@ -57,8 +61,12 @@ EXPORTS = {
 }
 
 
+BINDING_SRC = "torch_binding.cpp"
+BINDING_PATH = os.path.join(_PKG_DIR, "_hgs_torch.so")
+
+
 def sources():
-    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC))]
+    return [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f != BINDING_SRC]
 
 
 def needs_build() -> bool:
@@ -104,6 +112,68 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for o in objs:
         os.remove(o)
     return target
+
+
+def binding_needs_build() -> bool:
+    if not os.path.exists(BINDING_PATH):
+        return True
+    mt = os.path.getmtime(BINDING_PATH)
+    deps = [os.path.join(_CSRC, BINDING_SRC), os.path.join(_PKG_DIR, "..", "include", "hgs_rast.h")]
+    return any(os.path.getmtime(s) > mt for s in deps)
+
+
+def build_binding(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/torch_binding.cpp with g++ against this interpreter's torch and link it to
+    libhgs_rast.so (rpath $ORIGIN).  Host code only: hipcc is not involved."""
+    if not force and not binding_needs_build():
+        return BINDING_PATH
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found: cannot build _hgs_torch.so")
+    tlib = ce.library_paths()[0]
+    rocm_inc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_hgs_torch",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm_inc}", f"-I{sysconfig.get_paths()['include']}"]
+    cmd += [os.path.join(_CSRC, BINDING_SRC), "-o", BINDING_PATH + ".tmp", f"-L{tlib}", "-lc10", "-lc10_hip",
+            "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", f"-L{_PKG_DIR}", "-lhgs_rast",
+            f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed for torch_binding.cpp:\n" + res.stdout + res.stderr)
+    os.replace(BINDING_PATH + ".tmp", BINDING_PATH)
+    return BINDING_PATH
+
+
+_binding = None
+
+
+def load_binding():
+    """Import humangaussian_amd/_hgs_torch.so (the C++ autograd node).  Fails loudly."""
+    global _binding
+    if _binding is not None:
+        return _binding
+    load()                                   # ABI check of libhgs_rast.so first
+    if not os.path.exists(BINDING_PATH):
+        raise ImportError(
+            f"{BINDING_PATH} is missing: the torch binding has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback for the product path.")
+    import importlib.util
+    import torch  # noqa: F401  (libtorch must be loaded before the extension)
+    spec = importlib.util.spec_from_file_location("humangaussian_amd._hgs_torch", BINDING_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if mod.abi_version() != ABI_VERSION:
+        raise ImportError(f"{BINDING_PATH}: linked against ABI {mod.abi_version()} != {ABI_VERSION}")
+    _binding = mod
+    return mod
 
 
 _lib = None

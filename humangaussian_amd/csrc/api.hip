@@ -225,7 +225,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256, HGS_ROW_GROUPS), dim3(256), 0, stream, v, L);
     HGS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), 0, stream, v, L, status_dev,
+  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), v.T <= 7168 ? (size_t)v.T * 8 : 0, stream, v, L, status_dev,
                      status_host_mapped ? status_host : nullptr);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
