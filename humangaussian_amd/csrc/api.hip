@@ -56,7 +56,7 @@ GeomCarve carve_geom(int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, bstate, segT, segP, total; };
+struct BinCarve { size_t keys, recs, bstate, segT, segP, wg_tile, total; };
 
 BinCarve carve_bin(int64_t cap) {
   BinCarve c;
@@ -69,6 +69,7 @@ BinCarve carve_bin(int64_t cap) {
   const size_t nms = 2 * (C / HGS_SEG) + 2;      // bound on segments of multi-segment tiles
   c.segT = take(nms * HGS_TILE_PIX * sizeof(float));
   c.segP = take(nms * HGS_SEG_PLANES * HGS_TILE_PIX * sizeof(float));
+  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 4);   // one backward workgroup per bucket: <= R/64 + active tiles
   c.total = off;
   return c;
 }
@@ -97,6 +98,7 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
   L.segT = bp ? reinterpret_cast<float*>(bp + b.segT) : nullptr;
   L.segP = bp ? reinterpret_cast<float*>(bp + b.segP) : nullptr;
+  L.wg_tile = bp ? reinterpret_cast<uint32_t*>(bp + b.wg_tile) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;
 }

@@ -75,6 +75,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* tile_maxcontrib;
   uint32_t* tile_msegstart;   // [T+1] prefix of (nseg > 1 ? nseg : 0): index of a tile's segment planes
   uint32_t* pos_segstart;     // [T+1] prefix of nseg over tile_order positions: forward work items
+  uint32_t* wg_tile;          // [<= C + C/64] tile of every backward workgroup (written by the forward)
   uint32_t* hist;          // [nwg][T] per-workgroup tile histograms -> exclusive bases
   uint32_t* tile_grp;      // [HGS_ROW_GROUPS][T] row-group totals -> absolute group bases
   unsigned long long* keys;

@@ -16,20 +16,28 @@
 //       F'  = out_color . g_C + out_depth g_D + out_alpha g_A   (= total + background term)
 //   dL/dalpha_j = T_j S_j - (F' - F_j) / (1 - alpha_j)
 // which is algebraically upstream's back-to-front recurrence including the background term.
-// The ten per-pixel gradient terms of a record are summed over the wave's 64 pixels with a
-// 28-instruction reduce-scatter (wave_reduce.h), dropped into LDS per (entry, quadrant), and
-// the four quadrant partials are added in fixed order: no atomics, bitwise reproducible.
-// One 48 B gradient row per entry goes to HBM; hgs_k_preprocess_bwd sums a Gaussian's rows.
+// The ten sums over the wave's 64 pixels that a record needs ARE a dense contraction (two
+// per-(record, pixel) quantities against per-pixel constants, see the operand-A comment below),
+// so they run on the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32), 8 records per batch,
+// operands transposed through a wave-private LDS stage.  This replaced a 28-instruction
+// VALU/DPP reduce-scatter per record (82 -> ~40 VALU instructions per kept record).  Results
+// drop into LDS per (entry, quadrant) and the four quadrant partials are added in fixed order:
+// no atomics, bitwise reproducible.  One 48 B gradient row per entry goes to HBM;
+// hgs_k_preprocess_bwd sums a Gaussian's rows.
 //
-// Roofline: instruction issue (~85 instructions per kept record per wave); HBM traffic per
-// entry: 4 x 48 B record reads (L2-served), 24 B/pixel/bucket state in, 48 B row out.
+// Roofline: VALU issue (~40 instructions per kept record per wave) with the MFMA pipe running
+// beside it (2 x 32 cycles per record); HBM traffic per entry: 4 x 48 B record reads
+// (L2-served), 24 B/pixel/bucket state in, 48 B row out.
 //
 // This file is its own translation unit (built with -fno-slp-vectorize: the kernel is
 // throughput-bound, where v_pk_* packing only adds register moves).
 #include "hgs_common.h"
-#include "wave_reduce.h"
 
-#define HGS_BWD_UNROLL 2
+#define HGS_BWD_BATCH 8                  // records per MFMA batch (8 records x {k, wgt} = 16 columns)
+#define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
+#define HGS_PART_FLOATS 10               // sums per (entry, quadrant)
+
+typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
 
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
@@ -39,18 +47,16 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                  const float* __restrict__ dL_dalpha, float* __restrict__ grad_rows) {
-  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + HGS_BWD_UNROLL)];
-  __shared__ float s_part[HGS_BUCKET + 1][4][12];    // [slot][quadrant][value]; slot 64 = sink of the pads
+  // 12288 + 10240 + 17408 B = 39936 B: four workgroups per CU (160 KB of LDS)
+  __shared__ float4 s_rec[4][3 * HGS_BUCKET];
+  __shared__ __attribute__((aligned(16))) float s_part[HGS_BUCKET][4][HGS_PART_FLOATS];   // [slot][quadrant][value]
+  __shared__ __attribute__((aligned(16))) float s_stage[4][16 * HGS_STAGE_STRIDE];   // per wave: 16 columns x 64 pixels
 
-  // ---- which (tile, bucket) is this workgroup?  binary search the bucket prefix
+  // ---- which (tile, bucket) is this workgroup?  The forward left the tile of every backward
+  // workgroup in wg_tile (a binary search over tile_wgstart here cost 12 dependent loads).
   const uint32_t g = blockIdx.x;
   if (status->overflow || g >= L.tile_wgstart[v.T]) return;   // surplus workgroup
-  int lo = 0, hi = v.T;                       // invariant: wgstart[lo] <= g < wgstart[hi]
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (L.tile_wgstart[mid] <= g) lo = mid; else hi = mid;
-  }
-  const int t = lo;
+  const int t = (int)L.wg_tile[g];
   const uint32_t b = g - L.tile_wgstart[t];
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_start[t + 1] - start;
@@ -70,9 +76,10 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 
   // zero the per-(entry, quadrant) partials: quadrants that cull an entry leave zeros
   {
-    float4* z = reinterpret_cast<float4*>(&s_part[0][0][0]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) z[k * 256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* z = reinterpret_cast<float4*>(&s_part[0][0][0]);       // 640 float4
+    z[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    z[256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 128) z[512 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   // ---- this thread's pixel (same ownership as the forward: pf = tid)
@@ -130,62 +137,139 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     srec[3 * pos + 1] = c1;
     srec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float((uint32_t)lane));   // slot in bucket
   }
-  if (lane < HGS_BWD_UNROLL) {                       // pad records: opacity 0 (never active),
-    srec[3 * (cnt + lane) + 0] = zero4;              // their (zero) sums go to the sink slot
-    srec[3 * (cnt + lane) + 1] = zero4;
-    srec[3 * (cnt + lane) + 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float((uint32_t)HGS_BUCKET));
+
+  // ---- MFMA operand A: the per-pixel basis, fixed for the whole bucket.
+  // The ten sums over the quadrant's 64 pixels that a record needs are contractions of two
+  // per-(record, pixel) quantities with per-pixel constants:
+  //   k   (= op G dL/dalpha)  against  1, u, v, u^2, uv, v^2     (u, v = pixel - quadrant centre)
+  //   wgt (= alpha T)         against  g_C0, g_C1, g_C2, g_D
+  // dx = a - u, dy = b - v with (a, b) = mean - quadrant centre, so sum k dx^2 etc. follow from
+  // the six moments.  One v_mfma_f32_16x16x4_f32 chain per batch of 8 records computes
+  //   D[m][n] = sum_p A[m][p] B[p][n],  columns n < 8: k of record n, n >= 8: wgt of record n-8,
+  // rows m < 6: moment basis, rows 6..9: pixel gradients (the cross blocks are not used).
+  // Lane l supplies A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; instruction
+  // i = 4c + r contracts pixels p = 16c + 4(l >> 4) + r, so a lane fetches its four B values of
+  // a c-group with one 16 B LDS read.
+  float* __restrict__ stage = s_stage[w];
+  const int mrow = lane & 15, kk = lane >> 4;
+  {
+    // every lane writes ITS pixel's ten basis values as one column of the stage; every lane then
+    // reads the row it supplies to the MFMA (row 10 = zeros for the six unused rows of A)
+    const float ub = (float)(lane & 7) - 3.5f, vb = (float)(lane >> 3) - 3.5f;
+    stage[0 * HGS_STAGE_STRIDE + lane] = 1.0f;
+    stage[1 * HGS_STAGE_STRIDE + lane] = ub;
+    stage[2 * HGS_STAGE_STRIDE + lane] = vb;
+    stage[3 * HGS_STAGE_STRIDE + lane] = ub * ub;
+    stage[4 * HGS_STAGE_STRIDE + lane] = ub * vb;
+    stage[5 * HGS_STAGE_STRIDE + lane] = vb * vb;
+    stage[6 * HGS_STAGE_STRIDE + lane] = g0;
+    stage[7 * HGS_STAGE_STRIDE + lane] = g1;
+    stage[8 * HGS_STAGE_STRIDE + lane] = g2;
+    stage[9 * HGS_STAGE_STRIDE + lane] = gd;
+    stage[10 * HGS_STAGE_STRIDE + lane] = 0.0f;
   }
-  __syncthreads();                                   // s_part zeroed, s_rec ready
-
-  const int row16 = lane >> 4;                       // DPP row of this lane
-  const bool writer = (lane & 15) == 0;
-  const int v0 = hgsred::slot_of(0, row16), v1 = hgsred::slot_of(1, row16), v2 = hgsred::slot_of(2, row16);
-
-  for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_BWD_UNROLL) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float Areg[16];
+  {
+    const float* arow = stage + min(mrow, 10) * HGS_STAGE_STRIDE + 4 * kk;
 #pragma unroll
-    for (int u = 0; u < HGS_BWD_UNROLL; ++u) {
-      const float4 r0 = srec[3 * (k0 + u) + 0];      // mx my qa qb
-      const float4 r1 = srec[3 * (k0 + u) + 1];      // qc op r g
-      const float4 r2 = srec[3 * (k0 + u) + 2];      // b depth entry slot
-      const uint32_t slot = __float_as_uint(r2.w);
-      // same dx/dy expressions as the forward so skip decisions agree
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      float G, alpha, m2, m3;
-      const bool keep = hgs_eval_alpha(dx, dy, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
-      const bool act = keep && (q0 + slot < nc);
-      const float am = act ? r1.y * G : 0.0f;        // un-clamped alpha (= op*G), 0 when inactive
-      const float a = fminf(HGS_ALPHA_MAX, am);
-      const float wgt = a * T;
-      const float S = __builtin_fmaf(r1.z, g0, __builtin_fmaf(r1.w, g1, __builtin_fmaf(r2.x, g2,
-                      __builtin_fmaf(r2.y, gd, ga))));
-      F = __builtin_fmaf(wgt, S, F);
-      const float om = 1.0f - a;
-      // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
-      const float dLda = __builtin_fmaf(T, S, -((fp - F) * __builtin_amdgcn_rcpf(om)));
-      T *= om;
-      const float k = am * dLda;                     // dL/dG * G  (= op * G * dL/dalpha)
-      const float kdx = k * dx, kdy = k * dy;
-      float x[10], o[3];
-      // d(p2)/d(dx) = 2 qa dx + qb dy = m2 + qa dx ;  d(p2)/d(dy) = qb dx + 2 qc dy
-      x[0] = k * __builtin_fmaf(r0.z, dx, m2);
-      x[1] = k * __builtin_fmaf(r0.w, dx, m3 + m3);
-      x[2] = kdx * dx;
-      x[3] = kdx * dy;
-      x[4] = kdy * dy;
-      x[5] = k;
-      x[6] = wgt * g0;
-      x[7] = wgt * g1;
-      x[8] = wgt * g2;
-      x[9] = wgt * gd;
-      hgsred::reduce10(x, o);
-      if (writer) {
-        float* dst = &s_part[slot][w][0];
-        dst[v0] = o[0];
-        dst[v1] = o[1];
-        if (v2 >= 0) dst[v2] = o[2];
-      }
+    for (int c = 0; c < 4; ++c) {
+      const float4 aq = *reinterpret_cast<const float4*>(arow + 16 * c);
+      Areg[4 * c + 0] = aq.x; Areg[4 * c + 1] = aq.y; Areg[4 * c + 2] = aq.z; Areg[4 * c + 3] = aq.w;
     }
   }
+  const float cxq = (float)((t % v.grid_x) * HGS_TILE + ((w & 1) << 3)) + 3.5f;
+  const float cyq = (float)((t / v.grid_x) * HGS_TILE + ((w >> 1) << 3)) + 3.5f;
+  __syncthreads();                                   // s_part zeroed, s_rec ready (also orders the A reads
+                                                     // before the first batch overwrites the stage)
+
+  // Finishes a batch: D layout is lane l -> rows 4 (l >> 4) + r (r = register) of column l & 15.
+  auto finish = [&](const hgs_f32x4& a0, const hgs_f32x4& a1, uint32_t k0, uint32_t nrec) {
+    const float d0 = a0[0] + a1[0], d1 = a0[1] + a1[1], d2 = a0[2] + a1[2], d3 = a0[3] + a1[3];
+    // rows 4, 5 (uv, v^2 moments) of column n live in lane 16 + n: bring them to lane n
+    const float k11 = __shfl(d0, (lane + 16) & 63, 64), k02 = __shfl(d1, (lane + 16) & 63, 64);
+    const uint32_t rsel = (uint32_t)lane & 7u;       // record of the batch this lane finishes
+    if (rsel >= nrec) return;
+    const float4 q0r = srec[3 * (k0 + rsel) + 0];
+    const float4 q1r = srec[3 * (k0 + rsel) + 1];
+    const uint32_t slot_l = __float_as_uint(srec[3 * (k0 + rsel) + 2].w);
+    float* dst = &s_part[slot_l][w][0];
+    if (lane < 8) {
+      const float a = q0r.x - cxq, bb = q0r.y - cyq;
+      const float k00 = d0, k10 = d1, k01 = d2, k20 = d3;
+      const float sdx = __builtin_fmaf(a, k00, -k10), sdy = __builtin_fmaf(bb, k00, -k01);
+      const float sxx = __builtin_fmaf(a, __builtin_fmaf(a, k00, -(k10 + k10)), k20);
+      const float sxy = __builtin_fmaf(a, sdy, __builtin_fmaf(-bb, k10, k11));
+      const float syy = __builtin_fmaf(bb, __builtin_fmaf(bb, k00, -(k01 + k01)), k02);
+      // d(p2)/d(dx) = 2 qa dx + qb dy ;  d(p2)/d(dy) = qb dx + 2 qc dy
+      const float x0 = __builtin_fmaf(q0r.z + q0r.z, sdx, q0r.w * sdy);
+      const float x1 = __builtin_fmaf(q0r.w, sdx, (q1r.x + q1r.x) * sdy);
+      *reinterpret_cast<float2*>(dst + 0) = make_float2(x0, x1);
+      *reinterpret_cast<float2*>(dst + 2) = make_float2(sxx, sxy);
+      *reinterpret_cast<float2*>(dst + 4) = make_float2(syy, k00);
+    } else if (lane >= 24 && lane < 32) {            // rows 6, 7 of columns 8..15: sum wgt g_C0, g_C1
+      *reinterpret_cast<float2*>(dst + 6) = make_float2(d2, d3);
+    } else if (lane >= 40 && lane < 48) {            // rows 8, 9 of columns 8..15: sum wgt g_C2, g_D
+      *reinterpret_cast<float2*>(dst + 8) = make_float2(d0, d1);
+    }
+  };
+
+  // Software pipeline: the MFMA chain of batch i runs while the wave evaluates batch i + 1; its
+  // results are picked up (finish) only after that.
+  hgs_f32x4 pa0 = {0.f, 0.f, 0.f, 0.f}, pa1 = {0.f, 0.f, 0.f, 0.f};
+  uint32_t pk0 = 0, pn = 0;
+  for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_BWD_BATCH) {
+    const uint32_t nrec = min((uint32_t)HGS_BWD_BATCH, cnt - k0);
+#pragma unroll
+    for (int u = 0; u < HGS_BWD_BATCH; ++u) {
+      float kq = 0.0f, wgt = 0.0f;
+      if ((uint32_t)u < nrec) {                      // wave-uniform
+        const float4 r0 = srec[3 * (k0 + u) + 0];    // mx my qa qb
+        const float4 r1 = srec[3 * (k0 + u) + 1];    // qc op r g
+        const float4 r2 = srec[3 * (k0 + u) + 2];    // b depth entry slot
+        const uint32_t slot = __float_as_uint(r2.w);
+        // same dx/dy expressions as the forward so skip decisions agree
+        const float dx = r0.x - pxf, dy = r0.y - pyf;
+        float G, alpha, m2, m3;
+        const bool keep = hgs_eval_alpha(dx, dy, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
+        const bool act = keep && (q0 + slot < nc);
+        const float am = act ? r1.y * G : 0.0f;      // un-clamped alpha (= op*G), 0 when inactive
+        const float a = fminf(HGS_ALPHA_MAX, am);
+        wgt = a * T;
+        const float S = __builtin_fmaf(r1.z, g0, __builtin_fmaf(r1.w, g1, __builtin_fmaf(r2.x, g2,
+                        __builtin_fmaf(r2.y, gd, ga))));
+        F = __builtin_fmaf(wgt, S, F);
+        const float om = 1.0f - a;
+        // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
+        const float dLda = __builtin_fmaf(T, S, -((fp - F) * __builtin_amdgcn_rcpf(om)));
+        T *= om;
+        kq = am * dLda;                              // k = dL/dG * G
+      }
+      stage[u * HGS_STAGE_STRIDE + lane] = kq;
+      stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float4 bq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      bq[c] = *reinterpret_cast<const float4*>(&stage[mrow * HGS_STAGE_STRIDE + 16 * c + 4 * kk]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                 // the next batch overwrites the stage
+    if (pn) finish(pa0, pa1, pk0, pn);
+    // ---- contraction over the 64 pixels on the matrix cores (two accumulators: no dependent stall)
+    hgs_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 0], bq[c].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 1], bq[c].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 2], bq[c].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 3], bq[c].w, acc1, 0, 0, 0);
+    }
+    pa0 = acc0; pa1 = acc1; pk0 = k0; pn = nrec;
+  }
+  if (pn) finish(pa0, pa1, pk0, pn);
   __syncthreads();
 
   // ---- one gradient row per entry: quadrant partials added in fixed order, exp2 folding
@@ -200,7 +284,8 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int vi = (int)part * 3 + j;
-        const float sum = ((s_part[e][0][vi] + s_part[e][1][vi]) + s_part[e][2][vi]) + s_part[e][3][vi];
+        const int vc = min(vi, HGS_PART_FLOATS - 1);
+        const float sum = ((s_part[e][0][vc] + s_part[e][1][vc]) + s_part[e][2][vc]) + s_part[e][3][vc];
         float sc = 1.0f;
         if (vi == 0 || vi == 1) sc = il;
         else if (vi == 2 || vi == 4) sc = -0.5f;
