@@ -333,7 +333,7 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
   float* rows = static_cast<float*>(bwd_scratch);
   HGS_STAGE(0);
   if (groups > 0) {
-    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(groups), dim3(256), 0, stream, v, L, status_dev,
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(groups), dim3(64 * HGS_BWD_WAVES), 0, stream, v, L, status_dev,
                        L.recs, L.bstate, L.segP, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
                        dL_dout_alpha, rows);
     HGS_LAUNCH_CHECK();

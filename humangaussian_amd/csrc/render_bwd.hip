@@ -39,7 +39,7 @@
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_WAVES)
 hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const SortRec* __restrict__ recs_all,
                  const float* __restrict__ bstate, const float* __restrict__ segP,
@@ -47,14 +47,36 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                  const float* __restrict__ dL_dalpha, float* __restrict__ grad_rows) {
-  // 12288 + 10240 + 17408 B = 39936 B: four workgroups per CU (160 KB of LDS)
-  __shared__ float4 s_rec[4][3 * HGS_BUCKET];
-  __shared__ __attribute__((aligned(16))) float s_part[HGS_BUCKET][4][HGS_PART_FLOATS];   // [slot][quadrant][value]
-  __shared__ __attribute__((aligned(16))) float s_stage[4][16 * HGS_STAGE_STRIDE];   // per wave: 16 columns x 64 pixels
+  // HGS_BWD_WAVES (1, 2 or 4) wave64 per (tile, bucket); each sweeps 4 / HGS_BWD_WAVES of the tile's
+  // 8x8 quadrants one after the other (lane = pixel of the current quadrant) and accumulates the
+  // per-entry sums of its quadrants in its own LDS block, in a fixed order; one barrier at the
+  // end, then the blocks are added in wave order.  3072 + 4352 + 2560 B of LDS per wave: 16 waves
+  // per CU.  Fewer waves per bucket amortise the per-bucket loads better, more waves make the
+  // work items shorter (at 5.6k buckets on 4096 wave slots the tail of long items dominates).
+  __shared__ float4 s_rec_all[HGS_BWD_WAVES][3 * HGS_BUCKET];
+  __shared__ __attribute__((aligned(16))) float s_part_all[HGS_BWD_WAVES][HGS_BUCKET][HGS_PART_FLOATS];   // [wave][slot][value]
+  __shared__ __attribute__((aligned(16))) float stage_all[HGS_BWD_WAVES][16 * HGS_STAGE_STRIDE];          // 16 columns x 64 pixels
+  constexpr int QW = 4 / HGS_BWD_WAVES;                      // quadrants per wave
+  const int h = (HGS_BWD_WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  float4* __restrict__ s_rec = s_rec_all[h];
+  float (*__restrict__ s_part)[HGS_PART_FLOATS] = s_part_all[h];
+  float* __restrict__ stage = stage_all[h];
 
-  // ---- which (tile, bucket) is this workgroup?  The forward left the tile of every backward
-  // workgroup in wg_tile (a binary search over tile_wgstart here cost 12 dependent loads).
+  // ---- which (tile, bucket)?  The forward left the tile of every backward workgroup in wg_tile
+  // (a binary search over tile_wgstart here cost 12 dependent loads).
   const uint32_t g = blockIdx.x;
+#ifdef HGS_BWD_TIMING
+  unsigned long long tm[8];
+  tm[0] = __builtin_readcyclecounter();
+#define HGS_TM(i) tm[i] = __builtin_readcyclecounter()
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
+#define HGS_TACC(i) { const unsigned long long tn_ = __builtin_readcyclecounter(); tacc[i] += tn_ - tlast; tlast = tn_; }
+#define HGS_TSTART() tlast = __builtin_readcyclecounter()
+#else
+#define HGS_TM(i)
+#define HGS_TACC(i)
+#define HGS_TSTART()
+#endif
   if (status->overflow || g >= L.tile_wgstart[v.T]) return;   // surplus workgroup
   const int t = (int)L.wg_tile[g];
   const uint32_t b = g - L.tile_wgstart[t];
@@ -63,236 +85,300 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   const uint32_t maxc = L.tile_maxcontrib[t];
   const uint32_t q0 = b * HGS_BUCKET;
   const uint32_t m = min((uint32_t)HGS_BUCKET, n - q0);      // entries in this bucket
-  const int tid = threadIdx.x;
+  const int lane = (int)threadIdx.x & 63;
   const SortRec* __restrict__ brecs = recs_all + start + q0;
-
-  if (q0 >= maxc) {               // nothing in this bucket ever contributed: zero rows
-    if ((uint32_t)(tid >> 2) < m) {
-      float* row = grad_rows + (size_t)brecs[tid >> 2].entry * HGS_ROW_FLOATS + (tid & 3) * 3;
-      row[0] = 0.f; row[1] = 0.f; row[2] = 0.f;
-    }
-    return;
-  }
-
-  // zero the per-(entry, quadrant) partials: quadrants that cull an entry leave zeros
-  {
-    float4* z = reinterpret_cast<float4*>(&s_part[0][0][0]);       // 640 float4
-    z[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    z[256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 128) z[512 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-
-  // ---- this thread's pixel (same ownership as the forward: pf = tid)
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
-  int lx, ly;
-  hgs_fwd_thread_pixel(tid, lx, ly);
-  const int px = (t % v.grid_x) * HGS_TILE + lx, py = (t / v.grid_x) * HGS_TILE + ly;
-  const float pxf = (float)px, pyf = (float)py;
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, fp = 0.f;
-  uint32_t nc = 0;
-  if (px < v.W && py < v.H) {
-    const size_t pix = (size_t)py * v.W + px, HW = (size_t)v.H * v.W;
-    if (dL_dcolor) { g0 = dL_dcolor[pix]; g1 = dL_dcolor[HW + pix]; g2 = dL_dcolor[2 * HW + pix]; }
-    if (dL_ddepth) gd = dL_ddepth[pix];
-    if (dL_dalpha) ga = dL_dalpha[pix];
-    fp = out_color[pix] * g0 + out_color[HW + pix] * g1 + out_color[2 * HW + pix] * g2 +
-         out_depth[pix] * gd + out_alpha[pix] * ga;
-    nc = L.n_contrib[pix];
-  }
-  // running state at the bucket start.  A pixel with n_contrib <= q0 finished before this
-  // bucket (its forward wave may have exited without storing the state) and is never active.
-  float T = 1.0f, F = 0.0f;
-  if (b > 0 && nc > q0) {
-    const float* bs = bstate + (size_t)(L.tile_bstart[t] + b - 1) * HGS_BSTATE_FLOATS;
-    T = bs[0 * 256 + tid];
-    float c0 = bs[1 * 256 + tid], c1 = bs[2 * 256 + tid], c2 = bs[3 * 256 + tid];
-    float d = bs[4 * 256 + tid], wt = bs[5 * 256 + tid];
-    // long lists are blended in segments of HGS_SEG entries: C, D, W are relative to the segment
-    // start, the combine kernel left the segment's base (exclusive prefix) in segP
-    const uint32_t kseg = (hgs_nseg(n) > 1) ? q0 / HGS_SEG : 0u;
-    if (kseg > 0) {
-      const float* base = segP + (size_t)(L.tile_msegstart[t] + kseg) * HGS_SEG_PLANES * HGS_TILE_PIX;
-      c0 += base[0 * 256 + tid]; c1 += base[1 * 256 + tid]; c2 += base[2 * 256 + tid];
-      d += base[3 * 256 + tid]; wt += base[4 * 256 + tid];
-    }
-    F = c0 * g0 + c1 * g1 + c2 * g2 + d * gd + wt * ga;
-  }
-
-  // ---- compaction of the bucket's records for this quadrant (ballot + prefix popcount)
-  float4* __restrict__ srec = s_rec[w];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // the bucket's records: one per lane, kept in registers for the four compactions
   float4 c0 = zero4, c1 = zero4, c2 = zero4;
   if ((uint32_t)lane < m) {
     const float4* src = reinterpret_cast<const float4*>(brecs + lane);
     c0 = src[0]; c1 = src[1]; c2 = src[2];
   }
-  const bool hit = ((uint32_t)lane < m) && ((__float_as_uint(c2.w) >> (28 + w)) & 1u);
-  const unsigned long long ball = __ballot(hit);
-  const uint32_t cnt = (uint32_t)__popcll(ball);
-  const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-  if (hit) {
-    srec[3 * pos + 0] = c0;
-    srec[3 * pos + 1] = c1;
-    srec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float((uint32_t)lane));   // slot in bucket
+  if (q0 >= maxc) {               // nothing in this bucket ever contributed: zero rows
+    if (h == 0 && (uint32_t)lane < m) {
+      float4* row = reinterpret_cast<float4*>(grad_rows + (size_t)__float_as_uint(c2.z) * HGS_ROW_FLOATS);
+      row[0] = zero4; row[1] = zero4; row[2] = zero4;
+    }
+    return;
   }
-
-  // ---- MFMA operand A: the per-pixel basis, fixed for the whole bucket.
-  // The ten sums over the quadrant's 64 pixels that a record needs are contractions of two
-  // per-(record, pixel) quantities with per-pixel constants:
-  //   k   (= op G dL/dalpha)  against  1, u, v, u^2, uv, v^2     (u, v = pixel - quadrant centre)
-  //   wgt (= alpha T)         against  g_C0, g_C1, g_C2, g_D
-  // dx = a - u, dy = b - v with (a, b) = mean - quadrant centre, so sum k dx^2 etc. follow from
-  // the six moments.  One v_mfma_f32_16x16x4_f32 chain per batch of 8 records computes
-  //   D[m][n] = sum_p A[m][p] B[p][n],  columns n < 8: k of record n, n >= 8: wgt of record n-8,
-  // rows m < 6: moment basis, rows 6..9: pixel gradients (the cross blocks are not used).
-  // Lane l supplies A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; instruction
-  // i = 4c + r contracts pixels p = 16c + 4(l >> 4) + r, so a lane fetches its four B values of
-  // a c-group with one 16 B LDS read.
-  float* __restrict__ stage = s_stage[w];
+  {  // zero the per-entry sums: 640 floats
+    float* z = &s_part[0][0];
+#pragma unroll
+    for (int k = 0; k < HGS_PART_FLOATS; ++k) z[k * 64 + lane] = 0.0f;
+  }
+  const uint32_t bs_index = L.tile_bstart[t] + b - 1;
+  const uint32_t kseg = (hgs_nseg(n) > 1) ? q0 / HGS_SEG : 0u;
+  const uint32_t ms_index = (kseg > 0) ? L.tile_msegstart[t] + kseg : 0u;
   const int mrow = lane & 15, kk = lane >> 4;
-  {
-    // every lane writes ITS pixel's ten basis values as one column of the stage; every lane then
-    // reads the row it supplies to the MFMA (row 10 = zeros for the six unused rows of A)
-    const float ub = (float)(lane & 7) - 3.5f, vb = (float)(lane >> 3) - 3.5f;
-    stage[0 * HGS_STAGE_STRIDE + lane] = 1.0f;
-    stage[1 * HGS_STAGE_STRIDE + lane] = ub;
-    stage[2 * HGS_STAGE_STRIDE + lane] = vb;
-    stage[3 * HGS_STAGE_STRIDE + lane] = ub * ub;
-    stage[4 * HGS_STAGE_STRIDE + lane] = ub * vb;
-    stage[5 * HGS_STAGE_STRIDE + lane] = vb * vb;
-    stage[6 * HGS_STAGE_STRIDE + lane] = g0;
-    stage[7 * HGS_STAGE_STRIDE + lane] = g1;
-    stage[8 * HGS_STAGE_STRIDE + lane] = g2;
-    stage[9 * HGS_STAGE_STRIDE + lane] = gd;
-    stage[10 * HGS_STAGE_STRIDE + lane] = 0.0f;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  float Areg[16];
-  {
-    const float* arow = stage + min(mrow, 10) * HGS_STAGE_STRIDE + 4 * kk;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 aq = *reinterpret_cast<const float4*>(arow + 16 * c);
-      Areg[4 * c + 0] = aq.x; Areg[4 * c + 1] = aq.y; Areg[4 * c + 2] = aq.z; Areg[4 * c + 3] = aq.w;
-    }
-  }
-  const float cxq = (float)((t % v.grid_x) * HGS_TILE + ((w & 1) << 3)) + 3.5f;
-  const float cyq = (float)((t / v.grid_x) * HGS_TILE + ((w >> 1) << 3)) + 3.5f;
-  __syncthreads();                                   // s_part zeroed, s_rec ready (also orders the A reads
-                                                     // before the first batch overwrites the stage)
+  const int tile_x0 = (t % v.grid_x) * HGS_TILE, tile_y0 = (t / v.grid_x) * HGS_TILE;
+  HGS_TM(1);
 
-  // Finishes a batch: D layout is lane l -> rows 4 (l >> 4) + r (r = register) of column l & 15.
-  auto finish = [&](const hgs_f32x4& a0, const hgs_f32x4& a1, uint32_t k0, uint32_t nrec) {
-    const float d0 = a0[0] + a1[0], d1 = a0[1] + a1[1], d2 = a0[2] + a1[2], d3 = a0[3] + a1[3];
-    // rows 4, 5 (uv, v^2 moments) of column n live in lane 16 + n: bring them to lane n
-    const float k11 = __shfl(d0, (lane + 16) & 63, 64), k02 = __shfl(d1, (lane + 16) & 63, 64);
-    const uint32_t rsel = (uint32_t)lane & 7u;       // record of the batch this lane finishes
-    if (rsel >= nrec) return;
-    const float4 q0r = srec[3 * (k0 + rsel) + 0];
-    const float4 q1r = srec[3 * (k0 + rsel) + 1];
-    const uint32_t slot_l = __float_as_uint(srec[3 * (k0 + rsel) + 2].w);
-    float* dst = &s_part[slot_l][w][0];
-    if (lane < 8) {
-      const float a = q0r.x - cxq, bb = q0r.y - cyq;
-      const float k00 = d0, k10 = d1, k01 = d2, k20 = d3;
-      const float sdx = __builtin_fmaf(a, k00, -k10), sdy = __builtin_fmaf(bb, k00, -k01);
-      const float sxx = __builtin_fmaf(a, __builtin_fmaf(a, k00, -(k10 + k10)), k20);
-      const float sxy = __builtin_fmaf(a, sdy, __builtin_fmaf(-bb, k10, k11));
-      const float syy = __builtin_fmaf(bb, __builtin_fmaf(bb, k00, -(k01 + k01)), k02);
-      // d(p2)/d(dx) = 2 qa dx + qb dy ;  d(p2)/d(dy) = qb dx + 2 qc dy
-      const float x0 = __builtin_fmaf(q0r.z + q0r.z, sdx, q0r.w * sdy);
-      const float x1 = __builtin_fmaf(q0r.w, sdx, (q1r.x + q1r.x) * sdy);
-      *reinterpret_cast<float2*>(dst + 0) = make_float2(x0, x1);
-      *reinterpret_cast<float2*>(dst + 2) = make_float2(sxx, sxy);
-      *reinterpret_cast<float2*>(dst + 4) = make_float2(syy, k00);
-    } else if (lane >= 24 && lane < 32) {            // rows 6, 7 of columns 8..15: sum wgt g_C0, g_C1
-      *reinterpret_cast<float2*>(dst + 6) = make_float2(d2, d3);
-    } else if (lane >= 40 && lane < 48) {            // rows 8, 9 of columns 8..15: sum wgt g_C2, g_D
-      *reinterpret_cast<float2*>(dst + 8) = make_float2(d0, d1);
+  // Raw per-pixel inputs of one quadrant.  They are fetched one quadrant AHEAD (software
+  // prefetch): a single wave has nobody else to hide its HBM round trips behind.
+  struct PixRaw { float g0, g1, g2, gd, ga, o0, o1, o2, od, oa, T, s0, s1, s2, d, wt, e0, e1, e2, e3, e4; uint32_t nc; };
+  const bool have_state = b > 0;
+  const float* __restrict__ bs = bstate + (size_t)bs_index * HGS_BSTATE_FLOATS;
+  const float* __restrict__ sbase = segP + (size_t)ms_index * HGS_SEG_PLANES * HGS_TILE_PIX;
+  auto fetch = [&](int w) {
+    PixRaw r;
+    r.g0 = r.g1 = r.g2 = r.gd = r.ga = r.o0 = r.o1 = r.o2 = r.od = r.oa = 0.f;
+    r.T = 1.0f; r.s0 = r.s1 = r.s2 = r.d = r.wt = 0.f; r.nc = 0;
+    r.e0 = r.e1 = r.e2 = r.e3 = r.e4 = 0.f;
+    const int pf = w * 64 + lane;
+    const int px = tile_x0 + ((w & 1) << 3) + (lane & 7), py = tile_y0 + ((w >> 1) << 3) + (lane >> 3);
+    if (px < v.W && py < v.H) {
+      const size_t pix = (size_t)py * v.W + px, HW = (size_t)v.H * v.W;
+      if (dL_dcolor) { r.g0 = dL_dcolor[pix]; r.g1 = dL_dcolor[HW + pix]; r.g2 = dL_dcolor[2 * HW + pix]; }
+      if (dL_ddepth) r.gd = dL_ddepth[pix];
+      if (dL_dalpha) r.ga = dL_dalpha[pix];
+      r.o0 = out_color[pix]; r.o1 = out_color[HW + pix]; r.o2 = out_color[2 * HW + pix];
+      r.od = out_depth[pix]; r.oa = out_alpha[pix];
     }
-  };
-
-  // Software pipeline: the MFMA chain of batch i runs while the wave evaluates batch i + 1; its
-  // results are picked up (finish) only after that.
-  hgs_f32x4 pa0 = {0.f, 0.f, 0.f, 0.f}, pa1 = {0.f, 0.f, 0.f, 0.f};
-  uint32_t pk0 = 0, pn = 0;
-  for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_BWD_BATCH) {
-    const uint32_t nrec = min((uint32_t)HGS_BWD_BATCH, cnt - k0);
-#pragma unroll
-    for (int u = 0; u < HGS_BWD_BATCH; ++u) {
-      float kq = 0.0f, wgt = 0.0f;
-      if ((uint32_t)u < nrec) {                      // wave-uniform
-        const float4 r0 = srec[3 * (k0 + u) + 0];    // mx my qa qb
-        const float4 r1 = srec[3 * (k0 + u) + 1];    // qc op r g
-        const float4 r2 = srec[3 * (k0 + u) + 2];    // b depth entry slot
-        const uint32_t slot = __float_as_uint(r2.w);
-        // same dx/dy expressions as the forward so skip decisions agree
-        const float dx = r0.x - pxf, dy = r0.y - pyf;
-        float G, alpha, m2, m3;
-        const bool keep = hgs_eval_alpha(dx, dy, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
-        const bool act = keep && (q0 + slot < nc);
-        const float am = act ? r1.y * G : 0.0f;      // un-clamped alpha (= op*G), 0 when inactive
-        const float a = fminf(HGS_ALPHA_MAX, am);
-        wgt = a * T;
-        const float S = __builtin_fmaf(r1.z, g0, __builtin_fmaf(r1.w, g1, __builtin_fmaf(r2.x, g2,
-                        __builtin_fmaf(r2.y, gd, ga))));
-        F = __builtin_fmaf(wgt, S, F);
-        const float om = 1.0f - a;
-        // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
-        const float dLda = __builtin_fmaf(T, S, -((fp - F) * __builtin_amdgcn_rcpf(om)));
-        T *= om;
-        kq = am * dLda;                              // k = dL/dG * G
+    if (have_state) {            // unconditional on n_contrib: one load round, selected below
+      r.T = bs[0 * 256 + pf];
+      r.s0 = bs[1 * 256 + pf]; r.s1 = bs[2 * 256 + pf]; r.s2 = bs[3 * 256 + pf];
+      r.d = bs[4 * 256 + pf]; r.wt = bs[5 * 256 + pf];
+      // long lists are blended in segments of HGS_SEG entries: C, D, W are relative to the segment
+      // start, the combine kernel left the segment's base (exclusive prefix) in segP
+      // (added at consumption: an add here would make the prefetch wait for its own loads)
+      if (kseg > 0) {
+        r.e0 = sbase[0 * 256 + pf]; r.e1 = sbase[1 * 256 + pf]; r.e2 = sbase[2 * 256 + pf];
+        r.e3 = sbase[3 * 256 + pf]; r.e4 = sbase[4 * 256 + pf];
       }
-      stage[u * HGS_STAGE_STRIDE + lane] = kq;
-      stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgt;
+    }
+    return r;
+  };
+  // This wave's quadrants.  An entry can be dropped from a quadrant's list when it lies beyond
+  // the deepest pixel of that quadrant (slot >= max n_contrib - q0: no pixel ever reached it).
+  const int w_begin = h * QW;
+  uint32_t cntq[QW], ncq[QW];
+  unsigned long long ballq[QW];
+#pragma unroll
+  for (int j = 0; j < QW; ++j) {
+    const int w = w_begin + j;
+    const int px = tile_x0 + ((w & 1) << 3) + (lane & 7), py = tile_y0 + ((w >> 1) << 3) + (lane >> 3);
+    ncq[j] = (px < v.W && py < v.H) ? L.n_contrib[(size_t)py * v.W + px] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < QW; ++j) {
+    uint32_t mx = ncq[j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    const int w = w_begin + j;
+    ballq[j] = __ballot(((uint32_t)lane < m) && ((__float_as_uint(c2.w) >> (28 + w)) & 1u) &&
+                        (q0 + (uint32_t)lane < mx));
+    cntq[j] = (uint32_t)__popcll(ballq[j]);
+  }
+  int jnext = 0;
+  while (jnext < QW && cntq[jnext] == 0) ++jnext;
+  PixRaw nxt = fetch(w_begin + min(jnext, QW - 1));
+
+#pragma unroll 1
+  for (int j = jnext; j < QW; j = jnext) {
+    const int w = w_begin + j;
+    const unsigned long long ball = ballq[j];
+    const uint32_t cnt = cntq[j];
+    const bool hit = (ball >> lane) & 1ull;
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+    const int px = tile_x0 + ((w & 1) << 3) + (lane & 7), py = tile_y0 + ((w >> 1) << 3) + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const PixRaw cur = nxt;
+    const uint32_t nc = ncq[j];
+    jnext = j + 1;
+    while (jnext < QW && cntq[jnext] == 0) ++jnext;
+    if (jnext < QW) nxt = fetch(w_begin + jnext);    // in flight during this quadrant's loop
+    const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2, gd = cur.gd, ga = cur.ga;
+    const float fp = cur.o0 * g0 + cur.o1 * g1 + cur.o2 * g2 + cur.od * gd + cur.oa * ga;
+    // running state at the bucket start.  A pixel with n_contrib <= q0 finished before this
+    // bucket (its forward wave may have exited without storing the state) and is never active.
+    float T = 1.0f, F = 0.0f;
+    if (have_state && nc > q0) {
+      T = cur.T;
+      F = (cur.s0 + cur.e0) * g0 + (cur.s1 + cur.e1) * g1 + (cur.s2 + cur.e2) * g2 + (cur.d + cur.e3) * gd +
+          (cur.wt + cur.e4) * ga;
+    }
+
+    // ---- MFMA operand A: the per-pixel basis of this quadrant.
+    // The ten sums over the quadrant's 64 pixels that a record needs are contractions of two
+    // per-(record, pixel) quantities with per-pixel constants:
+    //   k   (= op G dL/dalpha)  against  1, u, v, u^2, uv, v^2     (u, v = pixel - quadrant centre)
+    //   wgt (= alpha T)         against  g_C0, g_C1, g_C2, g_D
+    // dx = a - u, dy = b - v with (a, b) = mean - quadrant centre, so sum k dx^2 etc. follow from
+    // the six moments.  One v_mfma_f32_16x16x4_f32 chain per batch of 8 records computes
+    //   D[m][n] = sum_p A[m][p] B[p][n],  columns n < 8: k of record n, n >= 8: wgt of record n-8,
+    // rows m < 6: moment basis, rows 6..9: pixel gradients (the cross blocks are not used).
+    // Lane l supplies A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; instruction
+    // i = 4c + r contracts pixels p = 16c + 4(l >> 4) + r, so a lane fetches its four B values of
+    // a c-group with one 16 B LDS read.
+    {
+      // every lane writes ITS pixel's ten basis values as one column of the stage; every lane then
+      // reads the row it supplies to the MFMA (row 10 = zeros for the six unused rows of A)
+      const float ub = (float)(lane & 7) - 3.5f, vb = (float)(lane >> 3) - 3.5f;
+      stage[0 * HGS_STAGE_STRIDE + lane] = 1.0f;
+      stage[1 * HGS_STAGE_STRIDE + lane] = ub;
+      stage[2 * HGS_STAGE_STRIDE + lane] = vb;
+      stage[3 * HGS_STAGE_STRIDE + lane] = ub * ub;
+      stage[4 * HGS_STAGE_STRIDE + lane] = ub * vb;
+      stage[5 * HGS_STAGE_STRIDE + lane] = vb * vb;
+      stage[6 * HGS_STAGE_STRIDE + lane] = g0;
+      stage[7 * HGS_STAGE_STRIDE + lane] = g1;
+      stage[8 * HGS_STAGE_STRIDE + lane] = g2;
+      stage[9 * HGS_STAGE_STRIDE + lane] = gd;
+      stage[10 * HGS_STAGE_STRIDE + lane] = 0.0f;
+    }
+    if (hit) {
+      s_rec[3 * pos + 0] = c0;
+      s_rec[3 * pos + 1] = c1;
+      s_rec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float((uint32_t)lane));   // slot in bucket
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float4 bq[4];
+    float Areg[16];
+    {
+      const float* arow = stage + min(mrow, 10) * HGS_STAGE_STRIDE + 4 * kk;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      bq[c] = *reinterpret_cast<const float4*>(&stage[mrow * HGS_STAGE_STRIDE + 16 * c + 4 * kk]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();                 // the next batch overwrites the stage
-    if (pn) finish(pa0, pa1, pk0, pn);
-    // ---- contraction over the 64 pixels on the matrix cores (two accumulators: no dependent stall)
-    hgs_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 0], bq[c].x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 1], bq[c].y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 2], bq[c].z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 3], bq[c].w, acc1, 0, 0, 0);
-    }
-    pa0 = acc0; pa1 = acc1; pk0 = k0; pn = nrec;
-  }
-  if (pn) finish(pa0, pa1, pk0, pn);
-  __syncthreads();
-
-  // ---- one gradient row per entry: quadrant partials added in fixed order, exp2 folding
-  // undone (d power = d p2 / log2e), conic factors applied, dL/dopacity = sum(k) / op
-  {
-    const uint32_t e = (uint32_t)(tid >> 2), part = (uint32_t)(tid & 3);
-    if (e < m) {
-      const SortRec& rec = brecs[e];
-      float* row = grad_rows + (size_t)rec.entry * HGS_ROW_FLOATS + part * 3;
-      const float il = 1.0f / HGS_LOG2E;
-      const float opi = (rec.op != 0.0f) ? 1.0f / rec.op : 0.0f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int vi = (int)part * 3 + j;
-        const int vc = min(vi, HGS_PART_FLOATS - 1);
-        const float sum = ((s_part[e][0][vc] + s_part[e][1][vc]) + s_part[e][2][vc]) + s_part[e][3][vc];
-        float sc = 1.0f;
-        if (vi == 0 || vi == 1) sc = il;
-        else if (vi == 2 || vi == 4) sc = -0.5f;
-        else if (vi == 3) sc = -1.0f;
-        else if (vi == 5) sc = opi;
-        row[j] = (vi < 10) ? sum * sc : 0.0f;
+      for (int c = 0; c < 4; ++c) {
+        const float4 aq = *reinterpret_cast<const float4*>(arow + 16 * c);
+        Areg[4 * c + 0] = aq.x; Areg[4 * c + 1] = aq.y; Areg[4 * c + 2] = aq.z; Areg[4 * c + 3] = aq.w;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float cxq = (float)(tile_x0 + ((w & 1) << 3)) + 3.5f;
+    const float cyq = (float)(tile_y0 + ((w >> 1) << 3)) + 3.5f;
+
+    // Finishes a batch: D layout is lane l -> rows 4 (l >> 4) + r (r = register) of column l & 15.
+    // The sums are ADDED to the entry's totals: quadrants 0..3 in this fixed order.
+    auto finish = [&](const hgs_f32x4& a0, const hgs_f32x4& a1, uint32_t k0, uint32_t nrec) {
+      const float d0 = a0[0] + a1[0], d1 = a0[1] + a1[1], d2 = a0[2] + a1[2], d3 = a0[3] + a1[3];
+      // rows 4, 5 (uv, v^2 moments) of column n live in lane 16 + n: bring them to lane n
+      const float k11 = __shfl(d0, (lane + 16) & 63, 64), k02 = __shfl(d1, (lane + 16) & 63, 64);
+      const uint32_t rsel = (uint32_t)lane & 7u;     // record of the batch this lane finishes
+      if (rsel >= nrec) return;
+      const float4 q0r = s_rec[3 * (k0 + rsel) + 0];
+      const float4 q1r = s_rec[3 * (k0 + rsel) + 1];
+      const uint32_t slot_l = __float_as_uint(s_rec[3 * (k0 + rsel) + 2].w);
+      float* dst = &s_part[slot_l][0];
+      if (lane < 8) {
+        const float a = q0r.x - cxq, bb = q0r.y - cyq;
+        const float k00 = d0, k10 = d1, k01 = d2, k20 = d3;
+        const float sdx = __builtin_fmaf(a, k00, -k10), sdy = __builtin_fmaf(bb, k00, -k01);
+        const float sxx = __builtin_fmaf(a, __builtin_fmaf(a, k00, -(k10 + k10)), k20);
+        const float sxy = __builtin_fmaf(a, sdy, __builtin_fmaf(-bb, k10, k11));
+        const float syy = __builtin_fmaf(bb, __builtin_fmaf(bb, k00, -(k01 + k01)), k02);
+        // d(p2)/d(dx) = 2 qa dx + qb dy ;  d(p2)/d(dy) = qb dx + 2 qc dy
+        const float x0 = __builtin_fmaf(q0r.z + q0r.z, sdx, q0r.w * sdy);
+        const float x1 = __builtin_fmaf(q0r.w, sdx, (q1r.x + q1r.x) * sdy);
+        float2* d2p = reinterpret_cast<float2*>(dst);
+        const float2 o0 = d2p[0], o1 = d2p[1], o2 = d2p[2];
+        d2p[0] = make_float2(o0.x + x0, o0.y + x1);
+        d2p[1] = make_float2(o1.x + sxx, o1.y + sxy);
+        d2p[2] = make_float2(o2.x + syy, o2.y + k00);
+      } else if (lane >= 24 && lane < 32) {          // rows 6, 7 of columns 8..15: sum wgt g_C0, g_C1
+        float2* d2p = reinterpret_cast<float2*>(dst + 6);
+        const float2 o = *d2p;
+        *d2p = make_float2(o.x + d2, o.y + d3);
+      } else if (lane >= 40 && lane < 48) {          // rows 8, 9 of columns 8..15: sum wgt g_C2, g_D
+        float2* d2p = reinterpret_cast<float2*>(dst + 8);
+        const float2 o = *d2p;
+        *d2p = make_float2(o.x + d0, o.y + d1);
+      }
+    };
+
+    // Software pipeline: the MFMA chain of batch i runs while the wave evaluates batch i + 1; its
+    // results are picked up (finish) only after that.
+    hgs_f32x4 pa0 = {0.f, 0.f, 0.f, 0.f}, pa1 = {0.f, 0.f, 0.f, 0.f};
+    uint32_t pk0 = 0, pn = 0;
+    HGS_TSTART();
+    for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_BWD_BATCH) {
+      const uint32_t nrec = min((uint32_t)HGS_BWD_BATCH, cnt - k0);
+#pragma unroll
+      for (int u = 0; u < HGS_BWD_BATCH; ++u) {
+        float kq = 0.0f, wgt = 0.0f;
+        if ((uint32_t)u < nrec) {                    // wave-uniform
+          const float4 r0 = s_rec[3 * (k0 + u) + 0];    // mx my qa qb
+          const float4 r1 = s_rec[3 * (k0 + u) + 1];    // qc op r g
+          const float4 r2 = s_rec[3 * (k0 + u) + 2];    // b depth entry slot
+          const uint32_t slot = __float_as_uint(r2.w);
+          // same dx/dy expressions as the forward so skip decisions agree
+          const float dx = r0.x - pxf, dy = r0.y - pyf;
+          float G, alpha, m2, m3;
+          const bool keep = hgs_eval_alpha(dx, dy, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
+          const bool act = keep && (q0 + slot < nc);
+          const float am = act ? r1.y * G : 0.0f;    // un-clamped alpha (= op*G), 0 when inactive
+          const float a = fminf(HGS_ALPHA_MAX, am);
+          wgt = a * T;
+          const float S = __builtin_fmaf(r1.z, g0, __builtin_fmaf(r1.w, g1, __builtin_fmaf(r2.x, g2,
+                          __builtin_fmaf(r2.y, gd, ga))));
+          F = __builtin_fmaf(wgt, S, F);
+          const float om = 1.0f - a;
+          // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
+          const float dLda = __builtin_fmaf(T, S, -((fp - F) * __builtin_amdgcn_rcpf(om)));
+          T *= om;
+          kq = am * dLda;                            // k = dL/dG * G
+        }
+        stage[u * HGS_STAGE_STRIDE + lane] = kq;
+        stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgt;
+      }
+      HGS_TACC(0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float4 bq[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        bq[c] = *reinterpret_cast<const float4*>(&stage[mrow * HGS_STAGE_STRIDE + 16 * c + 4 * kk]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();               // the next batch overwrites the stage
+      HGS_TACC(1);
+      // keep the previous batch's accumulators in AGPRs up to here: read any earlier and the wave
+      // waits for its MFMA chain before evaluating this batch (no overlap)
+      asm volatile("" : "+a"(pa0), "+a"(pa1));
+      if (pn) finish(pa0, pa1, pk0, pn);
+      HGS_TACC(2);
+      // ---- contraction over the 64 pixels on the matrix cores (two accumulators: no dependent stall)
+      hgs_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 0], bq[c].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 1], bq[c].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 2], bq[c].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[4 * c + 3], bq[c].w, acc1, 0, 0, 0);
+      }
+      pa0 = acc0; pa1 = acc1; pk0 = k0; pn = nrec;
+      HGS_TACC(3);
+    }
+    if (pn) finish(pa0, pa1, pk0, pn);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                 // s_rec / stage are rewritten by the next quadrant
   }
+  HGS_TM(4);
+
+  // ---- one gradient row per entry (wave 0, lane = entry): the waves' blocks added in wave order,
+  // exp2 folding undone (d power = d p2 / log2e), conic factors applied, dL/dopacity = sum(k) / op
+  if (HGS_BWD_WAVES > 1) __syncthreads();
+  if (h == 0 && (uint32_t)lane < m) {
+    float sp[HGS_PART_FLOATS];
+#pragma unroll
+    for (int k = 0; k < HGS_PART_FLOATS; ++k) {
+      sp[k] = s_part_all[0][lane][k];
+#pragma unroll
+      for (int hh = 1; hh < HGS_BWD_WAVES; ++hh) sp[k] += s_part_all[hh][lane][k];
+    }
+    const float op = c1.y;
+    const float il = 1.0f / HGS_LOG2E;
+    const float opi = (op != 0.0f) ? 1.0f / op : 0.0f;
+    float4* row = reinterpret_cast<float4*>(grad_rows + (size_t)__float_as_uint(c2.z) * HGS_ROW_FLOATS);
+    row[0] = make_float4(sp[0] * il, sp[1] * il, sp[2] * -0.5f, sp[3] * -1.0f);
+    row[1] = make_float4(sp[4] * -0.5f, sp[5] * opi, sp[6], sp[7]);
+    row[2] = make_float4(sp[8], sp[9], 0.0f, 0.0f);
+  }
+#ifdef HGS_BWD_TIMING
+  HGS_TM(6);
+  if (threadIdx.x == 0) {
+    unsigned long long* o = L.keys + (size_t)g * 8;
+    o[0] = tm[0]; o[1] = tm[1]; o[2] = tacc[0]; o[3] = tacc[1]; o[4] = tm[4]; o[5] = tacc[2]; o[6] = tm[6]; o[7] = tacc[3];
+  }
+#endif
 }
