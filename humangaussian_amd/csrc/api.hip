@@ -1,10 +1,10 @@
 // api.hip - host side of the C ABI declared in include/hgs_rast.h: buffer carving and the
-// launch sequences.  No allocation, no synchronisation, no global state.
+// launch sequences.  No allocation, no host synchronisation, no global state.
 //
-// Forward launch chain (one stream, 1 memset + 9 launches, no host round trip):
-//   memset tile_count -> preprocess_fwd -> scan -> fill -> sort_{huge,large,medium,small}
-//   -> render_fwd -> (async copy of hgs_status to pinned host memory)
-// Backward: render_bwd (bucket-parallel) -> preprocess_bwd.
+// Forward launch chain (one stream, no host round trip):
+//   preprocess_fwd -> colscan -> scan [status published] -> fill -> sort_{huge,large,lds}
+//   -> segT -> render_fwd (segments of long lists first, then the other tiles) -> combine
+// Backward: render_bwd (one wave per bucket) -> preprocess_bwd.
 #include "hgs_common.h"
 
 // The forward kernels and the per-Gaussian backward are included here (one translation
@@ -27,7 +27,7 @@ constexpr int HGS_MAX_BIN_WGS = 256;
 
 struct GeomCarve {
   size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
-      tile_wgstart, tile_maxcontrib, tile_msegstart, pos_segstart, hist, tile_grp, status, total;
+      tile_wgstart, tile_maxcontrib, tile_msegstart, hist, tile_grp, status, total;
 };
 
 inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
@@ -48,7 +48,6 @@ GeomCarve carve_geom(int P, int H, int W) {
   c.tile_wgstart = take((T + 1) * 4);
   c.tile_maxcontrib = take(T * 4);
   c.tile_msegstart = take((T + 1) * 4);
-  c.pos_segstart = take((T + 1) * 4);
   c.hist = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_MAX_BIN_WGS * T * 4 : 0);
   c.tile_grp = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
   c.status = take(sizeof(hgs_status));
@@ -56,7 +55,7 @@ GeomCarve carve_geom(int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, bstate, segT, segP, wg_tile, total; };
+struct BinCarve { size_t keys, recs, bstate, segT, segP, wg_tile, seg_item, total; };
 
 BinCarve carve_bin(int64_t cap) {
   BinCarve c;
@@ -69,6 +68,7 @@ BinCarve carve_bin(int64_t cap) {
   const size_t nms = 2 * (C / HGS_SEG) + 2;      // bound on segments of multi-segment tiles
   c.segT = take(nms * HGS_TILE_PIX * sizeof(float));
   c.segP = take(nms * HGS_SEG_PLANES * HGS_TILE_PIX * sizeof(float));
+  c.seg_item = take((nms + 2) * 8);
   c.wg_tile = take((C + C / HGS_BUCKET + 2) * 4);   // one backward workgroup per bucket: <= R/64 + active tiles
   c.total = off;
   return c;
@@ -90,7 +90,6 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
   L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
   L.tile_msegstart = reinterpret_cast<uint32_t*>(gp + g.tile_msegstart);
-  L.pos_segstart = reinterpret_cast<uint32_t*>(gp + g.pos_segstart);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.tile_grp = reinterpret_cast<uint32_t*>(gp + g.tile_grp);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
@@ -99,6 +98,7 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.segT = bp ? reinterpret_cast<float*>(bp + b.segT) : nullptr;
   L.segP = bp ? reinterpret_cast<float*>(bp + b.segP) : nullptr;
   L.wg_tile = bp ? reinterpret_cast<uint32_t*>(bp + b.wg_tile) : nullptr;
+  L.seg_item = bp ? reinterpret_cast<uint2*>(bp + b.seg_item) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;
 }
@@ -227,7 +227,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256, HGS_ROW_GROUPS), dim3(256), 0, stream, v, L);
     HGS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), v.T <= 7168 ? (size_t)v.T * 8 : 0, stream, v, L, status_dev,
+  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), v.T <= 14336 ? (size_t)v.T * 4 : 0, stream, v, L, status_dev,
                      status_host_mapped ? status_host : nullptr);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
@@ -270,23 +270,26 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(4);
-  // list-parallel blend: segment transmittances, segments, combine (grids are capacity
-  // bounds; surplus workgroups exit on the device-side totals)
+  // Blend: segment transmittances of the long lists (> HGS_SEG_THRESH entries), then ONE launch
+  // whose first seg_bound workgroups take the segments of the long lists and the next T the
+  // remaining tiles, then the combine of the segment partials.  Grids are capacity bounds;
+  // surplus workgroups exit on the device-side totals.  (Forking the long-list chain onto a second
+  // stream was measured: 79 -> 87 us at 100k Gaussians, 215 -> 188 us at 500k; not kept.)
   const bool use_seg = !v.seg_off && entry_capacity > HGS_SEG_THRESH;
-  const unsigned seg_bound = use_seg ? (unsigned)(entry_capacity / HGS_SEG + 1) : 0u;
+  const unsigned seg_bound = use_seg ? 2u * (unsigned)(entry_capacity / HGS_SEG) + 2u : 0u;
   if (use_seg) {
-    hipLaunchKernelGGL(hgs_k_fwd_segT, dim3(2 * seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L,
+    hipLaunchKernelGGL(hgs_k_fwd_segT, dim3(seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.recs, L.segT);
     HGS_LAUNCH_CHECK();
   }
   if (store_bwd_state)
     hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T + seg_bound), dim3(HGS_FWD_THREADS), 0, stream,
-                       v, L, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color, out_depth,
-                       out_alpha);
+                       v, L, (uint32_t)seg_bound, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color,
+                       out_depth, out_alpha);
   else
     hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T + seg_bound), dim3(HGS_FWD_THREADS), 0,
-                       stream, v, L, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color,
-                       out_depth, out_alpha);
+                       stream, v, L, (uint32_t)seg_bound, status_dev, L.recs, L.bstate, L.segT, L.segP,
+                       out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
   if (use_seg) {
     hipLaunchKernelGGL(hgs_k_fwd_combine, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L,

@@ -20,7 +20,7 @@
 namespace {
 constexpr int SCAN_NT = 1024;
 constexpr int SCAN_ITEMS = 4;      // tiles per thread per pass
-constexpr int SCAN_LDS_TILES = 7168;    // 56 KB of dynamic LDS (stays under the 64 KB default limit)
+constexpr int SCAN_LDS_TILES = 14336;   // 56 KB of dynamic LDS (stays under the 64 KB default limit)
 
 // exclusive scan of three counters at once over the workgroup (one barrier pair)
 constexpr int NSCAN = 4;
@@ -65,13 +65,11 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
   __shared__ uint32_t cls_hist[33];
   __shared__ uint32_t cls_base[33];
   __shared__ uint32_t max_n_s;
-  // dynamic LDS (launched with 8*T bytes when T <= SCAN_LDS_TILES, else 0): the per-tile counts
-  // and the tile order stay on chip for phases (c) and (d) - each global round trip of this
-  // single workgroup costs 1.5-3 us
+  // dynamic LDS (launched with 4*T bytes when T <= SCAN_LDS_TILES, else 0): the per-tile counts
+  // stay on chip for phase (c) - each global round trip of this single workgroup costs 1.5-3 us
   extern __shared__ uint32_t s_dyn[];
   const bool lds_tiles = v.T <= SCAN_LDS_TILES;
   uint32_t* s_n = s_dyn;
-  uint32_t* s_ord = s_dyn + v.T;
   const int tid = threadIdx.x;
 
   // (a) exclusive scan of per-chunk tiles_touched sums -> block_base
@@ -251,54 +249,8 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
       else
         pos = atomicAdd(&cls_base[32 - __clz(n)], 1u);
       L.tile_order[pos] = (uint32_t)t;
-      if (lds_tiles) s_ord[pos] = (uint32_t)t;
     }
   }
-  // (d) forward work items: one per segment of HGS_SEG entries, in tile_order (heavy first);
-  // pos_segstart = exclusive prefix of max(1, nseg) over tile_order positions
-  if (v.seg_off) return;                           // one work item per tile: tile_order is the list
-  __threadfence_block();
-  __syncthreads();
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  if (lds_tiles && (v.T & 3) == 0) {
-    // 4 consecutive positions per thread: one block scan per 4096 positions, 16 B stores
-    for (int base = 0; base < v.T; base += SCAN_NT * 4) {
-      const int p0 = base + tid * 4;
-      uint32_t ns[4] = {0, 0, 0, 0};
-      if (p0 < v.T) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ns[k] = hgs_nseg(s_n[s_ord[p0 + k]]);
-      }
-      uint32_t total;
-      const uint32_t ex1 = hgs_block_excl_scan<SCAN_NT>(ns[0] + ns[1] + ns[2] + ns[3], wtot, total);
-      const uint32_t b = carry_s + ex1;
-      if (p0 < v.T)
-        *reinterpret_cast<uint4*>(L.pos_segstart + p0) =
-            make_uint4(b, b + ns[0], b + ns[0] + ns[1], b + ns[0] + ns[1] + ns[2]);
-      __syncthreads();
-      if (tid == 0) carry_s += total;
-      __syncthreads();
-    }
-  } else {
-    for (int base = 0; base < v.T; base += SCAN_NT) {
-      const int pos = base + tid;
-      uint32_t ns = 0;
-      if (pos < v.T) {
-        const uint32_t t = L.tile_order[pos];
-        const uint32_t n = L.tile_start[t + 1] - L.tile_start[t];
-        ns = hgs_nseg(n);
-      }
-      uint32_t total;
-      const uint32_t ex1 = hgs_block_excl_scan<SCAN_NT>(ns, wtot, total);
-      const uint32_t carry = carry_s;
-      if (pos < v.T) L.pos_segstart[pos] = carry + ex1;
-      __syncthreads();
-      if (tid == 0) carry_s = carry + total;
-      __syncthreads();
-    }
-  }
-  if (tid == 0) L.pos_segstart[v.T] = carry_s;
 }
 
 // ---------------------------------------------------------------------------- 2. fill
@@ -400,6 +352,14 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
                                                const unsigned long long* sorted, int nt) {
   const int tx = t % v.grid_x, ty = t / v.grid_x;
   const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
+  {  // (tile, segment) table of the long lists: the segment kernels find their work with one load
+    const uint32_t nseg = hgs_nseg(n);
+    if (nseg > 1) {
+      const uint32_t ms0 = L.tile_msegstart[t], item_bound = 2u * (uint32_t)(v.entry_capacity / HGS_SEG) + 2u;
+      for (uint32_t sg = threadIdx.x; sg < nseg && ms0 + sg < item_bound; sg += nt)
+        L.seg_item[ms0 + sg] = make_uint2((uint32_t)t, sg);
+    }
+  }
   for (uint32_t k = threadIdx.x; k < n; k += nt) {
     const uint32_t idx = (uint32_t)sorted[k];
     const uint4* gp = reinterpret_cast<const uint4*>(&L.geom[idx]);

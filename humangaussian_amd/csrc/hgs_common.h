@@ -13,7 +13,7 @@
 //   uint32   tile_bstart[T+1] (bucket-state prefix)        bwd scratch: float grad_rows[R][12]
 //   uint32   tile_wgstart[T+1](backward WG prefix)
 //   uint32   tile_maxcontrib[T]                float segT[2C/SEG][256], segP[2C/SEG][7][256]
-//   uint32   tile_msegstart[T+1], pos_segstart[T+1]   (forward segments of long lists)
+//   uint32   tile_msegstart[T+1]                      (forward segments of long lists)
 //   uint32   hist[NWG][T]      (per-binning-workgroup tile histograms, T <= 16384)
 //
 // wave = 64 lanes everywhere; a "bucket" is 64 consecutive entries of one tile's list.
@@ -77,7 +77,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* tile_wgstart;
   uint32_t* tile_maxcontrib;
   uint32_t* tile_msegstart;   // [T+1] prefix of (nseg > 1 ? nseg : 0): index of a tile's segment planes
-  uint32_t* pos_segstart;     // [T+1] prefix of nseg over tile_order positions: forward work items
+  uint2* seg_item;            // [<= 2C/HGS_SEG + 4] (tile, segment) of every segment of the long lists
   uint32_t* wg_tile;          // [<= C + C/64] tile of every backward workgroup (written by the forward)
   uint32_t* hist;          // [nwg][T] per-workgroup tile histograms -> exclusive bases
   uint32_t* tile_grp;      // [HGS_ROW_GROUPS][T] row-group totals -> absolute group bases

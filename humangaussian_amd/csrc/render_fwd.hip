@@ -150,16 +150,6 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
   }
 }
 
-// binary search: largest i in [0, n) with prefix[i] <= g   (prefix[0] = 0, prefix[n] = total)
-__device__ __forceinline__ int find_owner(const uint32_t* __restrict__ prefix, int n, uint32_t g) {
-  int lo = 0, hi = n;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (prefix[mid] <= g) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------ segment transmittance
@@ -169,8 +159,9 @@ hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
   __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * HGS_FWD_UNROLL)];
   const uint32_t ms = blockIdx.x;
   if (status->overflow || ms >= L.tile_msegstart[v.T]) return;
-  const int t = find_owner(L.tile_msegstart, v.T, ms);
-  const uint32_t k = ms - L.tile_msegstart[t];
+  const uint2 item = L.seg_item[ms];                // (tile, segment): one load, no search
+  const int t = (int)item.x;
+  const uint32_t k = item.y;
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_start[t + 1] - start;
   const uint32_t nseg = hgs_nseg(n);
@@ -194,7 +185,7 @@ hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
 
 // ---------------------------------------------------------------------------- blend
 template <bool STORE>
-__device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
+__device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, uint32_t seg_bound,
                                                 const hgs_status* __restrict__ status,
                                                 const SortRec* __restrict__ recs_all,
                                                 float* __restrict__ bstate,
@@ -207,18 +198,20 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
   const bool overflow = status->overflow != 0;
   int t;
   uint32_t k = 0;
-  if (overflow) {                                   // lists are invalid: background only
-    if ((int)blockIdx.x >= v.T) return;
-    t = (int)blockIdx.x;
-  } else if (v.seg_off) {                            // one workgroup per tile, heavy first
-    if ((int)blockIdx.x >= v.T) return;
-    t = (int)L.tile_order[blockIdx.x];
+  // Work items, in dispatch order: first the segments of the long lists (the heaviest tiles: their
+  // chains start first), then one workgroup per remaining tile, heavy first.  The first
+  // `seg_bound` blocks are a capacity bound on the number of segments; surplus ones exit.
+  const bool LONG = blockIdx.x < seg_bound;
+  if (LONG) {
+    const uint32_t ms = blockIdx.x;
+    if (overflow || ms >= L.tile_msegstart[v.T]) return;
+    const uint2 item = L.seg_item[ms];              // (tile, segment): one load, no search
+    t = (int)item.x;
+    k = item.y;
   } else {
-    const uint32_t g = blockIdx.x;
-    if (g >= L.pos_segstart[v.T]) return;           // surplus workgroup of the bounded grid
-    const int pos = find_owner(L.pos_segstart, v.T, g);
-    t = (int)L.tile_order[pos];
-    k = g - L.pos_segstart[pos];
+    const uint32_t p = blockIdx.x - seg_bound;
+    if (p >= (uint32_t)v.T) return;
+    t = overflow ? (int)p : (int)L.tile_order[p];   // lists are invalid on overflow: background only
   }
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,6 +226,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
   const uint32_t start = overflow ? 0u : L.tile_start[t];
   const uint32_t n = overflow ? 0u : (L.tile_start[t + 1] - start);
   const uint32_t nseg = hgs_nseg(n);
+  if (!LONG && nseg > 1) return;
   const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
   const uint32_t ms0 = (nseg > 1) ? L.tile_msegstart[t] : 0u;
   if (STORE && !overflow && k == 0) {
@@ -301,21 +295,21 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
 }
 
 extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
-hgs_k_render_fwd_store(View v, Layout L, const hgs_status* __restrict__ status,
+hgs_k_render_fwd_store(View v, Layout L, uint32_t seg_bound, const hgs_status* __restrict__ status,
                        const SortRec* __restrict__ recs, float* __restrict__ bstate,
                        const float* __restrict__ segT, float* __restrict__ segP,
                        float* __restrict__ out_color, float* __restrict__ out_depth,
                        float* __restrict__ out_alpha) {
-  render_fwd_body<true>(v, L, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
+  render_fwd_body<true>(v, L, seg_bound, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
 }
 
 extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
-hgs_k_render_fwd_nostore(View v, Layout L, const hgs_status* __restrict__ status,
+hgs_k_render_fwd_nostore(View v, Layout L, uint32_t seg_bound, const hgs_status* __restrict__ status,
                          const SortRec* __restrict__ recs, float* __restrict__ bstate,
                          const float* __restrict__ segT, float* __restrict__ segP,
                          float* __restrict__ out_color, float* __restrict__ out_depth,
                          float* __restrict__ out_alpha) {
-  render_fwd_body<false>(v, L, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
+  render_fwd_body<false>(v, L, seg_bound, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
 }
 
 // -------------------------------------------------------------------------- combine
