@@ -134,6 +134,9 @@ View make_view(const hgs_settings* s, int P, int M, int64_t cap, int max_tile_hi
   // every list cut), so only lists longer than HGS_SEG_THRESH are segmented - a pure function
   // of the list length; a hint that rules such lists out merely skips the empty launches
   v.seg_off = (max_tile_hint > 0 && max_tile_hint <= HGS_SEG_THRESH) ? 1 : 0;
+  // few segments per list: a segment recomputes its predecessors' transmittance products itself
+  // (work quadratic in the segment count, hence the bound) and hgs_k_fwd_segT is not launched
+  v.seg_recompute = (max_tile_hint > 0 && max_tile_hint <= 12 * HGS_SEG) ? 1 : 0;
   return v;
 }
 
@@ -277,7 +280,7 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
   // stream was measured: 79 -> 87 us at 100k Gaussians, 215 -> 188 us at 500k; not kept.)
   const bool use_seg = !v.seg_off && entry_capacity > HGS_SEG_THRESH;
   const unsigned seg_bound = use_seg ? 2u * (unsigned)(entry_capacity / HGS_SEG) + 2u : 0u;
-  if (use_seg) {
+  if (use_seg && !v.seg_recompute) {
     hipLaunchKernelGGL(hgs_k_fwd_segT, dim3(seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.recs, L.segT);
     HGS_LAUNCH_CHECK();

@@ -101,6 +101,7 @@ struct View {            // per-call constants, passed by value to every kernel
   uint32_t entry_capacity;
   int32_t max_tile_hint;        // >0: caller promises no tile list is longer (else overflow bit 2)
   int32_t seg_off;              // 1: the caller's hint proves no list exceeds HGS_SEG_THRESH
+  int32_t seg_recompute;        // 1: the hint proves lists have <= 12 segments: no segT pre-pass
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

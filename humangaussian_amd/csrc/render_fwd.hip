@@ -152,6 +152,19 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
 
 }  // namespace
 
+// product of (1 - alpha) over segment i of a tile's list for this thread's pixel (no stop rule)
+__device__ __forceinline__ float segment_tprod(const float4* __restrict__ recs, uint32_t i, int w,
+                                               float4* __restrict__ srec, int lane, float pxf, float pyf) {
+  float P = 1.0f;
+  walk_segment(recs, i * HGS_SEG, (i + 1) * HGS_SEG, 1u << (28 + w), srec, lane,
+               [](uint32_t) {}, [] { return true; },
+               [&](const float4 (&ra)[HGS_FWD_UNROLL], const float4 (&rb)[HGS_FWD_UNROLL], const float4 (&)[HGS_FWD_UNROLL]) {
+#pragma unroll
+                 for (int u = 0; u < HGS_FWD_UNROLL; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
+               });
+  return P;
+}
+
 // ------------------------------------------------------------------ segment transmittance
 extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
 hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
@@ -173,13 +186,7 @@ hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
   hgs_fwd_thread_pixel(tid, lx, ly);
   const float pxf = (float)((t % v.grid_x) * HGS_TILE + lx), pyf = (float)((t / v.grid_x) * HGS_TILE + ly);
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
-  float P = 1.0f;
-  walk_segment(recs, k * HGS_SEG, (k + 1) * HGS_SEG, 1u << (28 + w), s_rec[w], lane,
-               [](uint32_t) {}, [] { return true; },
-               [&](const float4 (&ra)[HGS_FWD_UNROLL], const float4 (&rb)[HGS_FWD_UNROLL], const float4 (&)[HGS_FWD_UNROLL]) {
-#pragma unroll
-                 for (int u = 0; u < HGS_FWD_UNROLL; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
-               });
+  const float P = segment_tprod(recs, k, w, s_rec[w], lane, pxf, pyf);
   segT[(size_t)ms * HGS_TILE_PIX + tid] = P;
 }
 
@@ -240,7 +247,14 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   PixState s;
   s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
   s.last = 0;
-  for (uint32_t i = 0; i < k; ++i) s.T *= segT[(size_t)(ms0 + i) * HGS_TILE_PIX + tid];
+  if (v.seg_recompute) {
+    // lists of at most a few segments: the segment recomputes its predecessors' transmittance
+    // products itself (same arithmetic as hgs_k_fwd_segT, so the same bits) and the pre-pass
+    // kernel - 15 us alone on the GPU for ~60 long tiles - is not launched at all
+    for (uint32_t i = 0; i < k; ++i) s.T *= segment_tprod(recs, i, w, s_rec[w], lane, pxf, pyf);
+  } else {
+    for (uint32_t i = 0; i < k; ++i) s.T *= segT[(size_t)(ms0 + i) * HGS_TILE_PIX + tid];
+  }
   // T only decreases: "terminated before this segment" <=> entry transmittance < 1e-4
   s.done = !inside || (s.T < HGS_T_EPS);
 
