@@ -27,7 +27,7 @@ constexpr int HGS_MAX_BIN_WGS = 256;
 
 struct GeomCarve {
   size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
-      tile_wgstart, tile_maxcontrib, tile_msegstart, hist, tile_grp, status, total;
+      tile_wgstart, tile_maxcontrib, tile_msegstart, hist, tile_grp, tile_gbase, status, total;
 };
 
 inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
@@ -50,6 +50,7 @@ GeomCarve carve_geom(int P, int H, int W) {
   c.tile_msegstart = take((T + 1) * 4);
   c.hist = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_MAX_BIN_WGS * T * 4 : 0);
   c.tile_grp = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
+  c.tile_gbase = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
   c.status = take(sizeof(hgs_status));
   c.total = off;
   return c;
@@ -92,6 +93,7 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.tile_msegstart = reinterpret_cast<uint32_t*>(gp + g.tile_msegstart);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.tile_grp = reinterpret_cast<uint32_t*>(gp + g.tile_grp);
+  L.tile_gbase = reinterpret_cast<uint32_t*>(gp + g.tile_gbase);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
@@ -230,7 +232,8 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256, HGS_ROW_GROUPS), dim3(256), 0, stream, v, L);
     HGS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(hgs_k_scan, dim3(1), dim3(1024), v.T <= 14336 ? (size_t)v.T * 4 : 0, stream, v, L, status_dev,
+  // LDS-bin path: three workgroups (tile tables + status | block bases | tile order) in parallel
+  hipLaunchKernelGGL(hgs_k_scan, dim3(v.lds_bins ? 3 : 1), dim3(1024), v.T <= 14336 ? (size_t)v.T * 4 : 0, stream, v, L, status_dev,
                      status_host_mapped ? status_host : nullptr);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);

@@ -72,10 +72,16 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
   uint32_t* s_n = s_dyn;
   const int tid = threadIdx.x;
 
-  // (a) exclusive scan of per-chunk tiles_touched sums -> block_base
+  // Three independent jobs.  On the LDS-bin path they run as three workgroups of one launch
+  // (role = blockIdx.x) so that their latency chains overlap; on the global-atomic path (one
+  // workgroup) they run one after the other.
+  //   role 1: (a) block_base      role 0: (b) tile tables + status      role 2: (c) tile_order
+  const int role = (gridDim.x > 1) ? (int)blockIdx.x : -1;
   if (tid == 0) { carry_s = 0; carry3[0] = carry3[1] = carry3[2] = carry3[3] = 0; max_n_s = 0; }
   if (tid < 33) cls_hist[tid] = 0;
   __syncthreads();
+  // (a) exclusive scan of per-chunk tiles_touched sums -> block_base
+  if (role == -1 || role == 1)
   for (int base = 0; base < v.nblk; base += SCAN_NT) {
     const int k = base + tid;
     const uint32_t val = (k < v.nblk) ? L.block_sums[k] : 0u;
@@ -87,9 +93,10 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
     if (tid == 0) carry_s = carry + total;
     __syncthreads();
   }
-  const uint32_t R = carry_s;
+  if (role == 1) return;
 
   // (b) tile_start / bucket-state prefix / backward-workgroup prefix; class histogram
+  // (role 2 runs the same loop for the per-tile counts and the class histogram only)
   for (int base = 0; base < v.T; base += SCAN_NT * SCAN_ITEMS) {
     const int t0 = base + tid * SCAN_ITEMS;
     uint32_t n[SCAN_ITEMS], grp[HGS_ROW_GROUPS][SCAN_ITEMS];
@@ -116,7 +123,11 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
 #pragma unroll
       for (int k = 0; k < SCAN_ITEMS; ++k) n[k] = (t0 + k < v.T) ? L.tile_count[t0 + k] : 0u;
     }
-    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, mx = 0;
+    uint32_t mx = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) mx = max(mx, n[k]);
+    if (role != 2) {
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
     uint32_t p0[SCAN_ITEMS], p1[SCAN_ITEMS], p2[SCAN_ITEMS], p3[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -127,7 +138,6 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
       l1 += nb > 0 ? nb - 1 : 0;                               // stored bucket states
       l2 += nb;                                                // backward workgroups (1 per bucket)
       l3 += nseg > 1 ? nseg : 0;                               // segment planes of long lists
-      mx = max(mx, n[k]);
     }
     uint32_t ex[NSCAN], tot[NSCAN];
     const uint32_t lv[NSCAN] = {l0, l1, l2, l3};
@@ -152,7 +162,7 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
         uint32_t acc[SCAN_ITEMS] = {ts[0], ts[1], ts[2], ts[3]};
 #pragma unroll
         for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
-          *reinterpret_cast<uint4*>(L.tile_grp + (size_t)rg * v.T + t0) =
+          *reinterpret_cast<uint4*>(L.tile_gbase + (size_t)rg * v.T + t0) =
               make_uint4(acc[0], acc[1], acc[2], acc[3]);
 #pragma unroll
           for (int k = 0; k < SCAN_ITEMS; ++k) acc[k] += grp[rg][k];
@@ -174,7 +184,7 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
             uint32_t acc = ts[k];
 #pragma unroll
             for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
-              L.tile_grp[(size_t)rg * v.T + t] = acc;
+              L.tile_gbase[(size_t)rg * v.T + t] = acc;
               acc += grp[rg][k];
             }
           } else {
@@ -183,6 +193,9 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
         }
       }
     }
+    __syncthreads();
+    if (tid == 0) { carry3[0] = c0 + tot[0]; carry3[1] = c1 + tot[1]; carry3[2] = c2 + tot[2]; carry3[3] = c3 + tot[3]; }
+    }  // role != 2
     if (lds_tiles) {
 #pragma unroll
       for (int k = 0; k < SCAN_ITEMS; ++k)
@@ -201,17 +214,13 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
     }
     if (mx) atomicMax(&max_n_s, mx);
     __syncthreads();
-    if (tid == 0) { carry3[0] = c0 + tot[0]; carry3[1] = c1 + tot[1]; carry3[2] = c2 + tot[2]; carry3[3] = c3 + tot[3]; }
-    __syncthreads();
   }
-  if (tid == 0) {
+  if (tid == 0 && role != 2) {
+    const uint32_t R = carry3[0];            // sum of the tile counts = sum of tiles_touched
     L.tile_start[v.T] = carry3[0];
     L.tile_bstart[v.T] = carry3[1];
     L.tile_wgstart[v.T] = carry3[2];
     L.tile_msegstart[v.T] = carry3[3];
-    // heavy classes first; class 0 (empty tiles) last
-    uint32_t acc = 0;
-    for (int c = 32; c >= 0; --c) { cls_base[c] = acc; acc += cls_hist[c]; }
     hgs_status st;
     st.num_rendered = R;
     st.active_tiles = (uint32_t)v.T - cls_hist[0];
@@ -228,6 +237,11 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
       __threadfence_system();
     }
   }
+  if (role == 0) return;
+  if (tid == 0) {   // heavy classes first; class 0 (empty tiles) last
+    uint32_t acc = 0;
+    for (int c = 32; c >= 0; --c) { cls_base[c] = acc; acc += cls_hist[c]; }
+  }
   __syncthreads();
   // (c) tile_order: a permutation of all tiles, heavy first (order inside a class is free).
   // Non-empty tiles take a slot with one LDS atomic each; the empty class is handed out
@@ -235,7 +249,16 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
   for (int base = 0; base < v.T; base += SCAN_NT) {
     const int t = base + tid;
     uint32_t n = 0;
-    if (t < v.T) n = lds_tiles ? s_n[t] : L.tile_start[t + 1] - L.tile_start[t];
+    if (t < v.T) {
+      if (lds_tiles) {
+        n = s_n[t];
+      } else if (role == 2) {     // tile_start belongs to another workgroup of this launch
+#pragma unroll
+        for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) n += L.tile_grp[(size_t)rg * v.T + t];
+      } else {
+        n = L.tile_start[t + 1] - L.tile_start[t];
+      }
+    }
     const bool empty = (t < v.T) && (n == 0);
     const unsigned long long ball = __ballot(empty);
     uint32_t wbase = 0;
@@ -289,7 +312,7 @@ hgs_k_fill(View v, Layout L, const hgs_status* __restrict__ status) {
   if (status->overflow) return;
   const uint32_t* __restrict__ base_row = L.hist + (size_t)blockIdx.x * v.T;
   const int rpg = (v.nwg + HGS_ROW_GROUPS - 1) / HGS_ROW_GROUPS;
-  const uint32_t* __restrict__ grp_row = L.tile_grp + (size_t)(blockIdx.x / rpg) * v.T;
+  const uint32_t* __restrict__ grp_row = L.tile_gbase + (size_t)(blockIdx.x / rpg) * v.T;
   for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_cur[t] = grp_row[t] + base_row[t];
   __syncthreads();
   for (int c = 0; c < v.cpw; ++c) {

@@ -32,9 +32,13 @@
                                // measured 1 / 2 / 4: 96 / 98 / 100 us (100k Gaussians), 165 / 207 / 231 us (500k)
 #endif
 #define HGS_ROW_GROUPS 4       // histogram row groups scanned in parallel by hgs_k_colscan
+#ifndef HGS_SEG
 #define HGS_SEG 256            // entries per forward segment (list-parallel blend), multiple of 64
+#endif
+#ifndef HGS_SEG_THRESH
 #define HGS_SEG_THRESH 1024    // only tile lists longer than this are cut into segments: short
                                // lists blend faster in one piece (measured)
+#endif
 #define HGS_SEG_PLANES 7       // per-segment pixel planes: C0 C1 C2 D W Tend(signed) last(bits)
 #define HGS_NEAR_Z 0.2f
 #define HGS_ALPHA_MIN (1.0f / 255.0f)
@@ -80,7 +84,8 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint2* seg_item;            // [<= 2C/HGS_SEG + 4] (tile, segment) of every segment of the long lists
   uint32_t* wg_tile;          // [<= C + C/64] tile of every backward workgroup (written by the forward)
   uint32_t* hist;          // [nwg][T] per-workgroup tile histograms -> exclusive bases
-  uint32_t* tile_grp;      // [HGS_ROW_GROUPS][T] row-group totals -> absolute group bases
+  uint32_t* tile_grp;      // [HGS_ROW_GROUPS][T] row-group totals (colscan)
+  uint32_t* tile_gbase;    // [HGS_ROW_GROUPS][T] absolute base of each row group in the tile's list (scan)
   unsigned long long* keys;
   SortRec* recs;
   float* bstate;
