@@ -290,6 +290,31 @@ def test_sort_class_hint_violation_is_reported_and_valid_hint_is_exact():
     check_images(rc2, oc, od, oa)
 
 
+def test_long_list_paths_agree_bitwise():
+    """Long lists are blended in segments.  With no hint the segment transmittances come from the
+    hgs_k_fwd_segT pre-pass; with a hint <= 12 segments every segment recomputes its
+    predecessors itself.  Same arithmetic => same bits, forward and backward, and both match
+    the oracle."""
+    sc = make_scene(P=2600, seed=77, H=32, W=32, spread=0.02, scale=0.01, dist=2.0)
+    g = torch.Generator().manual_seed(5)
+    sc["opacities"] = 0.01 + 0.05 * torch.rand(2600, 1, generator=g)      # deep lists, late termination
+    a = RawCall(sc, capacity=1 << 17, max_tile_hint=0)
+    assert a.forward() == 0 and a.status[4] == 0
+    longest = a.status[6]
+    assert 1024 < longest <= 3072, longest                  # several segments, recompute path allowed
+    b = RawCall(sc, capacity=1 << 17, max_tile_hint=longest)
+    assert b.forward() == 0 and b.status[4] == 0
+    for x, y in ((a.color, b.color), (a.depth, b.depth), (a.alpha, b.alpha)):
+        assert torch.equal(x, y)
+    oc, orad, od, oa, _, _ = oracle_forward(sc)
+    check_images(b, oc, od, oa)
+    grads = rand_grads(32, 32, seed=8)
+    ga, gb = a.backward(*grads), b.backward(*grads)
+    for k in ga:
+        if ga[k] is not None:
+            assert torch.equal(ga[k], gb[k]), k
+
+
 def test_backward_without_host_status_matches():
     """hgs_backward(status=NULL): capacity-bounded grid + device-side status."""
     sc = make_scene(P=900, sh_degree=1, seed=61, H=48, W=64, spread=0.1)
