@@ -243,7 +243,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": dom_bytes, "avg_us": stage_us[dom],
-                         "note": "blend kernels are VALU-bound (no dense contraction, no MFMA); "
+                         "note": "blend kernels are VALU/MFMA-issue-bound (the backward pixel sums run on fp32 MFMA); "
                                  "HBM fraction reported as BASELINE.json asks",
                          "path": {"algorithmic_bytes": path_bytes, "gpu_us_sum": gpu_us,
                                   "achieved": path_bytes / (gpu_us * 1e-6) / 1e9,
