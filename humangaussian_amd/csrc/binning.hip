@@ -383,56 +383,78 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         L.seg_item[ms0 + sg] = make_uint2((uint32_t)t, sg);
     }
   }
-  for (uint32_t k = threadIdx.x; k < n; k += nt) {
-    const uint32_t idx = (uint32_t)sorted[k];
-    const uint4* gp = reinterpret_cast<const uint4*>(&L.geom[idx]);
-    const uint4 g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3];
-    // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | g3: offset radius ..
-    const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
-    const uint32_t entry = g3.x + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
-    const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
-    const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
-    const float op = __uint_as_float(g1.y);
-    // Conservative quadrant cull: a pixel can only pass alpha >= 1/255 inside the ellipse
-    // q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= tau, tau = 2 ln(255 op).  A quadrant (its 8x8 pixel
-    // centres span a rectangle) is kept iff the minimum of q over that rectangle is <= tau: the
-    // minimum of a convex quadratic over a box is 0 if the centre is inside, else it lies on an
-    // edge, where the free coordinate's optimum is the clamped 1-D minimiser.  (This exact test
-    // keeps 9 % fewer (entry, quadrant) pairs than the ellipse's bounding box on the 100k-Gaussian
-    // scene - tools/cull_stats.py - and every pair it drops has no live pixel.)  Margins absorb
-    // rounding; a set bit never changes results, a cleared bit must be provably empty.
-    uint32_t mask = 0;
-    const float a255 = 255.0f * op;
-    if (a255 >= 0.999f) {
-      const float tau = 2.0f * __logf(fmaxf(a255, 1.0f)) * 1.001f + 0.02f;
-      const float detc = ca * cc - cb * cb;
-      if (detc > 0.0f && cc > 0.0f && ca > 0.0f) {
-        const float bc = cb / cc, ba = cb / ca;
-        auto qf = [&](float px, float py) {
-          const float dx = px - mx, dy = py - my;
-          return ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy;
-        };
+  // GU records per thread in flight: the 64 B geom gathers are dependent random reads (~1-2 us
+  // each); issued one at a time they dominated the sort kernel of the heaviest tile
+  constexpr int GU = 4;
+  for (uint32_t kb = threadIdx.x; kb < n; kb += (uint32_t)nt * GU) {
+    uint32_t idxv[GU];
+    uint4 q0[GU], q1[GU], q2[GU], q3[GU];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float qx0 = x0 + (float)((q & 1) * 8), qy0 = y0 + (float)((q >> 1) * 8);
-          const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
-          float best = qf(fminf(fmaxf(mx, qx0), qx1), fminf(fmaxf(my, qy0), qy1));   // 0 when inside
-          best = fminf(best, qf(qx0, fminf(fmaxf(my - bc * (qx0 - mx), qy0), qy1)));
-          best = fminf(best, qf(qx1, fminf(fmaxf(my - bc * (qx1 - mx), qy0), qy1)));
-          best = fminf(best, qf(fminf(fmaxf(mx - ba * (qy0 - my), qx0), qx1), qy0));
-          best = fminf(best, qf(fminf(fmaxf(mx - ba * (qy1 - my), qx0), qx1), qy1));
-          const bool hit = best <= tau * 1.0005f + 1e-3f * best;
-          mask |= hit ? (1u << q) : 0u;
-        }
-      } else {
-        mask = 0xfu;   // degenerate conic: never cull
+    for (int u = 0; u < GU; ++u) {
+      const uint32_t k = kb + (uint32_t)u * nt;
+      idxv[u] = (k < n) ? (uint32_t)sorted[k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const uint32_t k = kb + (uint32_t)u * nt;
+      if (k < n) {
+        const uint4* gp = reinterpret_cast<const uint4*>(&L.geom[idxv[u]]);
+        q0[u] = gp[0]; q1[u] = gp[1]; q2[u] = gp[2]; q3[u] = gp[3];
       }
     }
-    uint4* dst = reinterpret_cast<uint4*>(&L.recs[start + k]);
-    const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
-    dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
-    dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-    dst[2] = make_uint4(g2.x, g2.y, entry, (idx & 0x0fffffffu) | (mask << 28));
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const uint32_t k = kb + (uint32_t)u * nt;
+      if (k >= n) continue;
+      const uint32_t idx = idxv[u];
+      const uint4 g0 = q0[u], g1 = q1[u], g2 = q2[u], g3 = q3[u];
+      // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | g3: offset radius ..
+      const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
+      const uint32_t entry = g3.x + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+      const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
+      const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
+      const float op = __uint_as_float(g1.y);
+      // Conservative quadrant cull: a pixel can only pass alpha >= 1/255 inside the ellipse
+      // q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= tau, tau = 2 ln(255 op).  A quadrant (its 8x8 pixel
+      // centres span a rectangle) is kept iff the minimum of q over that rectangle is <= tau: the
+      // minimum of a convex quadratic over a box is 0 if the centre is inside, else it lies on an
+      // edge, where the free coordinate's optimum is the clamped 1-D minimiser.  (This exact test
+      // keeps 9 % fewer (entry, quadrant) pairs than the ellipse's bounding box on the 100k-Gaussian
+      // scene - tools/cull_stats.py - and every pair it drops has no live pixel.)  Margins absorb
+      // rounding; a set bit never changes results, a cleared bit must be provably empty.
+      uint32_t mask = 0;
+      const float a255 = 255.0f * op;
+      if (a255 >= 0.999f) {
+        const float tau = 2.0f * __logf(fmaxf(a255, 1.0f)) * 1.001f + 0.02f;
+        const float detc = ca * cc - cb * cb;
+        if (detc > 0.0f && cc > 0.0f && ca > 0.0f) {
+          const float bc = cb / cc, ba = cb / ca;
+          auto qf = [&](float px, float py) {
+            const float dx = px - mx, dy = py - my;
+            return ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy;
+          };
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float qx0 = x0 + (float)((q & 1) * 8), qy0 = y0 + (float)((q >> 1) * 8);
+            const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
+            float best = qf(fminf(fmaxf(mx, qx0), qx1), fminf(fmaxf(my, qy0), qy1));   // 0 when inside
+            best = fminf(best, qf(qx0, fminf(fmaxf(my - bc * (qx0 - mx), qy0), qy1)));
+            best = fminf(best, qf(qx1, fminf(fmaxf(my - bc * (qx1 - mx), qy0), qy1)));
+            best = fminf(best, qf(fminf(fmaxf(mx - ba * (qy0 - my), qx0), qx1), qy0));
+            best = fminf(best, qf(fminf(fmaxf(mx - ba * (qy1 - my), qx0), qx1), qy1));
+            const bool hit = best <= tau * 1.0005f + 1e-3f * best;
+            mask |= hit ? (1u << q) : 0u;
+          }
+        } else {
+          mask = 0xfu;   // degenerate conic: never cull
+        }
+      }
+      uint4* dst = reinterpret_cast<uint4*>(&L.recs[start + k]);
+      const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
+      dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
+      dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
+      dst[2] = make_uint4(g2.x, g2.y, entry, (idx & 0x0fffffffu) | (mask << 28));
+    }
   }
 }
 
@@ -589,11 +611,11 @@ __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, in
 
 }  // namespace
 
-// All tiles with 1..4096 entries in ONE launch (256 threads; 4, 8 or 16 keys per thread by
+// All tiles with 1..4096 entries in ONE launch (512 threads; 2, 4 or 8 keys per thread by
 // list length): each sort is latency-bound on its own stage chain, so the few long lists
 // overlap with the many short ones instead of running in a second kernel after them.
 #ifndef HGS_SORT_NT
-#define HGS_SORT_NT 256
+#define HGS_SORT_NT 512
 #endif
 extern "C" __global__ void __launch_bounds__(HGS_SORT_NT)
 hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
