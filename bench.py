@@ -187,6 +187,7 @@ def main():
             traffic = None
     path_bytes = P * (292 + 36 * M) + 164 * R + 52 * npix + 8 * T
     gpu_us = sum(stage_us.values())
+    blend_us = stage_us["render_fwd"] + (0.0 if args.forward_only else stage_us.get("render_bwd", 0.0))
 
     # ---------------- CPU baseline: the PyTorch oracle on the host cores (rank 0, N=1).
     # Bounded sample: per-Gaussian preprocess + binning of the WHOLE cloud, blending fwd+bwd
@@ -247,7 +248,16 @@ def main():
                                  "HBM fraction reported as BASELINE.json asks",
                          "path": {"algorithmic_bytes": path_bytes, "gpu_us_sum": gpu_us,
                                   "achieved": path_bytes / (gpu_us * 1e-6) / 1e9,
-                                  "frac": path_bytes / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS}},
+                                  "frac": path_bytes / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                         # secondary roofline: 256 R pixel-Gaussian pairs, ~25 flop
+                         # forward + ~80 flop backward per pair, against the fp32 vector/MFMA peak
+                         "fp32": {"algorithmic_flops": 256.0 * R * ((25 if args.forward_only else 105)),
+                                  "achieved_tflops": 256.0 * R * (25 if args.forward_only else 105)
+                                  / (blend_us * 1e-6) / 1e12,
+                                  "peak_tflops": 157.3,
+                                  "frac": 256.0 * R * (25 if args.forward_only else 105)
+                                  / (blend_us * 1e-6) / 1e12 / 157.3,
+                                  "kernels": "render_fwd + render_bwd"}},
             "stage_us": stage_us,
             "host": host_info,
             "cpu_baseline": cpu,

@@ -12,6 +12,7 @@
 #include "preprocess.hip"
 #include "binning.hip"
 #include "render_fwd.hip"
+#include "knn.hip"
 
 // render_bwd.hip is a separate translation unit (different optimisation flags)
 extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*,
@@ -168,7 +169,17 @@ bool settings_ok(const hgs_settings* s) {
 
 extern "C" {
 
-int hgs_abi_version(void) { return 6; }
+int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* stream_) {
+  if (P < 0) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!points || !mean_dist2) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(hgs_k_knn3, dim3((P + 255) / 256), dim3(256), 0, stream, (int)P, points, mean_dist2);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+int hgs_abi_version(void) { return 7; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;

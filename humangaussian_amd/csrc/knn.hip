@@ -1,0 +1,49 @@
+// knn.hip - mean squared distance to the 3 nearest neighbours of every point: the
+// `simple_knn._C.distCUDA2` the reference calls when it creates a cloud from a point set
+// (/root/reference/gaussiansplatting/scene/gaussian_model.py:134, gs_renderer.py:386-389;
+// semantics in submodules/simple-knn/simple_knn.cu:147-183: neighbours exclude the point's own
+// INDEX, duplicates at distance 0 count, result = (d0 + d1 + d2) / 3 with d0 <= d1 <= d2).
+//
+// Upstream sorts by Morton code and prunes 1024-point boxes.  This runs once per cloud, not per
+// step, so the MI355X version is the exact, sort-free form: every workgroup owns 256 query points
+// (2 per lane would only help above ~1M points) and streams the whole set through LDS in 1024-point
+// float4 tiles; a lane keeps its three best distances in registers with a branch-free insert.
+// Cost: P^2 pairs x ~14 VALU instructions: 2.5 ms at 100k points, 60 ms at 500k.
+// Roofline: VALU; HBM traffic P * (P / 256) * 16 B reads, all L2 hits after the first pass.
+#include "hgs_common.h"
+
+#define HGS_KNN_TILE 1024
+
+extern "C" __global__ void __launch_bounds__(256)
+hgs_k_knn3(int P, const float* __restrict__ pts, float* __restrict__ out) {
+  __shared__ float4 tile[HGS_KNN_TILE];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  if (i < P) { px = pts[3 * (size_t)i]; py = pts[3 * (size_t)i + 1]; pz = pts[3 * (size_t)i + 2]; }
+  const float big = 3.402823466e+38f;
+  float b0 = big, b1 = big, b2 = big;
+  for (int base = 0; base < P; base += HGS_KNN_TILE) {
+#pragma unroll
+    for (int k = tid; k < HGS_KNN_TILE; k += 256) {
+      const int j = base + k;
+      tile[k] = (j < P) ? make_float4(pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2], 0.f)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int cnt = min(HGS_KNN_TILE, P - base);
+    const int self = i - base;                      // position of this lane's own point in the tile, if any
+#pragma unroll 4
+    for (int k = 0; k < cnt; ++k) {
+      const float4 q = tile[k];                     // LDS broadcast
+      const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+      float d = dx * dx + dy * dy + dz * dz;
+      d = (k == self) ? big : d;                    // a point is not its own neighbour
+      const float t0 = fminf(b0, d), c0 = fmaxf(b0, d);
+      const float t1 = fminf(b1, c0), c1 = fmaxf(b1, c0);
+      b0 = t0; b1 = t1; b2 = fminf(b2, c1);
+    }
+    __syncthreads();
+  }
+  if (i < P) out[i] = ((b0 + b1) + b2) / 3.0f;
+}

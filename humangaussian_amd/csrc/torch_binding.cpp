@@ -404,6 +404,24 @@ Tensor mark_visible(const Tensor& positions, const Tensor& bg, const Tensor& vie
   return present.to(at::kBool);
 }
 
+// replaces simple_knn._C.distCUDA2: mean squared distance to the 3 nearest neighbours
+Tensor knn_mean_dist2(const Tensor& points) {
+  at::NoGradGuard ng;
+  const c10::Device dev = points.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  if (points.dim() != 2 || points.size(1) != 3) throw std::runtime_error("points must have dimensions (num_points, 3)");
+  DeviceSwitch guard(dev.index());
+  const Tensor pts = f32c(points, dev, "points");
+  const int64_t P = pts.size(0);
+  Tensor out = at::empty({P}, at::TensorOptions().dtype(at::kFloat).device(dev));
+  if (P > 0) {
+    const int rc = hgs_knn_mean_dist2((int32_t)P, pts.data_ptr<float>(), out.data_ptr<float>(),
+                                      c10::hip::getCurrentHIPStream(dev.index()).stream());
+    check_rc(rc, "hgs_knn_mean_dist2");
+  }
+  return out;
+}
+
 void set_stage_events(const c10::optional<std::vector<int64_t>>& fwd, const c10::optional<std::vector<int64_t>>& bwd) {
   g_stage_fwd.clear();
   g_stage_bwd.clear();
@@ -439,6 +457,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "torch binding of libhgs_rast.so (include/hgs_rast.h): autograd node, capacity logic, the one host wait";
   m.def("rasterize", &rasterize, py::call_guard<py::gil_scoped_release>());
   m.def("mark_visible", &mark_visible, py::call_guard<py::gil_scoped_release>());
+  m.def("knn_mean_dist2", &knn_mean_dist2, py::call_guard<py::gil_scoped_release>());
   m.def("set_async", [](bool on) { g_async = on; });
   m.def("get_async", []() { return g_async; });
   m.def("set_stage_events", &set_stage_events);

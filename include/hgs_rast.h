@@ -138,6 +138,13 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M,
 int hgs_mark_visible(const hgs_settings* s, int32_t P, const float* means3D,
                      uint8_t* present, void* stream);
 
+/* Mean squared distance of every point to its 3 nearest neighbours (own index excluded,
+ * duplicates count): replaces `simple_knn._C.distCUDA2(points)`, which the reference calls to
+ * initialise the scales of a new cloud
+ * (/root/reference/gaussiansplatting/scene/gaussian_model.py:20,134; gs_renderer.py:14,386-389;
+ * kernel submodules/simple-knn/simple_knn.cu:147-183).  points: [P][3] fp32, mean_dist2: [P]. */
+int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* stream);
+
 /* Library / ABI version (bumped on any signature change). */
 int hgs_abi_version(void);
 

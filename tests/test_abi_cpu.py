@@ -78,6 +78,19 @@ def test_python_api_mirrors_reference_names_and_errors():
           scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
 
 
+def test_simple_knn_module_name_resolves():
+    """`from simple_knn._C import distCUDA2` (gaussian_model.py:20, gs_renderer.py:14) resolves to
+    the HIP implementation; CPU tensors fail loudly."""
+    from simple_knn._C import distCUDA2
+    from humangaussian_amd.knn import distCUDA2 as impl
+    assert distCUDA2 is impl
+    with pytest.raises(RuntimeError, match="HIP device"):
+        distCUDA2(torch.zeros(8, 3))
+    lib = _lib.load()
+    assert lib.hgs_knn_mean_dist2(-1, None, None, None) == -1
+    assert lib.hgs_knn_mean_dist2(0, None, None, None) == 0
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "humangaussian_amd")
     for dirpath, _, files in os.walk(pkg):

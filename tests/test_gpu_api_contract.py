@@ -181,3 +181,30 @@ def test_gaussiandreamer_step_access_pattern():
         g, = torch.autograd.grad(li, pc._xyz)
         acc += g
     assert float((acc - total).abs().max()) <= 2e-3 * float(total.abs().max())
+
+
+@pytest.mark.gpu
+def test_dist_cuda2_matches_kdtree_reference():
+    """simple_knn._C.distCUDA2 replacement: mean squared distance to the 3 nearest neighbours
+    (own index excluded, duplicates count) against a float64 k-d tree; call sites
+    gaussian_model.py:134 / gs_renderer.py:386-389 clamp the result and take log(sqrt())."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(3)
+    for n in (4, 257, 5000):
+        pts = rng.normal(0, 0.4, (n, 3)).astype(np.float32)
+        if n > 100:
+            pts[10] = pts[11]                     # exact duplicates: distance 0 counts
+            pts[20] = pts[21] = pts[22]
+        d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+        ref = (d[:, 1:] ** 2).mean(1)
+        got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy().astype(np.float64)
+        assert got.shape == (n,)
+        assert np.allclose(got, ref, rtol=2e-5, atol=1e-9), (n, np.abs(got - ref).max())
+    assert distCUDA2(torch.zeros(0, 3).cuda()).shape == (0,)
+    # the synthetic-cloud initialiser uses the same definition on the CPU
+    from humangaussian_amd import synth
+    pts = synth.humanoid_points(3000, seed=1)
+    got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    assert np.allclose(got, synth.mean_knn_dist2(pts), rtol=2e-5, atol=1e-9)
