@@ -33,13 +33,24 @@
 // throughput-bound, where v_pk_* packing only adds register moves).
 #include "hgs_common.h"
 
-#define HGS_BWD_BATCH 8                  // records per MFMA batch (8 records x {k, wgt} = 16 columns)
+#ifndef HGS_BWD_PREFETCH
+#define HGS_BWD_PREFETCH 1               // fetch the next quadrant's pixel inputs during the current one
+#endif
+#ifndef HGS_BWD_BATCH
+#define HGS_BWD_BATCH 8                  // records per MFMA batch (8 records x {k, wgt} = 16 columns).
+#endif                                   // 4 (half-empty MFMAs, 7.8 KB LDS, 5 waves/SIMD) was measured:
+                                         // 96 -> 127 us - the fp32 MFMA time is not hidden behind VALU work
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 #define HGS_PART_FLOATS 10               // sums per (entry, quadrant)
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
 
-extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_WAVES)
+#ifdef HGS_BWD_WAVES_PER_EU
+#define HGS_BWD_OCC __attribute__((amdgpu_waves_per_eu(HGS_BWD_WAVES_PER_EU, HGS_BWD_WAVES_PER_EU)))
+#else
+#define HGS_BWD_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_WAVES) HGS_BWD_OCC
 hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const SortRec* __restrict__ recs_all,
                  const float* __restrict__ bstate, const float* __restrict__ segP,
@@ -55,12 +66,15 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   // work items shorter (at 5.6k buckets on 4096 wave slots the tail of long items dominates).
   __shared__ float4 s_rec_all[HGS_BWD_WAVES][3 * HGS_BUCKET];
   __shared__ __attribute__((aligned(16))) float s_part_all[HGS_BWD_WAVES][HGS_BUCKET][HGS_PART_FLOATS];   // [wave][slot][value]
-  __shared__ __attribute__((aligned(16))) float stage_all[HGS_BWD_WAVES][16 * HGS_STAGE_STRIDE];          // 16 columns x 64 pixels
+  __shared__ __attribute__((aligned(16))) float stage_all[HGS_BWD_WAVES][2 * HGS_BWD_BATCH * HGS_STAGE_STRIDE];   // 2 B columns x 64 pixels
   constexpr int QW = 4 / HGS_BWD_WAVES;                      // quadrants per wave
   const int h = (HGS_BWD_WAVES == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   float4* __restrict__ s_rec = s_rec_all[h];
   float (*__restrict__ s_part)[HGS_PART_FLOATS] = s_part_all[h];
   float* __restrict__ stage = stage_all[h];
+  // scratch for the basis transposition: 11 rows; the stage if it is large enough, else the record
+  // buffer (768 floats), which is filled only after the basis has been read back
+  float* __restrict__ basis = (2 * HGS_BWD_BATCH >= 11) ? stage : reinterpret_cast<float*>(s_rec);
 
   // ---- which (tile, bucket)?  The forward left the tile of every backward workgroup in wg_tile
   // (a binary search over tile_wgstart here cost 12 dependent loads).
@@ -172,7 +186,9 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   }
   int jnext = 0;
   while (jnext < QW && cntq[jnext] == 0) ++jnext;
+#if HGS_BWD_PREFETCH
   PixRaw nxt = fetch(w_begin + min(jnext, QW - 1));
+#endif
 
 #pragma unroll 1
   for (int j = jnext; j < QW; j = jnext) {
@@ -184,11 +200,17 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
     const int px = tile_x0 + ((w & 1) << 3) + (lane & 7), py = tile_y0 + ((w >> 1) << 3) + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
+#if HGS_BWD_PREFETCH
     const PixRaw cur = nxt;
+#else
+    const PixRaw cur = fetch(w);
+#endif
     const uint32_t nc = ncq[j];
     jnext = j + 1;
     while (jnext < QW && cntq[jnext] == 0) ++jnext;
+#if HGS_BWD_PREFETCH
     if (jnext < QW) nxt = fetch(w_begin + jnext);    // in flight during this quadrant's loop
+#endif
     const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2, gd = cur.gd, ga = cur.ga;
     const float fp = cur.o0 * g0 + cur.o1 * g1 + cur.o2 * g2 + cur.od * gd + cur.oa * ga;
     // running state at the bucket start.  A pixel with n_contrib <= q0 finished before this
@@ -216,33 +238,35 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       // every lane writes ITS pixel's ten basis values as one column of the stage; every lane then
       // reads the row it supplies to the MFMA (row 10 = zeros for the six unused rows of A)
       const float ub = (float)(lane & 7) - 3.5f, vb = (float)(lane >> 3) - 3.5f;
-      stage[0 * HGS_STAGE_STRIDE + lane] = 1.0f;
-      stage[1 * HGS_STAGE_STRIDE + lane] = ub;
-      stage[2 * HGS_STAGE_STRIDE + lane] = vb;
-      stage[3 * HGS_STAGE_STRIDE + lane] = ub * ub;
-      stage[4 * HGS_STAGE_STRIDE + lane] = ub * vb;
-      stage[5 * HGS_STAGE_STRIDE + lane] = vb * vb;
-      stage[6 * HGS_STAGE_STRIDE + lane] = g0;
-      stage[7 * HGS_STAGE_STRIDE + lane] = g1;
-      stage[8 * HGS_STAGE_STRIDE + lane] = g2;
-      stage[9 * HGS_STAGE_STRIDE + lane] = gd;
-      stage[10 * HGS_STAGE_STRIDE + lane] = 0.0f;
-    }
-    if (hit) {
-      s_rec[3 * pos + 0] = c0;
-      s_rec[3 * pos + 1] = c1;
-      s_rec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float((uint32_t)lane));   // slot in bucket
+      basis[0 * HGS_STAGE_STRIDE + lane] = 1.0f;
+      basis[1 * HGS_STAGE_STRIDE + lane] = ub;
+      basis[2 * HGS_STAGE_STRIDE + lane] = vb;
+      basis[3 * HGS_STAGE_STRIDE + lane] = ub * ub;
+      basis[4 * HGS_STAGE_STRIDE + lane] = ub * vb;
+      basis[5 * HGS_STAGE_STRIDE + lane] = vb * vb;
+      basis[6 * HGS_STAGE_STRIDE + lane] = g0;
+      basis[7 * HGS_STAGE_STRIDE + lane] = g1;
+      basis[8 * HGS_STAGE_STRIDE + lane] = g2;
+      basis[9 * HGS_STAGE_STRIDE + lane] = gd;
+      basis[10 * HGS_STAGE_STRIDE + lane] = 0.0f;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float Areg[16];
     {
-      const float* arow = stage + min(mrow, 10) * HGS_STAGE_STRIDE + 4 * kk;
+      const float* arow = basis + min(mrow, 10) * HGS_STAGE_STRIDE + 4 * kk;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float4 aq = *reinterpret_cast<const float4*>(arow + 16 * c);
         Areg[4 * c + 0] = aq.x; Areg[4 * c + 1] = aq.y; Areg[4 * c + 2] = aq.z; Areg[4 * c + 3] = aq.w;
       }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                 // basis reads done: its scratch may be overwritten
+    if (hit) {
+      s_rec[3 * pos + 0] = c0;
+      s_rec[3 * pos + 1] = c1;
+      s_rec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float((uint32_t)lane));   // slot in bucket
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -255,13 +279,13 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float d0 = a0[0] + a1[0], d1 = a0[1] + a1[1], d2 = a0[2] + a1[2], d3 = a0[3] + a1[3];
       // rows 4, 5 (uv, v^2 moments) of column n live in lane 16 + n: bring them to lane n
       const float k11 = __shfl(d0, (lane + 16) & 63, 64), k02 = __shfl(d1, (lane + 16) & 63, 64);
-      const uint32_t rsel = (uint32_t)lane & 7u;     // record of the batch this lane finishes
+      const uint32_t rsel = (uint32_t)lane & (HGS_BWD_BATCH - 1);   // record of the batch this lane finishes
       if (rsel >= nrec) return;
       const float4 q0r = s_rec[3 * (k0 + rsel) + 0];
       const float4 q1r = s_rec[3 * (k0 + rsel) + 1];
       const uint32_t slot_l = __float_as_uint(s_rec[3 * (k0 + rsel) + 2].w);
       float* dst = &s_part[slot_l][0];
-      if (lane < 8) {
+      if (lane < HGS_BWD_BATCH) {
         const float a = q0r.x - cxq, bb = q0r.y - cyq;
         const float k00 = d0, k10 = d1, k01 = d2, k20 = d3;
         const float sdx = __builtin_fmaf(a, k00, -k10), sdy = __builtin_fmaf(bb, k00, -k01);
@@ -276,11 +300,11 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         d2p[0] = make_float2(o0.x + x0, o0.y + x1);
         d2p[1] = make_float2(o1.x + sxx, o1.y + sxy);
         d2p[2] = make_float2(o2.x + syy, o2.y + k00);
-      } else if (lane >= 24 && lane < 32) {          // rows 6, 7 of columns 8..15: sum wgt g_C0, g_C1
+      } else if (lane >= 16 + HGS_BWD_BATCH && lane < 16 + 2 * HGS_BWD_BATCH) {   // rows 6, 7 of columns B..2B-1: sum wgt g_C0, g_C1
         float2* d2p = reinterpret_cast<float2*>(dst + 6);
         const float2 o = *d2p;
         *d2p = make_float2(o.x + d2, o.y + d3);
-      } else if (lane >= 40 && lane < 48) {          // rows 8, 9 of columns 8..15: sum wgt g_C2, g_D
+      } else if (lane >= 32 + HGS_BWD_BATCH && lane < 32 + 2 * HGS_BWD_BATCH) {   // rows 8, 9 of columns B..2B-1: sum wgt g_C2, g_D
         float2* d2p = reinterpret_cast<float2*>(dst + 8);
         const float2 o = *d2p;
         *d2p = make_float2(o.x + d0, o.y + d1);
@@ -328,7 +352,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       float4 bq[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        bq[c] = *reinterpret_cast<const float4*>(&stage[mrow * HGS_STAGE_STRIDE + 16 * c + 4 * kk]);
+        bq[c] = *reinterpret_cast<const float4*>(&stage[min(mrow, 2 * HGS_BWD_BATCH - 1) * HGS_STAGE_STRIDE + 16 * c + 4 * kk]);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();               // the next batch overwrites the stage
       HGS_TACC(1);
