@@ -112,6 +112,22 @@ __device__ __forceinline__ void project_cov(const View& v, const float* __restri
   o.det = o.a * o.c - o.b * o.b;
 }
 
+// One Gaussian's (M,3) SH block as 16 B loads into registers.  A thread's block is 12 M bytes
+// (192 B at degree 3), so scalar loads cost 48 uncoalescable instructions per thread; when 3 M is
+// a multiple of 4 the block is 16 B aligned and twelve dwordx4 loads do (SH degree 3:
+// preprocess_fwd 90 -> ~45 us at 500k Gaussians).  `sh48` must be indexed with constants only.
+__device__ __forceinline__ bool sh_block_vectorisable(int M) { return ((M * 3) & 3) == 0 && M <= 16; }
+__device__ __forceinline__ void load_sh_block(const float* __restrict__ src, int M, float (&sh48)[48]) {
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  const int nq = (M * 3) >> 2;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < nq) t = s4[q];
+    sh48[4 * q + 0] = t.x; sh48[4 * q + 1] = t.y; sh48[4 * q + 2] = t.z; sh48[4 * q + 3] = t.w;
+  }
+}
+
 // SH basis evaluation for one Gaussian; sh points at its (M,3) block.
 __device__ __forceinline__ void eval_sh(int deg, const float* __restrict__ sh, float x,
                                         float y, float z, float out[3]) {
@@ -208,7 +224,13 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float ddx = x - cp[0], ddy = y - cp[1], ddz = z - cp[2];
     const float n = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
     float col[3];
-    eval_sh(v.D, shs + (size_t)i * v.M * 3, ddx / n, ddy / n, ddz / n, col);
+    if (sh_block_vectorisable(v.M)) {
+      float sh48[48];
+      load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
+      eval_sh(v.D, sh48, ddx / n, ddy / n, ddz / n, col);
+    } else {
+      eval_sh(v.D, shs + (size_t)i * v.M * 3, ddx / n, ddy / n, ddz / n, col);
+    }
     uint32_t cl = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -461,7 +483,14 @@ hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float ox = x - cp[0], oy = y - cp[1], oz = z - cp[2];
       const float n = sqrtf(ox * ox + oy * oy + oz * oz);
       const float dx = ox / n, dy = oy / n, dz = oz / n;
-      const float* sh = shs + (size_t)i * v.M * 3;
+      float sh48[48];
+      if (sh_block_vectorisable(v.M)) {
+        load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
+      } else {
+        const float* shp = shs + (size_t)i * v.M * 3;
+#pragma unroll
+        for (int k = 3; k < 48; ++k) sh48[k] = (k < 3 * ncoef) ? shp[k] : 0.f;   // degree >= 1 terms only
+      }
       float basis[16];
       basis[0] = SH_C0;
       float ddir[3] = {0.f, 0.f, 0.f};
@@ -469,9 +498,9 @@ hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         basis[1] = -SH_C1 * dy; basis[2] = SH_C1 * dz; basis[3] = -SH_C1 * dx;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          ddir[0] += draw[ch] * (-SH_C1 * sh[9 + ch]);
-          ddir[1] += draw[ch] * (-SH_C1 * sh[3 + ch]);
-          ddir[2] += draw[ch] * (SH_C1 * sh[6 + ch]);
+          ddir[0] += draw[ch] * (-SH_C1 * sh48[9 + ch]);
+          ddir[1] += draw[ch] * (-SH_C1 * sh48[3 + ch]);
+          ddir[2] += draw[ch] * (SH_C1 * sh48[6 + ch]);
         }
         if (v.D > 1) {
           const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
@@ -481,7 +510,7 @@ hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
 #pragma unroll
           for (int ch = 0; ch < 3; ++ch) {
-            const float s4 = sh[12 + ch], s5 = sh[15 + ch], s6 = sh[18 + ch], s7 = sh[21 + ch], s8 = sh[24 + ch];
+            const float s4 = sh48[12 + ch], s5 = sh48[15 + ch], s6 = sh48[18 + ch], s7 = sh48[21 + ch], s8 = sh48[24 + ch];
             ddir[0] += draw[ch] * (SH_C2[0] * dy * s4 + SH_C2[2] * -2.f * dx * s6 + SH_C2[3] * dz * s7 + SH_C2[4] * 2.f * dx * s8);
             ddir[1] += draw[ch] * (SH_C2[0] * dx * s4 + SH_C2[1] * dz * s5 + SH_C2[2] * -2.f * dy * s6 + SH_C2[4] * -2.f * dy * s8);
             ddir[2] += draw[ch] * (SH_C2[1] * dy * s5 + SH_C2[2] * 4.f * dz * s6 + SH_C2[3] * dx * s7);
@@ -496,8 +525,8 @@ hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
             basis[15] = SH_C3[6] * dx * (xx - 3.f * yy);
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-              const float s9 = sh[27 + ch], s10 = sh[30 + ch], s11 = sh[33 + ch], s12 = sh[36 + ch];
-              const float s13 = sh[39 + ch], s14 = sh[42 + ch], s15 = sh[45 + ch];
+              const float s9 = sh48[27 + ch], s10 = sh48[30 + ch], s11 = sh48[33 + ch], s12 = sh48[36 + ch];
+              const float s13 = sh48[39 + ch], s14 = sh48[42 + ch], s15 = sh48[45 + ch];
               ddir[0] += draw[ch] * (SH_C3[0] * s9 * 6.f * xy + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2.f * xy +
                                      SH_C3[3] * s12 * -6.f * xz + SH_C3[4] * s13 * (4.f * zz - 3.f * xx - yy) +
                                      SH_C3[5] * s14 * 2.f * xz + SH_C3[6] * s15 * 3.f * (xx - yy));
@@ -511,17 +540,39 @@ hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           }
         }
       }
-      for (int k = 0; k < v.M; ++k) {
-        const float bk = (k < ncoef) ? basis[k] : 0.f;
-        out[3 * k + 0] = bk * draw[0];
-        out[3 * k + 1] = bk * draw[1];
-        out[3 * k + 2] = bk * draw[2];
+      if (sh_block_vectorisable(v.M)) {            // 16 B stores of the (M,3) gradient block
+        float o48[48];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float bk = (k < ncoef) ? basis[k] : 0.f;
+          o48[3 * k + 0] = bk * draw[0];
+          o48[3 * k + 1] = bk * draw[1];
+          o48[3 * k + 2] = bk * draw[2];
+        }
+        float4* o4 = reinterpret_cast<float4*>(out);
+        const int nq = (v.M * 3) >> 2;
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+          if (q < nq) o4[q] = make_float4(o48[4 * q], o48[4 * q + 1], o48[4 * q + 2], o48[4 * q + 3]);
+      } else {
+        for (int k = 0; k < v.M; ++k) {
+          const float bk = (k < ncoef) ? basis[k] : 0.f;
+          out[3 * k + 0] = bk * draw[0];
+          out[3 * k + 1] = bk * draw[1];
+          out[3 * k + 2] = bk * draw[2];
+        }
       }
       // d(normalize)/d(dir_orig)
       const float dot = dx * ddir[0] + dy * ddir[1] + dz * ddir[2];
       dmean[0] += (ddir[0] - dx * dot) / n;
       dmean[1] += (ddir[1] - dy * dot) / n;
       dmean[2] += (ddir[2] - dz * dot) / n;
+    } else if (sh_block_vectorisable(v.M)) {
+      float4* o4 = reinterpret_cast<float4*>(out);
+      const int nq = (v.M * 3) >> 2;
+#pragma unroll
+      for (int q = 0; q < 12; ++q)
+        if (q < nq) o4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       for (int k = 0; k < 3 * v.M; ++k) out[k] = 0.f;
     }
