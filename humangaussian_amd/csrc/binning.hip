@@ -644,7 +644,8 @@ hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   const uint32_t n = L.tile_start[t + 1] - start;
   if (n <= 4096u || n > 16384u) return;
   // long lists: the plain LDS network with all 1024 threads on 2 comparators per stage
-  // beats 16 keys per thread in registers (measured at 500k Gaussians: 181 vs 220 us)
+  // beats 16 keys per thread in registers (measured at 500k Gaussians: 181 vs 220 us) and ties
+  // with the register/shuffle hybrid at 8 keys x 1024 threads (153 vs 156 us)
   for (uint32_t k = threadIdx.x; k < n; k += 1024) keys[k] = L.keys[start + k];
   __syncthreads();
   bitonic_sort<1024>(keys, n);
