@@ -202,6 +202,25 @@ def test_long_tile_lists_sort_classes_and_early_termination(n):
     assert np.array_equal(ncon, aux["n_contrib"].numpy().astype(np.uint32))
 
 
+@pytest.mark.parametrize("side", [1936, 2048, 2080])
+def test_very_large_images_bin_paths(side):
+    """Tile-count regimes of the binning stage: T = 121^2 = 14641 (LDS histograms, scan without the
+    on-chip count copy), T = 128^2 = 16384 (largest LDS-histogram case), T = 130^2 = 16900
+    (global-atomic fallback: hgs_k_preprocess_fwd_ga / hgs_k_fill_ga, single-workgroup scan).
+    Few Gaussians so that the oracle stays fast; forward and backward are compared."""
+    sc = make_scene(P=200, sh_degree=1, seed=side, H=side, W=side, spread=0.5, scale=0.002)
+    rc = RawCall(sc, capacity=1 << 17)
+    assert rc.forward() == 0 and not rc.status[4]
+    oc, orad, od, oa, aux, _ = oracle_forward(sc)
+    assert torch.equal(rc.radii.cpu(), orad)
+    assert rc.status[0] == int((aux["ranges"][:, 1] - aux["ranges"][:, 0]).sum())
+    check_images(rc, oc, od, oa)
+    grads = rand_grads(side, side, seed=3)
+    got = rc.backward(*grads)
+    *_, ref = oracle_forward(sc, dtype=torch.float64, grads=grads)
+    check_grads(got, ref)
+
+
 # ---------------------------------------------------------------------------- backward
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
