@@ -9,7 +9,7 @@
 // are ballot/prefix-popcount COMPACTED per quadrant with the conservative cull mask (only
 // ~41 % of (quadrant, entry) pairs survive - work the previous lane=Gaussian systolic
 // formulation could not skip; it needed 2.3x more instructions, see
-// render_bwd_systolic.hip.txt and DESIGN.md section 4).
+// tools/render_bwd_systolic.hip.txt and DESIGN.md section 4).
 //
 // With  S_j = c_j . g_C + d_j g_D + g_A   (g_* = incoming pixel gradients),
 //       F   = running sum of w_j S_j       (front to back, like T),

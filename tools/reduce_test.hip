@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
-#include "../humangaussian_amd/csrc/wave_reduce.h"
+#include "wave_reduce.h"
 __global__ void k(const float* in, float* out) {
   const int lane = threadIdx.x;
   float x[10], o[3];
