@@ -28,7 +28,7 @@ constexpr int HGS_MAX_BIN_WGS = 256;
 
 struct GeomCarve {
   size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
-      tile_wgstart, tile_maxcontrib, tile_msegstart, hist, tile_grp, tile_gbase, status, total;
+      tile_wgstart, tile_maxcontrib, tile_msegstart, tile_pos, pos_wgstart, hist, tile_grp, tile_gbase, status, total;
 };
 
 inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
@@ -49,6 +49,8 @@ GeomCarve carve_geom(int P, int H, int W) {
   c.tile_wgstart = take((T + 1) * 4);
   c.tile_maxcontrib = take(T * 4);
   c.tile_msegstart = take((T + 1) * 4);
+  c.tile_pos = take(T * 4);
+  c.pos_wgstart = take((T + 1) * 4);
   c.hist = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_MAX_BIN_WGS * T * 4 : 0);
   c.tile_grp = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
   c.tile_gbase = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
@@ -71,7 +73,7 @@ BinCarve carve_bin(int64_t cap) {
   c.segT = take(nms * HGS_TILE_PIX * sizeof(float));
   c.segP = take(nms * HGS_SEG_PLANES * HGS_TILE_PIX * sizeof(float));
   c.seg_item = take((nms + 2) * 8);
-  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 4);   // one backward workgroup per bucket: <= R/64 + active tiles
+  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 8);   // one backward workgroup per bucket: <= R/64 + active tiles
   c.total = off;
   return c;
 }
@@ -92,6 +94,8 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
   L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
   L.tile_msegstart = reinterpret_cast<uint32_t*>(gp + g.tile_msegstart);
+  L.tile_pos = reinterpret_cast<uint32_t*>(gp + g.tile_pos);
+  L.pos_wgstart = reinterpret_cast<uint32_t*>(gp + g.pos_wgstart);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.tile_grp = reinterpret_cast<uint32_t*>(gp + g.tile_grp);
   L.tile_gbase = reinterpret_cast<uint32_t*>(gp + g.tile_gbase);
@@ -100,7 +104,7 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
   L.segT = bp ? reinterpret_cast<float*>(bp + b.segT) : nullptr;
   L.segP = bp ? reinterpret_cast<float*>(bp + b.segP) : nullptr;
-  L.wg_tile = bp ? reinterpret_cast<uint32_t*>(bp + b.wg_tile) : nullptr;
+  L.wg_tile = bp ? reinterpret_cast<uint2*>(bp + b.wg_tile) : nullptr;
   L.seg_item = bp ? reinterpret_cast<uint2*>(bp + b.seg_item) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;

@@ -272,7 +272,31 @@ hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
       else
         pos = atomicAdd(&cls_base[32 - __clz(n)], 1u);
       L.tile_order[pos] = (uint32_t)t;
+      L.tile_pos[t] = pos;
+      L.pos_wgstart[pos] = (n + HGS_BUCKET - 1) / HGS_BUCKET;      // buckets of the tile at this position
     }
+  }
+  // Backward work items in tile_order too (heavy tiles first, a tile's buckets consecutive):
+  // pos_wgstart = exclusive prefix of the bucket counts over positions.  With ~5.6k items on
+  // 4096 wave slots the items that start late must be the light ones.
+  __syncthreads();
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < v.T; base += SCAN_NT * 4) {
+    const int p0 = base + tid * 4;
+    uint32_t nb[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (p0 + k < v.T) nb[k] = L.pos_wgstart[p0 + k];
+    uint32_t total;
+    const uint32_t ex = hgs_block_excl_scan<SCAN_NT>(nb[0] + nb[1] + nb[2] + nb[3], wtot, total);
+    uint32_t run = carry_s + ex;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (p0 + k < v.T) { L.pos_wgstart[p0 + k] = run; run += nb[k]; }
+    __syncthreads();
+    if (tid == 0) carry_s += total;
+    __syncthreads();
   }
 }
 

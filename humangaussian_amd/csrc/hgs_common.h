@@ -82,7 +82,9 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* tile_maxcontrib;
   uint32_t* tile_msegstart;   // [T+1] prefix of (nseg > 1 ? nseg : 0): index of a tile's segment planes
   uint2* seg_item;            // [<= 2C/HGS_SEG + 4] (tile, segment) of every segment of the long lists
-  uint32_t* wg_tile;          // [<= C + C/64] tile of every backward workgroup (written by the forward)
+  uint2* wg_tile;             // [<= C + C/64] (tile, bucket) of every backward work item (written by the forward)
+  uint32_t* tile_pos;         // [T] position of a tile in tile_order
+  uint32_t* pos_wgstart;      // [T] first backward work item of the tile at a tile_order position
   uint32_t* hist;          // [nwg][T] per-workgroup tile histograms -> exclusive bases
   uint32_t* tile_grp;      // [HGS_ROW_GROUPS][T] row-group totals (colscan)
   uint32_t* tile_gbase;    // [HGS_ROW_GROUPS][T] absolute base of each row group in the tile's list (scan)

@@ -76,8 +76,8 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   // buffer (768 floats), which is filled only after the basis has been read back
   float* __restrict__ basis = (2 * HGS_BWD_BATCH >= 11) ? stage : reinterpret_cast<float*>(s_rec);
 
-  // ---- which (tile, bucket)?  The forward left the tile of every backward workgroup in wg_tile
-  // (a binary search over tile_wgstart here cost 12 dependent loads).
+  // ---- which (tile, bucket)?  The forward left (tile, bucket) of every work item in wg_tile, heavy
+  // tiles first (a binary search over a prefix array here cost 12 dependent loads).
   const uint32_t g = blockIdx.x;
 #ifdef HGS_BWD_TIMING
   unsigned long long tm[8];
@@ -92,8 +92,9 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #define HGS_TSTART()
 #endif
   if (status->overflow || g >= L.tile_wgstart[v.T]) return;   // surplus workgroup
-  const int t = (int)L.wg_tile[g];
-  const uint32_t b = g - L.tile_wgstart[t];
+  const uint2 item = L.wg_tile[g];
+  const int t = (int)item.x;
+  const uint32_t b = item.y;
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_start[t + 1] - start;
   const uint32_t maxc = L.tile_maxcontrib[t];

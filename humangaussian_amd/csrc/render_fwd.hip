@@ -237,10 +237,12 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
   const uint32_t ms0 = (nseg > 1) ? L.tile_msegstart[t] : 0u;
   if (STORE && !overflow && k == 0) {
-    // backward workgroup -> tile map (one workgroup per 64-entry bucket): spares the backward a
-    // 12-step dependent binary search over tile_wgstart at the start of every workgroup
-    const uint32_t w0 = L.tile_wgstart[t], nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
-    for (uint32_t bb = tid; bb < nb; bb += HGS_FWD_THREADS) L.wg_tile[w0 + bb] = (uint32_t)t;
+    // backward work item -> (tile, bucket) map, one item per 64-entry bucket, in tile_order (heavy
+    // tiles first): spares the backward a dependent binary search at the start of every wave and
+    // puts the light items at the end of its dispatch order
+    const uint32_t pos = LONG ? L.tile_pos[t] : (blockIdx.x - seg_bound);
+    const uint32_t w0 = L.pos_wgstart[pos], nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
+    for (uint32_t bb = tid; bb < nb; bb += HGS_FWD_THREADS) L.wg_tile[w0 + bb] = make_uint2((uint32_t)t, bb);
   }
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
 
