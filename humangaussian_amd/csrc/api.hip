@@ -183,7 +183,20 @@ int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 7; }
+int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gathered, float* out,
+                          void* stream_) {
+  if (world < 1 || P < 0 || F < 1) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!gathered || !out) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const long long n = (long long)P * F;
+  hipLaunchKernelGGL(hgs_k_reduce_view_packs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (int)world, n, (int)F, gathered, out);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+int hgs_abi_version(void) { return 8; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;

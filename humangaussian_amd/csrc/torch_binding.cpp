@@ -422,6 +422,21 @@ Tensor knn_mean_dist2(const Tensor& points) {
   return out;
 }
 
+// view-parallel reduction of the all-gathered packs: (world, P, F) -> (P, F)
+Tensor reduce_view_packs(const Tensor& gathered) {
+  at::NoGradGuard ng;
+  const c10::Device dev = gathered.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  if (gathered.dim() != 3) throw std::runtime_error("gathered packs must have dimensions (world, num_points, F)");
+  DeviceSwitch guard(dev.index());
+  const Tensor g = f32c(gathered, dev, "gathered");
+  Tensor out = at::empty({g.size(1), g.size(2)}, g.options());
+  const int rc = hgs_reduce_view_packs((int32_t)g.size(0), g.size(1), (int32_t)g.size(2), g.data_ptr<float>(),
+                                       out.data_ptr<float>(), c10::hip::getCurrentHIPStream(dev.index()).stream());
+  check_rc(rc, "hgs_reduce_view_packs");
+  return out;
+}
+
 void set_stage_events(const c10::optional<std::vector<int64_t>>& fwd, const c10::optional<std::vector<int64_t>>& bwd) {
   g_stage_fwd.clear();
   g_stage_bwd.clear();
@@ -458,6 +473,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize, py::call_guard<py::gil_scoped_release>());
   m.def("mark_visible", &mark_visible, py::call_guard<py::gil_scoped_release>());
   m.def("knn_mean_dist2", &knn_mean_dist2, py::call_guard<py::gil_scoped_release>());
+  m.def("reduce_view_packs", &reduce_view_packs, py::call_guard<py::gil_scoped_release>());
   m.def("set_async", [](bool on) { g_async = on; });
   m.def("get_async", []() { return g_async; });
   m.def("set_stage_events", &set_stage_events);

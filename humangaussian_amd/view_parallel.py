@@ -62,6 +62,11 @@ def allgather_reduce(pack: torch.Tensor, group=None) -> torch.Tensor:
                        device=pack.device)
     dist.all_gather_into_tensor(flat, pack, group=group)
     gathered = flat.view((world,) + tuple(pack.shape))
+    if pack.is_cuda and pack.dim() == 2:
+        # one HIP pass (rank-order sum, max on the radii column) instead of 2 (world - 1) strided
+        # torch kernels launched from a Python loop
+        from . import _lib
+        return _lib.load_binding().reduce_view_packs(gathered)
     total = gathered[0].clone()
     for r in range(1, world):                     # fixed order => deterministic sum
         total[:, :-1] += gathered[r][:, :-1]

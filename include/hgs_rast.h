@@ -145,6 +145,13 @@ int hgs_mark_visible(const hgs_settings* s, int32_t P, const float* means3D,
  * kernel submodules/simple-knn/simple_knn.cu:147-183).  points: [P][3] fp32, mean_dist2: [P]. */
 int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* stream);
 
+/* View-parallel reduction behind the single all-gather (the serial accumulation it
+ * reproduces: /root/reference/threestudio/systems/GaussianDreamer.py:253-256,385-391).
+ * gathered: [world][P][F] fp32 packs (per-Gaussian gradient columns, radii as the LAST column);
+ * out: [P][F] = sum over ranks in rank order for columns < F-1, max for column F-1. */
+int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gathered, float* out,
+                          void* stream);
+
 /* Library / ABI version (bumped on any signature change). */
 int hgs_abi_version(void);
 

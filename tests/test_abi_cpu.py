@@ -89,6 +89,8 @@ def test_simple_knn_module_name_resolves():
     lib = _lib.load()
     assert lib.hgs_knn_mean_dist2(-1, None, None, None) == -1
     assert lib.hgs_knn_mean_dist2(0, None, None, None) == 0
+    assert lib.hgs_reduce_view_packs(0, 1, 1, None, None, None) == -1
+    assert lib.hgs_reduce_view_packs(2, 0, 18, None, None, None) == 0
 
 
 def test_product_package_never_imports_the_oracle():

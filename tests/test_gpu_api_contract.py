@@ -208,3 +208,20 @@ def test_dist_cuda2_matches_kdtree_reference():
     pts = synth.humanoid_points(3000, seed=1)
     got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
     assert np.allclose(got, synth.mean_knn_dist2(pts), rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_view_pack_reduction_kernel_equals_rank_order_loop():
+    """hgs_reduce_view_packs (what allgather_reduce runs on HIP tensors) against the rank-order
+    torch loop the CPU/gloo tests exercise: sums bit-identical, radii column = max."""
+    from humangaussian_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    for world, P, F in ((1, 100, 18), (3, 1000, 18), (8, 4097, 63)):
+        packs = torch.randn(world, P, F, generator=g)
+        packs[:, :, -1] = torch.randint(0, 300, (world, P), generator=g).float()
+        ref = packs[0].clone()
+        for r in range(1, world):
+            ref[:, :-1] += packs[r][:, :-1]
+            ref[:, -1] = torch.maximum(ref[:, -1], packs[r][:, -1])
+        got = _lib.load_binding().reduce_view_packs(packs.cuda()).cpu()
+        assert torch.equal(got, ref), (world, P, F)
