@@ -268,6 +268,9 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                                  go_async ? nullptr : st.status_event,
                                  g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(), stream);
       check_rc(rc, "hgs_forward");
+      // `debug=True` is upstream's switch for surfacing device errors at the call that caused
+      // them (std::runtime_error): synchronise and report
+      if (debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer forward (debug=True)");
       // host work that does not depend on the result runs HERE, while the GPU is busy
       if (want_grad && !grads_ready) {
         plan->d_means3D = at::empty({P, 3}, fopt);
@@ -357,6 +360,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         fptr_mut(plan->d_opac), fptr_mut(plan->d_sc), fptr_mut(plan->d_ro), fptr_mut(plan->d_cv),
         g_stage_bwd.empty() ? nullptr : g_stage_bwd.data(), stream);
     check_rc(rc, "hgs_backward");
+    if (plan->settings.s.debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer backward (debug=True)");
     variable_list out(21);
     out[0] = plan->d_means3D; out[1] = plan->d_means2D; out[2] = plan->d_sh; out[3] = plan->d_cp;
     out[4] = plan->d_opac; out[5] = plan->d_sc; out[6] = plan->d_ro; out[7] = plan->d_cv;
