@@ -225,3 +225,27 @@ def test_view_pack_reduction_kernel_equals_rank_order_loop():
             ref[:, -1] = torch.maximum(ref[:, -1], packs[r][:, -1])
         got = _lib.load_binding().reduce_view_packs(packs.cuda()).cpu()
         assert torch.equal(got, ref), (world, P, F)
+
+
+def test_debug_flag_path_gives_identical_results():
+    """pipe.debug=True (gaussian_renderer/__init__.py:49): upstream's switch for surfacing device
+    errors at the causing call; here it synchronises after each native call - same numbers."""
+    import math
+    from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
+    sc = make_scene(P=400, sh_degree=1, seed=5, H=64, W=64)
+    cam = sc["cam"]
+    outs = []
+    for dbg in (False, True):
+        rs = GaussianRasterizationSettings(
+            64, 64, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), sc["bg"].to(DEV), 1.0,
+            cam.world_view_transform.to(DEV), cam.full_proj_transform.to(DEV), 1, cam.camera_center.to(DEV),
+            False, dbg)
+        ins = {k: sc[k].to(DEV).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros_like(ins["means3D"], requires_grad=True)
+        c, r, d, a = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"],
+                                            opacities=ins["opacities"], scales=ins["scales"],
+                                            rotations=ins["rotations"])
+        (c.sum() + d.sum() + a.sum()).backward()
+        outs.append((c.detach(), r, ins["means3D"].grad, m2.grad))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
