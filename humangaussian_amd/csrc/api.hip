@@ -196,7 +196,22 @@ int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gath
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 8; }
+int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, const float* g_means2D,
+                               const float* g_sh, const float* g_opac, const float* g_scales,
+                               const float* g_rot, const int32_t* radii, float* out, void* stream_) {
+  if (P < 0 || M < 0) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!g_means3D || !g_means2D || (M > 0 && !g_sh) || !g_opac || !g_scales || !g_rot || !radii || !out)
+    return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const long long n = (long long)P * (15 + 3 * M);
+  hipLaunchKernelGGL(hgs_k_pack_view_contribution, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (int)P, (int)M, g_means3D, g_means2D, g_sh, g_opac, g_scales, g_rot, radii, out);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+int hgs_abi_version(void) { return 9; }
 
 size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
   if (P < 0 || H <= 0 || W <= 0) return 0;

@@ -67,3 +67,27 @@ hgs_k_reduce_view_packs(int world, long long n, int F, const float* __restrict__
   }
   out[i] = acc;
 }
+
+// Packs one rank's per-Gaussian contribution [means3D 3 | means2D 3 | sh 3M | opacity 1 | scale 3 |
+// rot 4 | radii 1] into the (P, F) fp32 tensor that travels through the all-gather (radii as exact
+// fp32 integers).  One pass instead of seven reshapes/casts and a torch.cat.
+extern "C" __global__ void __launch_bounds__(256)
+hgs_k_pack_view_contribution(int P, int M, const float* __restrict__ g_means3D,
+                             const float* __restrict__ g_means2D, const float* __restrict__ g_sh,
+                             const float* __restrict__ g_opac, const float* __restrict__ g_scales,
+                             const float* __restrict__ g_rot, const int32_t* __restrict__ radii,
+                             float* __restrict__ out) {
+  const int F = 3 + 3 + 3 * M + 1 + 3 + 4 + 1;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)P * F) return;
+  const int p = (int)(i / F), f = (int)(i % F);
+  float v;
+  if (f < 3) v = g_means3D[3 * (size_t)p + f];
+  else if (f < 6) v = g_means2D[3 * (size_t)p + (f - 3)];
+  else if (f < 6 + 3 * M) v = g_sh[(size_t)p * 3 * M + (f - 6)];
+  else if (f < 7 + 3 * M) v = g_opac[p];
+  else if (f < 10 + 3 * M) v = g_scales[3 * (size_t)p + (f - 7 - 3 * M)];
+  else if (f < 14 + 3 * M) v = g_rot[4 * (size_t)p + (f - 10 - 3 * M)];
+  else v = (float)radii[p];
+  out[i] = v;
+}

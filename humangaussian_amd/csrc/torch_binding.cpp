@@ -426,6 +426,32 @@ Tensor knn_mean_dist2(const Tensor& points) {
   return out;
 }
 
+// one rank's (P, 15 + 3M) pack for the view-parallel all-gather
+Tensor pack_view_contribution(const Tensor& g_means3D, const Tensor& g_means2D, const Tensor& g_sh,
+                              const Tensor& g_opac, const Tensor& g_scales, const Tensor& g_rot,
+                              const Tensor& radii) {
+  at::NoGradGuard ng;
+  const c10::Device dev = g_means3D.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  DeviceSwitch guard(dev.index());
+  const int64_t P = g_means3D.size(0);
+  const Tensor a = f32c(g_means3D, dev, "means3D grad"), b = f32c(g_means2D, dev, "means2D grad");
+  const Tensor c = f32c(g_sh, dev, "sh grad"), d = f32c(g_opac, dev, "opacity grad");
+  const Tensor e = f32c(g_scales, dev, "scales grad"), f = f32c(g_rot, dev, "rotations grad");
+  if (radii.device() != dev || radii.scalar_type() != at::kInt) throw std::runtime_error("radii must be int32 on the same device");
+  const Tensor r = radii.contiguous();
+  const int64_t M = P > 0 ? c.numel() / (3 * P) : 0;
+  if (a.numel() != 3 * P || b.numel() != 3 * P || c.numel() != 3 * M * P || d.numel() != P || e.numel() != 3 * P ||
+      f.numel() != 4 * P || r.numel() != P)
+    throw std::runtime_error("pack_view_contribution: inconsistent shapes");
+  Tensor out = at::empty({P, 15 + 3 * M}, a.options());
+  const int rc = hgs_pack_view_contribution((int32_t)P, (int32_t)M, fptr(a), fptr(b), fptr(c), fptr(d), fptr(e), fptr(f),
+                                            P > 0 ? r.data_ptr<int32_t>() : nullptr, fptr_mut(out),
+                                            c10::hip::getCurrentHIPStream(dev.index()).stream());
+  check_rc(rc, "hgs_pack_view_contribution");
+  return out;
+}
+
 // view-parallel reduction of the all-gathered packs: (world, P, F) -> (P, F)
 Tensor reduce_view_packs(const Tensor& gathered) {
   at::NoGradGuard ng;
@@ -478,6 +504,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("mark_visible", &mark_visible, py::call_guard<py::gil_scoped_release>());
   m.def("knn_mean_dist2", &knn_mean_dist2, py::call_guard<py::gil_scoped_release>());
   m.def("reduce_view_packs", &reduce_view_packs, py::call_guard<py::gil_scoped_release>());
+  m.def("pack_view_contribution", &pack_view_contribution, py::call_guard<py::gil_scoped_release>());
   m.def("set_async", [](bool on) { g_async = on; });
   m.def("get_async", []() { return g_async; });
   m.def("set_stage_events", &set_stage_events);

@@ -35,6 +35,11 @@ def shard_views(num_views: int, rank: int, world: int) -> List[int]:
 def pack_contribution(grads: Dict[str, torch.Tensor], radii: torch.Tensor) -> torch.Tensor:
     """(P, F) fp32 pack.  radii (int32) travel as exact fp32 integers (< 2^24)."""
     P = radii.shape[0]
+    if radii.is_cuda and radii.dtype == torch.int32 and P > 0:
+        from . import _lib          # one HIP pass instead of seven reshapes/casts and a cat
+        return _lib.load_binding().pack_view_contribution(
+            grads["means3D"], grads["means2D"], grads["shs"], grads["opacities"], grads["scales"],
+            grads["rotations"], radii)
     cols = [grads[k].reshape(P, -1).float() for k in GRAD_KEYS]
     cols.append(radii.reshape(P, 1).float())
     return torch.cat(cols, dim=1).contiguous()

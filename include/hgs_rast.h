@@ -152,6 +152,12 @@ int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
 int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gathered, float* out,
                           void* stream);
 
+/* Packs one rank's contribution for that all-gather: out[P][15 + 3M] =
+ * [dL/dmeans3D 3 | dL/dmeans2D 3 | dL/dsh 3M | dL/dopacity 1 | dL/dscale 3 | dL/drot 4 | radii 1]. */
+int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, const float* g_means2D,
+                               const float* g_sh, const float* g_opac, const float* g_scales,
+                               const float* g_rot, const int32_t* radii, float* out, void* stream);
+
 /* Library / ABI version (bumped on any signature change). */
 int hgs_abi_version(void);
 

@@ -91,6 +91,7 @@ def test_simple_knn_module_name_resolves():
     assert lib.hgs_knn_mean_dist2(0, None, None, None) == 0
     assert lib.hgs_reduce_view_packs(0, 1, 1, None, None, None) == -1
     assert lib.hgs_reduce_view_packs(2, 0, 18, None, None, None) == 0
+    assert lib.hgs_pack_view_contribution(5, 1, *([None] * 9)) == -1
 
 
 def test_product_package_never_imports_the_oracle():

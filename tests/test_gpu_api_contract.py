@@ -249,3 +249,18 @@ def test_debug_flag_path_gives_identical_results():
         outs.append((c.detach(), r, ins["means3D"].grad, m2.grad))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+def test_view_pack_kernel_equals_torch_cat():
+    from humangaussian_amd import view_parallel as vp
+    g = torch.Generator().manual_seed(2)
+    for P, M in ((1, 1), (777, 1), (300, 16)):
+        grads = {"means3D": torch.randn(P, 3, generator=g), "means2D": torch.randn(P, 3, generator=g),
+                 "shs": torch.randn(P, M, 3, generator=g), "opacities": torch.randn(P, 1, generator=g),
+                 "scales": torch.randn(P, 3, generator=g), "rotations": torch.randn(P, 4, generator=g)}
+        radii = torch.randint(0, 400, (P,), generator=g, dtype=torch.int32)
+        ref = vp.pack_contribution(grads, radii)                          # CPU tensors: torch path
+        got = vp.pack_contribution({k: v.cuda() for k, v in grads.items()}, radii.cuda()).cpu()
+        assert got.shape == ref.shape and torch.equal(got, ref)
+        back, r2 = vp.unpack_contribution(got, {k: v.shape for k, v in grads.items()})
+        assert torch.equal(r2, radii) and all(torch.equal(back[k], grads[k]) for k in grads)
