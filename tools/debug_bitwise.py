@@ -1,7 +1,7 @@
 """Ad-hoc: per-field mismatch report of HIP preprocess records vs the fp32 oracle."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import oracle
 from abi_runner import RawCall
