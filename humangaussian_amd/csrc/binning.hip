@@ -584,32 +584,50 @@ __device__ __forceinline__ void lds_stage(u64 (&k)[E], u64* lds, uint32_t base, 
   }
 }
 
+// one LDS stage for a wave that holds only padding: it must keep the barrier count of the others
+__device__ __forceinline__ void lds_stage_idle() {
+  __syncthreads();
+  __syncthreads();
+}
+
 template <int E, int NT>
 __device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad) {
   const uint32_t base = threadIdx.x * E;
+  // Waves whose key slots all lie beyond npad hold +inf padding only; no comparator ever changes
+  // them, so they skip the network and just keep the barrier count.  (Device timestamps showed
+  // the kernel issue-bound with every tile running all of its 8 waves through every stage: 762
+  // tiles, most of them far shorter than 512 * E keys.)  Wave-uniform: npad and 64 E are powers
+  // of two.
+  const bool active = base < npad;
   for (uint32_t kk = 2; kk <= npad; kk <<= 1) {
     // --- mirror stage of span kk: index i pairs with i ^ (kk-1)
     if (kk <= (uint32_t)E) {
-      if (kk == 2) reg_stage_mirror<E>(k, 2);
-      else if (kk == 4) { if (E >= 4) reg_stage_mirror<E>(k, 4); }
-      else if (kk == 8) { if (E >= 8) reg_stage_mirror<E>(k, 8); }
-      else if (kk == 16) { if (E >= 16) reg_stage_mirror<E>(k, 16); }
+      if (active) {
+        if (kk == 2) reg_stage_mirror<E>(k, 2);
+        else if (kk == 4) { if (E >= 4) reg_stage_mirror<E>(k, 4); }
+        else if (kk == 8) { if (E >= 8) reg_stage_mirror<E>(k, 8); }
+        else if (kk == 16) { if (E >= 16) reg_stage_mirror<E>(k, 16); }
+      }
     } else {
       const bool keep_min = (base & (kk >> 1)) == 0;
-      if (kk <= 64u * E) lane_stage<E>(k, (int)(kk / E - 1), true, keep_min);
-      else lds_stage<E>(k, lds, base, kk - 1, keep_min);
+      if (kk <= 64u * E) { if (active) lane_stage<E>(k, (int)(kk / E - 1), true, keep_min); }
+      else if (active) lds_stage<E>(k, lds, base, kk - 1, keep_min);
+      else lds_stage_idle();
     }
     // --- xor stages j = kk/4 .. 1
     for (uint32_t j = kk >> 2; j > 0; j >>= 1) {
       if (j < (uint32_t)E) {
-        if (j == 1) reg_stage_xor<E>(k, 1);
-        else if (j == 2) { if (E > 2) reg_stage_xor<E>(k, 2); }
-        else if (j == 4) { if (E > 4) reg_stage_xor<E>(k, 4); }
-        else if (j == 8) { if (E > 8) reg_stage_xor<E>(k, 8); }
+        if (active) {
+          if (j == 1) reg_stage_xor<E>(k, 1);
+          else if (j == 2) { if (E > 2) reg_stage_xor<E>(k, 2); }
+          else if (j == 4) { if (E > 4) reg_stage_xor<E>(k, 4); }
+          else if (j == 8) { if (E > 8) reg_stage_xor<E>(k, 8); }
+        }
       } else {
         const bool keep_min = (base & j) == 0;
-        if (j < 64u * E) lane_stage<E>(k, (int)(j / E), false, keep_min);
-        else lds_stage<E>(k, lds, base, j, keep_min);
+        if (j < 64u * E) { if (active) lane_stage<E>(k, (int)(j / E), false, keep_min); }
+        else if (active) lds_stage<E>(k, lds, base, j, keep_min);
+        else lds_stage_idle();
       }
     }
   }
@@ -623,14 +641,33 @@ __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, in
   while (npad < n) npad <<= 1;
   u64 k[E];
   const uint32_t base = threadIdx.x * E;
+#ifdef HGS_SORT_TIMING
+  unsigned long long tmk[4];
+  tmk[0] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
   for (int e = 0; e < E; ++e) k[e] = (base + e < n) ? L.keys[start + base + e] : ~0ull;
+#ifdef HGS_SORT_TIMING
+  asm volatile("s_waitcnt vmcnt(0)");
+  tmk[1] = __builtin_readcyclecounter();
+#endif
   hybrid_sort<E, NT>(k, keys, npad);
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < E; ++e) keys[base + e] = k[e];
   __syncthreads();
+#ifdef HGS_SORT_TIMING
+  tmk[2] = __builtin_readcyclecounter();
+#endif
   gather_records(v, L, t, start, n, keys, NT);
+#ifdef HGS_SORT_TIMING
+  __syncthreads();
+  tmk[3] = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(L.segT) + (size_t)blockIdx.x * 8;
+    o[0] = tmk[0]; o[1] = tmk[1]; o[2] = tmk[2]; o[3] = tmk[3]; o[4] = n; o[5] = E;
+  }
+#endif
 }
 
 }  // namespace
