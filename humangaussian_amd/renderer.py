@@ -18,16 +18,32 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 _SH_C0 = 0.28209479177387814
 _SH_C1 = 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792,
+          0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+          -0.4570457994644658, 1.445305721320277, -0.5900435899266435)
 
 
-def _eval_sh_deg01(deg, sh, dirs):
-    """Only used by the `convert_SHs_python` branch (kept for API completeness)."""
+def _eval_sh_python(deg, sh, dirs):
+    """Real SH basis up to degree 3 in plain torch, for the `convert_SHs_python` branch
+    (what `gaussiansplatting/utils/sh_utils.py:57-112` computes there).  sh: (..., 3, K)
+    coefficients, dirs: (..., 3) unit vectors -> (..., 3) colours before the +0.5 shift."""
+    assert 0 <= deg <= 3 and sh.shape[-1] >= (deg + 1) ** 2
     res = _SH_C0 * sh[..., 0]
     if deg > 0:
         x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
         res = res - _SH_C1 * y * sh[..., 1] + _SH_C1 * z * sh[..., 2] - _SH_C1 * x * sh[..., 3]
-    if deg > 1:
-        raise NotImplementedError("convert_SHs_python above degree 1: pass shs to the rasterizer")
+        if deg > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            res = (res + _SH_C2[0] * xy * sh[..., 4] + _SH_C2[1] * yz * sh[..., 5]
+                   + _SH_C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] + _SH_C2[3] * xz * sh[..., 7]
+                   + _SH_C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                res = (res + _SH_C3[0] * y * (3 * xx - yy) * sh[..., 9] + _SH_C3[1] * xy * z * sh[..., 10]
+                       + _SH_C3[2] * y * (4 * zz - xx - yy) * sh[..., 11]
+                       + _SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+                       + _SH_C3[4] * x * (4 * zz - xx - yy) * sh[..., 13]
+                       + _SH_C3[5] * z * (xx - yy) * sh[..., 14] + _SH_C3[6] * x * (xx - 3 * yy) * sh[..., 15])
     return res
 
 
@@ -81,7 +97,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
             dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
             dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-            colors_precomp = torch.clamp_min(_eval_sh_deg01(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+            colors_precomp = torch.clamp_min(_eval_sh_python(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
         else:
             shs = pc.get_features
     else:

@@ -291,10 +291,21 @@ def bin_and_sort(pre):
 
 # ------------------------------------------------------------------------------ blending
 
-def _blend_tile(pxf, pyf, xy, conic, opac, rgb, depth, chunk=4096):
+FRAGILE_EPS_ALPHA = 2e-5   # relative distance of op*G from 1/255 below which fp32 may decide differently
+FRAGILE_EPS_T = 2e-4       # relative distance of test_T from 1e-4 (T is a product of hundreds of factors)
+FRAGILE_EPS_POWER = 2e-6   # absolute distance of the exponent from 0
+
+
+def _blend_tile(pxf, pyf, xy, conic, opac, rgb, depth, chunk=4096, fragile_out=None):
     """Stage F6 for one tile.  pxf/pyf: (Npix,) pixel centres; the rest are the tile's
-    depth-sorted Gaussians.  Returns C (Npix,3), D, Wt, T_final (Npix,), n_contrib."""
+    depth-sorted Gaussians.  Returns C (Npix,3), D, Wt, T_final (Npix,), n_contrib.
+    `fragile_out` (a list) receives a (Npix,) bool mask of pixels where one of the three hard
+    decisions of SURVEY A.5 (power > 0, alpha < 1/255, test_T < 1e-4) sits within rounding
+    distance of its threshold, i.e. where two correct fp32 implementations may legitimately
+    take different branches ("threshold flips"); parity tests gate every other pixel tightly."""
     npix = pxf.shape[0]
+    fragile = torch.zeros(npix, dtype=torch.bool)
+    fragile_entries = torch.zeros(xy.shape[0], dtype=torch.bool)   # entries involved in such a decision
     dt = xy.dtype
     T_run = torch.ones(npix, dtype=dt)
     C = torch.zeros(npix, 3, dtype=dt)
@@ -322,6 +333,14 @@ def _blend_tile(pxf, pyf, xy, conic, opac, rgb, depth, chunk=4096):
             stop = keep & (Tincl < T_EPS)
             stopped = torch.cumsum(stop.to(torch.int32), dim=1) > 0   # from the stopper on
             live = keep & ~stopped
+            if fragile_out is not None:
+                reach = (~done[:, None]) & ~(stopped & ~stop)             # entries up to and including the stopper
+                near_a = (power <= FRAGILE_EPS_POWER) & ((araw / ALPHA_MIN - 1.0).abs() < FRAGILE_EPS_ALPHA)
+                near_p = power.abs() < FRAGILE_EPS_POWER
+                near_t = (alpha >= ALPHA_MIN * (1 - FRAGILE_EPS_ALPHA)) & ((Tincl / T_EPS - 1.0).abs() < FRAGILE_EPS_T)
+                hit = reach & (near_a | near_p | near_t)
+                fragile |= hit.any(dim=1)
+                fragile_entries[s:e] |= hit.any(dim=0)
             pos = torch.arange(s + 1, e + 1)[None, :].expand(npix, -1)
             last = torch.where(live, pos, torch.zeros_like(pos)).amax(dim=1)
             n_contrib = torch.maximum(n_contrib, last)
@@ -334,6 +353,9 @@ def _blend_tile(pxf, pyf, xy, conic, opac, rgb, depth, chunk=4096):
                                       dim=1)[:, -1]
         with torch.no_grad():
             done = done | stopped[:, -1]
+    if fragile_out is not None:
+        fragile_out.append(fragile)
+        fragile_out.append(fragile_entries)
     return C, D, Wt, T_run, n_contrib
 
 
@@ -352,6 +374,7 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
     alpha = torch.zeros(1, H, W, dtype=dtype)
     n_contrib_img = torch.zeros(H, W, dtype=torch.int64)
     final_T = torch.ones(H, W, dtype=dtype)
+    fragile_img = torch.zeros(H, W, dtype=torch.bool)
     if P == 0:
         radii = torch.zeros(0, dtype=torch.int32)
         out = (color, radii, depth, alpha)
@@ -375,8 +398,11 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
         x1, y1 = min(x0 + TILE, W), min(y0 + TILE, H)
         ys, xs = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
         pxf, pyf = xs.reshape(-1).to(dtype), ys.reshape(-1).to(dtype)
+        fr = [] if return_aux else None
         C, D, Wt, Tf, nc = _blend_tile(pxf, pyf, pre["mean2D"][gi], pre["conic"][gi],
-                                       pre["opacity"][gi], pre["rgb"][gi], pre["depth"][gi])
+                                       pre["opacity"][gi], pre["rgb"][gi], pre["depth"][gi], fragile_out=fr)
+        if fr:
+            fragile_img[y0:y1, x0:x1] = fr[0].reshape(y1 - y0, x1 - x0)
         Cb = C + Tf[:, None] * bg[None, :]
         color_parts.append((y0, y1, x0, x1, Cb))
         depth_parts.append(D)
@@ -411,7 +437,81 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
         alpha = torch.cat(rows_a, 1)
     out = (colors_out, pre["radii"], depth, alpha)
     if return_aux:
-        return out + ({"n_contrib": n_contrib_img, "final_T": final_T, "pre": pre,
+        return out + ({"n_contrib": n_contrib_img, "final_T": final_T, "pre": pre, "fragile": fragile_img,
                        "ranges": ranges, "g_sorted": g_sorted,
                        "active_tiles": n_active_total, "blended_tiles": len(active)},)
     return out
+
+
+# ------------------------------------------------------------- streamed forward + backward
+
+def forward_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                     settings: OracleSettings, dL_dcolor, dL_ddepth, dL_dalpha,
+                     dtype=torch.float64, want_means2D=True):
+    """Forward AND backward of `rasterize` with memory bounded by ONE tile: the blend graph
+    of each tile is built, back-propagated into per-Gaussian leaf copies of the preprocess
+    outputs and dropped; the accumulated per-Gaussian gradients are then chained through the
+    preprocess graph once.  Mathematically identical to `rasterize(...)` + autograd (same
+    functions, same quirks), but usable at BASELINE.json's config 4 (500k Gaussians, lists of
+    10^4 entries) in float64.  `fragile` / `flip_gaussians`: pixels / Gaussians involved in a hard
+    decision that sits within rounding distance of its threshold (see `_blend_tile`).
+    Returns dict(color, radii, depth, alpha, n_contrib, fragile, flip_gaussians,
+    grads={means3D, means2D, shs|colors_precomp, opacities, scales, rotations|cov3D_precomp})."""
+    H, W = int(settings.image_height), int(settings.image_width)
+    bg = settings.bg.to(dtype).reshape(3)
+    P = means3D.shape[0]
+    leaf = lambda t: None if t is None else t.detach().to(dtype).clone().requires_grad_(True)  # noqa: E731
+    ins = dict(means3D=leaf(means3D), shs=leaf(shs), colors_precomp=leaf(colors_precomp),
+               opacities=leaf(opacities), scales=leaf(scales), rotations=leaf(rotations),
+               cov3D_precomp=leaf(cov3D_precomp))
+    m2 = torch.zeros(P, 3, dtype=dtype, requires_grad=True) if want_means2D else None
+    pre = preprocess(ins["means3D"], m2, ins["shs"], ins["colors_precomp"], ins["opacities"],
+                     ins["scales"], ins["rotations"], ins["cov3D_precomp"], settings, dtype)
+    g_sorted, _, ranges = bin_and_sort(pre)
+    gx, gy = pre["grid"]
+    names = ("mean2D", "conic", "opacity", "rgb", "depth")
+    cut = {k: pre[k].detach().clone().requires_grad_(True) for k in names}
+    color = bg[:, None, None].expand(3, H, W).clone()
+    depth = torch.zeros(1, H, W, dtype=dtype)
+    alpha = torch.zeros(1, H, W, dtype=dtype)
+    n_contrib = torch.zeros(H, W, dtype=torch.int64)
+    fragile = torch.zeros(H, W, dtype=torch.bool)
+    flip_gaussians = torch.zeros(P, dtype=torch.bool)
+    gc, gd, ga = dL_dcolor.to(dtype), dL_ddepth.to(dtype), dL_dalpha.to(dtype)
+    active = torch.nonzero(ranges[:, 1] > ranges[:, 0]).reshape(-1).tolist()
+    for t in active:
+        s, e = int(ranges[t, 0]), int(ranges[t, 1])
+        gi = g_sorted[s:e]
+        ty_, tx_ = divmod(t, gx)
+        x0, y0 = tx_ * TILE, ty_ * TILE
+        x1, y1 = min(x0 + TILE, W), min(y0 + TILE, H)
+        ys, xs = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
+        pxf, pyf = xs.reshape(-1).to(dtype), ys.reshape(-1).to(dtype)
+        fr = []
+        C, D, Wt, Tf, nc = _blend_tile(pxf, pyf, cut["mean2D"][gi], cut["conic"][gi], cut["opacity"][gi],
+                                       cut["rgb"][gi], cut["depth"][gi], fragile_out=fr)
+        Cb = C + Tf[:, None] * bg[None, :]
+        hh, ww = y1 - y0, x1 - x0
+        loss = ((Cb.t().reshape(3, hh, ww) * gc[:, y0:y1, x0:x1]).sum()
+                + (D.reshape(hh, ww) * gd[0, y0:y1, x0:x1]).sum()
+                + (Wt.reshape(hh, ww) * ga[0, y0:y1, x0:x1]).sum())
+        loss.backward()
+        with torch.no_grad():
+            color[:, y0:y1, x0:x1] = Cb.t().reshape(3, hh, ww)
+            depth[0, y0:y1, x0:x1] = D.reshape(hh, ww)
+            alpha[0, y0:y1, x0:x1] = Wt.reshape(hh, ww)
+            n_contrib[y0:y1, x0:x1] = nc.reshape(hh, ww)
+            fragile[y0:y1, x0:x1] = fr[0].reshape(hh, ww)
+            flip_gaussians[gi[fr[1]]] = True
+    heads, hgrads = [], []
+    for k in names:
+        if cut[k].grad is not None and pre[k].requires_grad:
+            heads.append(pre[k]); hgrads.append(cut[k].grad)
+    if heads:
+        torch.autograd.backward(heads, hgrads)
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in ins.items() if v is not None}
+    if m2 is not None:
+        grads["means2D"] = m2.grad if m2.grad is not None else torch.zeros_like(m2)
+    return dict(color=color, radii=pre["radii"], depth=depth, alpha=alpha, n_contrib=n_contrib,
+                fragile=fragile, flip_gaussians=flip_gaussians, grads=grads, num_rendered=int(g_sorted.numel()),
+                max_list=int((ranges[:, 1] - ranges[:, 0]).max()) if len(active) else 0)

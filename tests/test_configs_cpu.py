@@ -55,3 +55,17 @@ def test_config1_ply_to_cpu_render_512(tmp_path):
     assert 0.02 < cover < 0.5                            # a person in the middle of the frame
     ys, xs = torch.nonzero(a[0] > 0.5, as_tuple=True)
     assert float(ys.max() - ys.min()) > float(xs.max() - xs.min())    # standing upright (taller than wide)... 
+
+
+def test_renderer_python_sh_matches_reference_goldens():
+    """renderer._eval_sh_python (the convert_SHs_python branch, degrees 0-3) against the outputs of
+    the reference's own eval_sh (tests/golden/reference_helpers.npz, utils/sh_utils.py:57-112)."""
+    import os
+    import numpy as np
+    from humangaussian_amd.renderer import _eval_sh_python
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_helpers.npz"))
+    sh = torch.from_numpy(ref["sh_coeffs"]).double().transpose(1, 2)      # (P, 3, K) as the reference passes it
+    d = torch.from_numpy(ref["sh_dirs"]).double()
+    for deg in range(4):
+        got = _eval_sh_python(deg, sh, d)
+        assert np.abs(got.numpy() - ref[f"sh_eval_deg{deg}"]).max() < 2e-6, deg

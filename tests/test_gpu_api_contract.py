@@ -264,3 +264,68 @@ def test_view_pack_kernel_equals_torch_cat():
         assert got.shape == ref.shape and torch.equal(got, ref)
         back, r2 = vp.unpack_contribution(got, {k: v.shape for k, v in grads.items()})
         assert torch.equal(r2, radii) and all(torch.equal(back[k], grads[k]) for k in grads)
+
+
+def test_mark_visible_matches_oracle_including_near_plane_boundary_and_empty():
+    """`GaussianRasterizer.markVisible` / `hgs_mark_visible` (replaces `_C.mark_visible`): the frustum
+    test is `view-space z > 0.2`, nothing else.  Checked against oracle.mark_visible on a cloud that
+    straddles the camera, at the exact boundary (z == 0.2 is NOT visible, the next float is) and
+    for P == 0, through the Python API and through the raw C ABI."""
+    import ctypes
+    import numpy as np
+    from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    dev = torch.device("cuda")
+    sc = make_scene(P=5000, sh_degree=0, seed=5, H=64, W=64, spread=2.5)     # many points behind the camera
+    st = oracle_settings(sc)
+    cam = sc["cam"]
+    rs = GaussianRasterizationSettings(64, 64, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), sc["bg"].to(dev), 1.0,
+                                       cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 0,
+                                       cam.camera_center.to(dev), False, False)
+    got = GaussianRasterizer(rs).markVisible(sc["means3D"].to(dev))
+    ref = oracle.mark_visible(sc["means3D"], st)
+    assert got.dtype == torch.bool and got.shape == (5000,)
+    assert torch.equal(got.cpu(), ref) and 0 < int(ref.sum()) < 5000
+    # exact boundary with an identity view matrix: view-space z == world z
+    near = np.float32(0.2)
+    zs = torch.tensor([float(near), float(np.nextafter(near, np.float32(1))), float(np.nextafter(near, np.float32(0))),
+                       0.0, -1.0, 5.0], dtype=torch.float32)
+    pts = torch.stack([torch.zeros(6), torch.zeros(6), zs], 1)
+    rs_id = rs._replace(viewmatrix=torch.eye(4, device=dev), projmatrix=torch.eye(4, device=dev))
+    got = GaussianRasterizer(rs_id).markVisible(pts.to(dev)).cpu()
+    assert got.tolist() == [False, True, False, False, False, True]
+    st_id = st._replace(viewmatrix=torch.eye(4), projmatrix=torch.eye(4))
+    assert torch.equal(got, oracle.mark_visible(pts, st_id))
+    # P == 0
+    empty = GaussianRasterizer(rs).markVisible(torch.zeros(0, 3, device=dev))
+    assert empty.shape == (0,) and empty.dtype == torch.bool
+    # raw C ABI (include/hgs_rast.h: hgs_mark_visible), caller-owned buffers
+    lib = _lib.load()
+    s = _lib.HgsSettings()
+    vm = cam.world_view_transform.to(dev).contiguous()
+    s.image_height = s.image_width = 64
+    s.viewmatrix = vm.data_ptr()
+    m = sc["means3D"].to(dev).contiguous()
+    present = torch.full((5000,), 7, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    rc = lib.hgs_mark_visible(ctypes.byref(s), 5000, ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(present.data_ptr()),
+                              ctypes.c_void_p(stream.cuda_stream))
+    stream.synchronize()
+    assert rc == 0 and torch.equal(present.cpu().bool(), ref) and int(present.max()) == 1
+    assert lib.hgs_mark_visible(ctypes.byref(s), 0, None, None, None) == 0
+
+
+def test_convert_shs_python_branch_degree3_matches_rasterizer_sh():
+    """pipe.convert_SHs_python (gaussian_renderer/__init__.py:73-78) at SH degree 3: colours computed
+    in Python and handed over as colors_precomp give the image the in-kernel SH path gives."""
+    dev = torch.device("cuda")
+    sc = make_scene(P=400, sh_degree=3, seed=21, H=64, W=80, spread=0.3)
+    pc = FakeGaussianModel(sc, 3)
+    cam = FakeCamera(sc["cam"])
+
+    class PyShPipe(Pipe):
+        convert_SHs_python = True
+    with torch.no_grad():
+        a = render(cam, pc, PyShPipe(), sc["bg"].to(dev))
+        b = render(cam, pc, Pipe(), sc["bg"].to(dev))
+    assert float((a["render"] - b["render"]).abs().max()) < 2e-5
+    assert torch.equal(a["radii"], b["radii"])

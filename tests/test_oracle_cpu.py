@@ -221,3 +221,29 @@ def test_golden_scene_regenerates():
                                   sc["rotations"], None, oracle_settings(sc), dtype=torch.float64)
     assert np.abs(c.numpy() - z["color"]).max() < 1e-9 and np.abs(d.numpy() - z["depth"]).max() < 1e-9
     assert np.array_equal(r.numpy(), z["radii"])
+
+
+def test_streamed_forward_backward_equals_autograd_of_rasterize():
+    """oracle.forward_backward (memory bounded by one tile; used for the full-size config-4 parity
+    test) is the same function as rasterize() + autograd: identical outputs and gradients."""
+    sc = make_scene(P=300, sh_degree=2, seed=11, H=80, W=112, spread=0.3, scale=0.06)
+    st = oracle_settings(sc)
+    gen = torch.Generator().manual_seed(4)
+    gc, gd, ga = (torch.randn(s, generator=gen, dtype=torch.float64) for s in ((3, 80, 112), (1, 80, 112), (1, 80, 112)))
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    ins = {k: sc[k].double().requires_grad_(True) for k in names}
+    m2 = torch.zeros(300, 3, dtype=torch.float64, requires_grad=True)
+    c, r, d, a, aux = oracle.rasterize(ins["means3D"], m2, ins["shs"], None, ins["opacities"], ins["scales"],
+                                       ins["rotations"], None, st, dtype=torch.float64, return_aux=True)
+    ((c * gc).sum() + (d * gd).sum() + (a * ga).sum()).backward()
+    out = oracle.forward_backward(sc["means3D"], sc["shs"], None, sc["opacities"], sc["scales"], sc["rotations"],
+                                  None, st, gc, gd, ga, dtype=torch.float64)
+    assert torch.equal(out["radii"], r) and torch.equal(out["n_contrib"], aux["n_contrib"])
+    for got, ref in ((out["color"], c), (out["depth"], d), (out["alpha"], a)):
+        assert float((got - ref.detach()).abs().max()) < 1e-12
+    for k in names:
+        ref = ins[k].grad
+        assert float((out["grads"][k] - ref).abs().max()) <= 1e-10 * max(1.0, float(ref.abs().max())), k
+    assert float((out["grads"]["means2D"] - m2.grad).abs().max()) <= 1e-10 * float(m2.grad.abs().max())
+    # the fragile mask flags only a small minority of pixels on a generic scene
+    assert out["fragile"].dtype == torch.bool and float(out["fragile"].float().mean()) < 0.02
