@@ -12,6 +12,8 @@ from .rasterizer import (  # noqa: F401
     GaussianRasterizationSettings,
     GaussianRasterizer,
     rasterize_gaussians,
+    rasterize_gaussians_batch,
 )
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians",
+           "rasterize_gaussians_batch"]

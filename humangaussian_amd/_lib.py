@@ -19,7 +19,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("HGS_LIB") or os.path.join(_PKG_DIR, "libhgs_rast.so")   # HGS_LIB: A/B experiments only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared"]
@@ -50,6 +50,14 @@ EXPORTS = {
     "hgs_bin_bytes": (c_size_t, [c_int64]),
     "hgs_img_bytes": (c_size_t, [c_int32, c_int32]),
     "hgs_bwd_scratch_bytes": (c_size_t, [c_int64]),
+    "hgs_geom_bytes_batch": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "hgs_img_bytes_batch": (c_size_t, [c_int32, c_int32, c_int32]),
+    "hgs_forward_batch": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 7
+                          + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
+                                              c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "hgs_backward_batch": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 8
+                           + [c_void_p] * 6 + [c_void_p] * 3 + [POINTER(HgsStatus), c_int64, c_void_p]
+                           + [c_void_p] * 8 + [c_void_p, c_void_p]),
     "hgs_forward": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32] + [c_void_p] * 7
                     + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
                                         c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),

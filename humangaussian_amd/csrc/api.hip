@@ -1,8 +1,8 @@
 // api.hip - host side of the C ABI declared in include/hgs_rast.h: buffer carving and the
 // launch sequences.  No allocation, no host synchronisation, no global state.
 //
-// Forward launch chain (one stream, no host round trip):
-//   preprocess_fwd -> colscan -> scan [status published] -> fill -> sort_{huge,large,lds}
+// Forward launch chain (one stream, no host round trip), for all B views of a call at once:
+//   memset(counters) -> preprocess_fwd -> tiles [status published] -> fill (+ tile order) -> sort_{huge,large,lds}
 //   -> segT -> render_fwd (segments of long lists first, then the other tiles) -> combine
 // Backward: render_bwd (one wave per bucket) -> preprocess_bwd.
 #include "hgs_common.h"
@@ -24,36 +24,50 @@ namespace {
 
 constexpr size_t ALIGN = 256;
 constexpr size_t HGS_LDS_BINS_MAX = 16384;   // T*4 bytes of LDS <= 64 KB
-constexpr int HGS_MAX_BIN_WGS = 256;
+constexpr int HGS_MAX_BIN_WGS_PER_VIEW = 256;
+constexpr int HGS_BIN_WGS_TOTAL = 1024;      // binning workgroups of a batch (all views)
 
 struct GeomCarve {
-  size_t geom, block_sums, block_base, tile_count, tile_start, tile_order, tile_bstart,
-      tile_wgstart, tile_maxcontrib, tile_msegstart, tile_pos, pos_wgstart, hist, tile_grp, tile_gbase, status, total;
+  size_t geom, tile_n, tile_start, tile_bstart, tile_wgstart, tile_msegstart, tile_maxcontrib, tile_order,
+      hist, tile_gbase, tile_count, chunk_sums, chunk_base, ctr, status, total;
 };
 
 inline int grid_dim(int pixels) { return (pixels + HGS_TILE - 1) / HGS_TILE; }
 
-GeomCarve carve_geom(int P, int H, int W) {
+// binning workgroups per view / chunks per workgroup for a batch of B views of P Gaussians
+inline void bin_shape(int B, int P, int& nblk, int& cpw, int& nwg) {
+  nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  int want = HGS_BIN_WGS_TOTAL / (B > 0 ? B : 1);
+  if (want > HGS_MAX_BIN_WGS_PER_VIEW) want = HGS_MAX_BIN_WGS_PER_VIEW;
+  if (want < 1) want = 1;
+  cpw = (nblk + want - 1) / want;
+  if (cpw < 1) cpw = 1;
+  nwg = (nblk + cpw - 1) / cpw;
+}
+
+GeomCarve carve_geom(int B, int P, int H, int W) {
   const size_t T = (size_t)grid_dim(W) * grid_dim(H);
-  const size_t nblk = ((size_t)P + HGS_BLOCK - 1) / HGS_BLOCK;
+  const size_t TT = T * (size_t)B;
+  int nblk, cpw, nwg;
+  bin_shape(B, P, nblk, cpw, nwg);
+  const bool lds = T <= HGS_LDS_BINS_MAX;
   GeomCarve c;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = hgs_align_up(off + bytes, ALIGN); return o; };
-  c.geom = take((size_t)P * sizeof(GeomRec));
-  c.block_sums = take(nblk * 4);
-  c.block_base = take(nblk * 4);
-  c.tile_count = take(T * 4);
-  c.tile_start = take((T + 1) * 4);
-  c.tile_order = take(T * 4);
-  c.tile_bstart = take((T + 1) * 4);
-  c.tile_wgstart = take((T + 1) * 4);
-  c.tile_maxcontrib = take(T * 4);
-  c.tile_msegstart = take((T + 1) * 4);
-  c.tile_pos = take(T * 4);
-  c.pos_wgstart = take((T + 1) * 4);
-  c.hist = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_MAX_BIN_WGS * T * 4 : 0);
-  c.tile_grp = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
-  c.tile_gbase = take(T <= HGS_LDS_BINS_MAX ? (size_t)HGS_ROW_GROUPS * T * 4 : 0);
+  c.geom = take((size_t)B * P * sizeof(GeomRec));
+  c.tile_n = take(TT * 4);
+  c.tile_start = take(TT * 4);
+  c.tile_bstart = take(TT * 4);
+  c.tile_wgstart = take(TT * 4);
+  c.tile_msegstart = take(TT * 4);
+  c.tile_maxcontrib = take(TT * 4);
+  c.tile_order = take(TT * 4);
+  c.hist = take(lds ? (size_t)B * nwg * T * 4 : 0);
+  c.tile_gbase = take(lds ? (size_t)HGS_ROW_GROUPS * TT * 4 : 0);
+  c.tile_count = take(lds ? 0 : TT * 4);
+  c.chunk_sums = take((size_t)B * nblk * 4);
+  c.chunk_base = take((size_t)B * nblk * 4);
+  c.ctr = take(sizeof(Counters));
   c.status = take(sizeof(hgs_status));
   c.total = off;
   return c;
@@ -73,32 +87,33 @@ BinCarve carve_bin(int64_t cap) {
   c.segT = take(nms * HGS_TILE_PIX * sizeof(float));
   c.segP = take(nms * HGS_SEG_PLANES * HGS_TILE_PIX * sizeof(float));
   c.seg_item = take((nms + 2) * 8);
-  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 8);   // one backward workgroup per bucket: <= R/64 + active tiles
+  // one backward work item per bucket: <= C/64 + (tiles with a partial bucket) <= C/64 + min(C, tiles);
+  // sized by C alone so that the carve does not depend on the image
+  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 8);
   c.total = off;
   return c;
 }
 
-Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_t cap) {
-  const GeomCarve g = carve_geom(P, H, W);
+Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W, int64_t cap) {
+  const GeomCarve g = carve_geom(B, P, H, W);
   const BinCarve b = carve_bin(cap);
   char* gp = static_cast<char*>(geom);
   char* bp = static_cast<char*>(bin);
   Layout L;
   L.geom = reinterpret_cast<GeomRec*>(gp + g.geom);
-  L.block_sums = reinterpret_cast<uint32_t*>(gp + g.block_sums);
-  L.block_base = reinterpret_cast<uint32_t*>(gp + g.block_base);
-  L.tile_count = reinterpret_cast<uint32_t*>(gp + g.tile_count);
+  L.tile_n = reinterpret_cast<uint32_t*>(gp + g.tile_n);
   L.tile_start = reinterpret_cast<uint32_t*>(gp + g.tile_start);
-  L.tile_order = reinterpret_cast<uint32_t*>(gp + g.tile_order);
   L.tile_bstart = reinterpret_cast<uint32_t*>(gp + g.tile_bstart);
   L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
-  L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
   L.tile_msegstart = reinterpret_cast<uint32_t*>(gp + g.tile_msegstart);
-  L.tile_pos = reinterpret_cast<uint32_t*>(gp + g.tile_pos);
-  L.pos_wgstart = reinterpret_cast<uint32_t*>(gp + g.pos_wgstart);
+  L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
+  L.tile_order = reinterpret_cast<uint32_t*>(gp + g.tile_order);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
-  L.tile_grp = reinterpret_cast<uint32_t*>(gp + g.tile_grp);
   L.tile_gbase = reinterpret_cast<uint32_t*>(gp + g.tile_gbase);
+  L.tile_count = reinterpret_cast<uint32_t*>(gp + g.tile_count);
+  L.chunk_sums = reinterpret_cast<uint32_t*>(gp + g.chunk_sums);
+  L.chunk_base = reinterpret_cast<uint32_t*>(gp + g.chunk_base);
+  L.ctr = reinterpret_cast<Counters*>(gp + g.ctr);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
@@ -110,30 +125,34 @@ Layout make_layout(void* geom, void* bin, void* img, int P, int H, int W, int64_
   return L;
 }
 
-View make_view(const hgs_settings* s, int P, int M, int64_t cap, int max_tile_hint = 0) {
+View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_tile_hint = 0) {
   View v;
-  v.viewmatrix = s->viewmatrix;
-  v.projmatrix = s->projmatrix;
-  v.campos = s->campos;
-  v.bg = s->bg;
-  v.tanfovx = s->tanfovx;
-  v.tanfovy = s->tanfovy;
-  v.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
-  v.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
+  for (int b = 0; b < HGS_MAX_VIEWS; ++b) {
+    const hgs_settings& sb = s[b < B ? b : 0];
+    Cam& c = v.cam[b];
+    c.viewmatrix = sb.viewmatrix;
+    c.projmatrix = sb.projmatrix;
+    c.campos = sb.campos;
+    c.bg = sb.bg;
+    c.tanfovx = sb.tanfovx;
+    c.tanfovy = sb.tanfovy;
+    c.focal_x = (float)sb.image_width / (2.0f * sb.tanfovx);
+    c.focal_y = (float)sb.image_height / (2.0f * sb.tanfovy);
+  }
   v.scale_modifier = s->scale_modifier;
   v.W = s->image_width;
   v.H = s->image_height;
   v.grid_x = grid_dim(v.W);
   v.grid_y = grid_dim(v.H);
   v.T = v.grid_x * v.grid_y;
+  v.B = B;
+  v.TT = B * v.T;
   v.P = P;
   v.M = M;
   v.D = s->sh_degree;
-  v.nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   v.lds_bins = (size_t)v.T <= HGS_LDS_BINS_MAX ? 1 : 0;
-  v.cpw = v.lds_bins ? (v.nblk + HGS_MAX_BIN_WGS - 1) / HGS_MAX_BIN_WGS : 1;
-  if (v.cpw < 1) v.cpw = 1;
-  v.nwg = (v.nblk + v.cpw - 1) / v.cpw;
+  bin_shape(B, P, v.nblk, v.cpw, v.nwg);
+  if (!v.lds_bins) { v.cpw = 1; v.nwg = v.nblk; }
   v.entry_capacity = (uint32_t)(cap < 0 ? 0 : (cap > 0xffffffffll ? 0xffffffffll : cap));
   v.max_tile_hint = max_tile_hint;
   // list-parallel blending pays for the long tail of tile lists only (same-box sweep, 100k
@@ -167,6 +186,18 @@ bool settings_ok(const hgs_settings* s) {
   return s && s->image_height > 0 && s->image_width > 0 && s->bg && s->viewmatrix &&
          s->projmatrix && s->campos && s->sh_degree >= 0 && s->sh_degree <= 3 &&
          s->image_width <= 16 * 65535 && s->image_height <= 16 * 65535;
+}
+
+// a batch: 1..HGS_MAX_VIEWS valid settings that agree in everything that is not per camera
+bool batch_ok(const hgs_settings* s, int B) {
+  if (!s || B < 1 || B > HGS_MAX_VIEWS) return false;
+  for (int b = 0; b < B; ++b) {
+    if (!settings_ok(s + b)) return false;
+    if (s[b].image_height != s[0].image_height || s[b].image_width != s[0].image_width ||
+        s[b].sh_degree != s[0].sh_degree || s[b].scale_modifier != s[0].scale_modifier)
+      return false;
+  }
+  return (size_t)B * grid_dim(s->image_width) * grid_dim(s->image_height) < (1u << 30);
 }
 
 }  // namespace
@@ -211,30 +242,32 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 9; }
+int hgs_abi_version(void) { return 10; }
 
-size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) {
-  if (P < 0 || H <= 0 || W <= 0) return 0;
-  return carve_geom(P, H, W).total;
+size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t H, int32_t W) {
+  if (B < 1 || B > HGS_MAX_VIEWS || P < 0 || H <= 0 || W <= 0) return 0;
+  return carve_geom(B, P, H, W).total;
 }
+size_t hgs_geom_bytes(int32_t P, int32_t H, int32_t W) { return hgs_geom_bytes_batch(1, P, H, W); }
 size_t hgs_bin_bytes(int64_t entry_capacity) { return carve_bin(entry_capacity).total; }
-size_t hgs_img_bytes(int32_t H, int32_t W) {
-  if (H <= 0 || W <= 0) return 0;
-  return hgs_align_up((size_t)H * W * 4, ALIGN);
+size_t hgs_img_bytes_batch(int32_t B, int32_t H, int32_t W) {
+  if (B < 1 || B > HGS_MAX_VIEWS || H <= 0 || W <= 0) return 0;
+  return hgs_align_up((size_t)B * H * W * 4, ALIGN);
 }
+size_t hgs_img_bytes(int32_t H, int32_t W) { return hgs_img_bytes_batch(1, H, W); }
 size_t hgs_bwd_scratch_bytes(int64_t R) {
   return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_ROW_FLOATS * sizeof(float), ALIGN);
 }
 
-int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3D,
-                const float* shs, const float* colors_precomp, const float* opacities,
-                const float* scales, const float* rotations, const float* cov3D_precomp,
-                float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
-                void* geom, void* bin, int64_t entry_capacity, void* img,
-                int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
-                int32_t status_host_mapped, void* status_event, void* const* stage_events,
-                void* stream_) {
-  if (!settings_ok(s) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
+int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                      const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, const float* rotations, const float* cov3D_precomp,
+                      float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                      void* geom, void* bin, int64_t entry_capacity, void* img,
+                      int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
+                      int32_t status_host_mapped, void* status_event, void* const* stage_events,
+                      void* stream_) {
+  if (!batch_ok(s, B) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
     return HGS_EINVAL;
   if (P > 0) {
@@ -245,39 +278,41 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     if (has_sr == (cov3D_precomp != nullptr)) return HGS_ESHAPE;
     if (shs && M < (s->sh_degree + 1) * (s->sh_degree + 1)) return HGS_ESHAPE;
     if (entry_capacity > 0 && !bin) return HGS_EINVAL;
+    if ((int64_t)B * P >= (1ll << 31) || P >= (1 << 28)) return HGS_EINVAL;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const View v = make_view(s, P, M, entry_capacity, max_tile_entries_hint > 0 ? max_tile_entries_hint : 0);
-  const Layout L = make_layout(geom, bin, img, P, v.H, v.W, entry_capacity);
+  const View v = make_view(s, B, P, M, entry_capacity, max_tile_entries_hint > 0 ? max_tile_entries_hint : 0);
+  const Layout L = make_layout(geom, bin, img, B, P, v.H, v.W, entry_capacity);
   hgs_status* status_dev =
-      reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(P, v.H, v.W).status);
+      reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(B, P, v.H, v.W).status);
 
   HGS_STAGE(0);
   hipError_t e = hipSuccess;
+  if (v.nblk == 0) {       // no preprocess launch (P == 0): nobody else zeroes the counters
+    e = hipMemsetAsync(L.ctr, 0, sizeof(Counters), stream);
+    if (e != hipSuccess) return hip_rc(e);
+  }
   const size_t lds_bytes = (size_t)v.T * 4;
   if (!v.lds_bins) {
-    e = hipMemsetAsync(L.tile_count, 0, (size_t)v.T * 4, stream);
+    e = hipMemsetAsync(L.tile_count, 0, (size_t)v.TT * 4, stream);
     if (e != hipSuccess) return hip_rc(e);
   }
   if (v.nblk > 0) {
     if (v.lds_bins)
-      hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v,
+      hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.B * v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v,
                          L, means3D, shs, colors_precomp, opacities, scales, rotations,
                          cov3D_precomp, radii);
     else
-      hipLaunchKernelGGL(hgs_k_preprocess_fwd_ga, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
+      hipLaunchKernelGGL(hgs_k_preprocess_fwd_ga, dim3(v.B * v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
                          means3D, shs, colors_precomp, opacities, scales, rotations,
                          cov3D_precomp, radii);
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(1);
-  if (v.lds_bins) {
-    hipLaunchKernelGGL(hgs_k_colscan, dim3((v.T + 255) / 256, HGS_ROW_GROUPS), dim3(256), 0, stream, v, L);
-    HGS_LAUNCH_CHECK();
-  }
-  // LDS-bin path: three workgroups (tile tables + status | block bases | tile order) in parallel
-  hipLaunchKernelGGL(hgs_k_scan, dim3(v.lds_bins ? 3 : 1), dim3(1024), v.T <= 14336 ? (size_t)v.T * 4 : 0, stream, v, L, status_dev,
-                     status_host_mapped ? status_host : nullptr);
+  // tile tables + status: 64 tiles per workgroup, all views in one launch
+  const unsigned bpv = (unsigned)((v.T + HGS_TILES_PER_WG - 1) / HGS_TILES_PER_WG);
+  hipLaunchKernelGGL(hgs_k_tiles, dim3(bpv * (unsigned)v.B), dim3(64 * HGS_ROW_GROUPS), 0, stream, v, L,
+                     status_dev, status_host_mapped ? status_host : nullptr);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
   // the status is final here: publish it now so the host can wait for it alone
@@ -289,26 +324,25 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     e = hipEventRecord(static_cast<hipEvent_t>(status_event), stream);
     if (e != hipSuccess) return hip_rc(e);
   }
-  if (v.nblk > 0 && entry_capacity > 0) {
+  const unsigned order_wgs = (unsigned)((v.TT + HGS_BLOCK - 1) / HGS_BLOCK);
+  if (entry_capacity > 0) {
+    // binning workgroups scatter the keys; `order_wgs` more place the tiles into tile_order
     if (v.lds_bins)
-      hipLaunchKernelGGL(hgs_k_fill, dim3(v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v, L,
-                         status_dev);
+      hipLaunchKernelGGL(hgs_k_fill, dim3((unsigned)(v.B * v.nwg) + order_wgs), dim3(HGS_BLOCK), lds_bytes,
+                         stream, v, L, status_dev, v.B * v.nwg);
     else
-      hipLaunchKernelGGL(hgs_k_fill_ga, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
-                         status_dev);
+      hipLaunchKernelGGL(hgs_k_fill_ga, dim3((unsigned)(v.B * v.nblk) + order_wgs), dim3(HGS_BLOCK), 0, stream,
+                         v, L, status_dev, v.B * v.nblk);
     HGS_LAUNCH_CHECK();
     HGS_STAGE(3);
     // tiles are ordered heavy-first, so a class with more than LO entries per tile can only
     // occupy the first capacity/LO positions of tile_order
     auto class_grid = [&](int64_t lo) {
       const int64_t g = entry_capacity / lo + 1;
-      return (unsigned)(g < v.T ? g : v.T);
+      return (unsigned)(g < v.TT ? g : v.TT);
     };
     // the caller's hint (longest tile list it has seen, with margin) lets us skip launching
     // sort classes that cannot occur; a wrong hint is caught on the device (overflow bit 2).
-    // (Forking the long-list classes onto a second stream to run beside the main class was
-    // measured at 500k Gaussians: 153 -> 146 us only - 128 KB-LDS workgroups do not co-reside with
-    // four 32 KB ones - and not kept.)
     const int hint = v.max_tile_hint;
     if (hint <= 0 || hint > 16384) {
       hipLaunchKernelGGL(hgs_k_sort_huge, dim3(class_grid(16384)), dim3(1024), 0, stream, v, L, status_dev);
@@ -318,15 +352,18 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
       hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
       HGS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(hgs_k_sort_lds, dim3(v.T), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
+    hipLaunchKernelGGL(hgs_k_sort_lds, dim3(class_grid(1)), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(hgs_k_fill_ga, dim3(order_wgs), dim3(HGS_BLOCK), 0, stream, v, L, status_dev, 0);   // tile order only
+    HGS_LAUNCH_CHECK();
+    HGS_STAGE(3);
   }
   HGS_STAGE(4);
   // Blend: segment transmittances of the long lists (> HGS_SEG_THRESH entries), then ONE launch
-  // whose first seg_bound workgroups take the segments of the long lists and the next T the
+  // whose first seg_bound workgroups take the segments of the long lists and the next B*T the
   // remaining tiles, then the combine of the segment partials.  Grids are capacity bounds;
-  // surplus workgroups exit on the device-side totals.  (Forking the long-list chain onto a second
-  // stream was measured: 79 -> 87 us at 100k Gaussians, 215 -> 188 us at 500k; not kept.)
+  // surplus workgroups exit on the device-side totals.
   const bool use_seg = !v.seg_off && entry_capacity > HGS_SEG_THRESH;
   const unsigned seg_bound = use_seg ? 2u * (unsigned)(entry_capacity / HGS_SEG) + 2u : 0u;
   if (use_seg && !v.seg_recompute) {
@@ -335,20 +372,97 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
     HGS_LAUNCH_CHECK();
   }
   if (store_bwd_state)
-    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.T + seg_bound), dim3(HGS_FWD_THREADS), 0, stream,
+    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.TT + seg_bound), dim3(HGS_FWD_THREADS), 0, stream,
                        v, L, (uint32_t)seg_bound, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color,
                        out_depth, out_alpha);
   else
-    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.T + seg_bound), dim3(HGS_FWD_THREADS), 0,
+    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.TT + seg_bound), dim3(HGS_FWD_THREADS), 0,
                        stream, v, L, (uint32_t)seg_bound, status_dev, L.recs, L.bstate, L.segT, L.segP,
                        out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
   if (use_seg) {
-    hipLaunchKernelGGL(hgs_k_fwd_combine, dim3(v.T), dim3(HGS_FWD_THREADS), 0, stream, v, L,
+    hipLaunchKernelGGL(hgs_k_fwd_combine, dim3(v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.segP, out_color, out_depth, out_alpha);
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(5);
+  return HGS_OK;
+}
+
+int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3D,
+                const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, const float* rotations, const float* cov3D_precomp,
+                float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                void* geom, void* bin, int64_t entry_capacity, void* img,
+                int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
+                int32_t status_host_mapped, void* status_event, void* const* stage_events,
+                void* stream_) {
+  return hgs_forward_batch(s, 1, P, M, means3D, shs, colors_precomp, opacities, scales, rotations,
+                           cov3D_precomp, out_color, out_depth, out_alpha, radii, geom, bin, entry_capacity,
+                           img, store_bwd_state, max_tile_entries_hint, status_host, status_host_mapped,
+                           status_event, stage_events, stream_);
+}
+
+int hgs_backward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                       const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* scales, const float* rotations, const float* cov3D_precomp,
+                       const int32_t* radii, const float* out_color, const float* out_depth,
+                       const float* out_alpha, const float* dL_dout_color,
+                       const float* dL_dout_depth, const float* dL_dout_alpha, const void* geom,
+                       const void* bin, const void* img, const hgs_status* status,
+                       int64_t entry_capacity, void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                       float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
+                       void* stream_) {
+  (void)opacities; (void)radii;
+  if (!batch_ok(s, B) || P < 0 || !geom || !img || entry_capacity < 0) return HGS_EINVAL;
+  if (status && status->overflow) return HGS_EINVAL;
+  if (status && (int64_t)status->reserved[0] != entry_capacity) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!means3D || !out_color || !out_depth || !out_alpha) return HGS_EINVAL;
+  if ((shs != nullptr) == (colors_precomp != nullptr)) return HGS_ESHAPE;
+  if ((scales != nullptr) != (rotations != nullptr)) return HGS_ESHAPE;
+  if ((scales != nullptr) == (cov3D_precomp != nullptr)) return HGS_ESHAPE;
+  if (shs && !dL_dshs) return HGS_EINVAL;
+  const bool maybe_entries = status ? status->num_rendered > 0 : entry_capacity > 0;
+  if (maybe_entries && (!bin || !bwd_scratch)) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t cap = entry_capacity;
+  const View v = make_view(s, B, P, M, cap);
+  const Layout L = make_layout(const_cast<void*>(geom), const_cast<void*>(bin),
+                               const_cast<void*>(img), B, P, v.H, v.W, cap);
+  const hgs_status* status_dev = reinterpret_cast<const hgs_status*>(
+      static_cast<const char*>(geom) + carve_geom(B, P, v.H, v.W).status);
+  // host status known: exact grid.  Unknown: capacity bound, surplus workgroups exit.
+  uint32_t groups = 0;
+  if (status) groups = status->bwd_groups;
+  else if (maybe_entries) {
+    const int64_t gb = cap / HGS_BUCKET + (cap < v.TT ? cap : (int64_t)v.TT);
+    groups = (uint32_t)gb;
+  }
+  float* rows = static_cast<float*>(bwd_scratch);
+  HGS_STAGE(0);
+  if (groups > 0) {
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(groups), dim3(64 * HGS_BWD_WAVES), 0, stream, v, L, status_dev,
+                       L.recs, L.bstate, L.segP, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
+                       dL_dout_alpha, rows);
+    HGS_LAUNCH_CHECK();
+  }
+  HGS_STAGE(1);
+#define HGS_LAUNCH_PRE_BWD(K)                                                                         \
+  hipLaunchKernelGGL(K, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, status_dev, rows, means3D, shs, \
+                     colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D,       \
+                     dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,            \
+                     dL_dcov3D_precomp)
+  switch (shs ? v.D : 0) {
+    case 0: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d0); break;
+    case 1: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d1); break;
+    case 2: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d2); break;
+    default: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d3); break;
+  }
+#undef HGS_LAUNCH_PRE_BWD
+  HGS_LAUNCH_CHECK();
+  HGS_STAGE(2);
   return HGS_OK;
 }
 
@@ -363,45 +477,11 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
                  float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                  float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
                  void* stream_) {
-  (void)opacities; (void)radii;
-  if (!settings_ok(s) || P < 0 || !geom || !img || entry_capacity < 0) return HGS_EINVAL;
-  if (status && status->overflow) return HGS_EINVAL;
-  if (status && (int64_t)status->reserved[0] != entry_capacity) return HGS_EINVAL;
-  if (P == 0) return HGS_OK;
-  if (!means3D || !out_color || !out_depth || !out_alpha) return HGS_EINVAL;
-  if ((shs != nullptr) == (colors_precomp != nullptr)) return HGS_ESHAPE;
-  if ((scales != nullptr) != (rotations != nullptr)) return HGS_ESHAPE;
-  if ((scales != nullptr) == (cov3D_precomp != nullptr)) return HGS_ESHAPE;
-  if (shs && !dL_dshs) return HGS_EINVAL;
-  const bool maybe_entries = status ? status->num_rendered > 0 : entry_capacity > 0;
-  if (maybe_entries && (!bin || !bwd_scratch)) return HGS_EINVAL;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int64_t cap = entry_capacity;
-  const View v = make_view(s, P, M, cap);
-  const Layout L = make_layout(const_cast<void*>(geom), const_cast<void*>(bin),
-                               const_cast<void*>(img), P, v.H, v.W, cap);
-  const hgs_status* status_dev = reinterpret_cast<const hgs_status*>(
-      static_cast<const char*>(geom) + carve_geom(P, v.H, v.W).status);
-  // host status known: exact grid.  Unknown: capacity bound, surplus workgroups exit.
-  const uint32_t groups = status ? status->bwd_groups
-                                 : (maybe_entries ? (uint32_t)(cap / HGS_BUCKET + v.T) : 0u);
-  float* rows = static_cast<float*>(bwd_scratch);
-  HGS_STAGE(0);
-  if (groups > 0) {
-    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(groups), dim3(64 * HGS_BWD_WAVES), 0, stream, v, L, status_dev,
-                       L.recs, L.bstate, L.segP, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
-                       dL_dout_alpha, rows);
-    HGS_LAUNCH_CHECK();
-  }
-  HGS_STAGE(1);
-  hipLaunchKernelGGL(hgs_k_preprocess_bwd, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
-                     status_dev, rows,
-                     means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans3D,
-                     dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales,
-                     dL_drotations, dL_dcov3D_precomp);
-  HGS_LAUNCH_CHECK();
-  HGS_STAGE(2);
-  return HGS_OK;
+  return hgs_backward_batch(s, 1, P, M, means3D, shs, colors_precomp, opacities, scales, rotations,
+                            cov3D_precomp, radii, out_color, out_depth, out_alpha, dL_dout_color,
+                            dL_dout_depth, dL_dout_alpha, geom, bin, img, status, entry_capacity, bwd_scratch,
+                            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales,
+                            dL_drotations, dL_dcov3D_precomp, stage_events, stream_);
 }
 
 int hgs_mark_visible(const hgs_settings* s, int32_t P, const float* means3D, uint8_t* present,

@@ -1,13 +1,19 @@
 // binning.hip - tile binning and per-tile depth sort (stages F2-F5 of SURVEY.md 2.3(B)).
 //
 // Upstream: InclusiveSum over Gaussians -> duplicateWithKeys -> one GLOBAL 64-bit radix
-// sort of all (tile|depth) keys -> identifyTileRanges.  Here (MI355X-first):
-//   1. hgs_k_scan      one workgroup: scans the per-workgroup tiles_touched sums and the
-//                      per-tile counts (from the preprocess atomics), orders tiles heavy-first
-//                      for scheduling, lays out bucket-state and backward-workgroup prefixes,
-//                      publishes hgs_status.
-//   2. hgs_k_fill      per Gaussian: entry-id prefix + scatter (depth_bits<<32 | idx) keys into
-//                      its tiles' list segments (order inside a tile is arbitrary here).
+// sort of all (tile|depth) keys -> identifyTileRanges.  Here (MI355X-first), for all B views of
+// a call at once (global tile g = view * T + tile):
+//   1. hgs_k_tiles     many workgroups, 64 tiles each: sums the per-workgroup histogram rows
+//                      hgs_k_preprocess_fwd left (16 row groups walked by 16 waves in parallel,
+//                      rows turned into exclusive bases in place), and hands every tile its list
+//                      range, bucket-state range, backward work-item range and segment-plane range
+//                      by BUMP ALLOCATION (two 64-bit atomics per 64 tiles) - no prefix scan
+//                      over the tiles, no single-workgroup latency chain.  The last workgroup to
+//                      finish (ticket) publishes hgs_status and the class bases of the
+//                      heavy-first tile order.
+//   2. hgs_k_fill      per Gaussian: scatter (depth_bits<<32 | idx) keys into its tiles' list
+//                      ranges (order inside a tile is arbitrary here); extra workgroups of the same
+//                      launch place the tiles into tile_order (heavy classes first).
 //   3. hgs_k_sort_*    per tile: bitonic sort of the tile's keys IN LDS (unique keys =>
 //                      deterministic result = upstream's stable order: depth, ties by index),
 //                      then gathers the Gaussians into a depth-ordered, contiguous 48-byte
@@ -17,376 +23,225 @@
 // gather + 48 B write per entry for the records.
 #include "hgs_common.h"
 
-namespace {
-constexpr int SCAN_NT = 1024;
-constexpr int SCAN_ITEMS = 4;      // tiles per thread per pass
-constexpr int SCAN_LDS_TILES = 14336;   // 56 KB of dynamic LDS (stays under the 64 KB default limit)
-
-// exclusive scan of three counters at once over the workgroup (one barrier pair)
-constexpr int NSCAN = 4;
-__device__ __forceinline__ void block_excl_scanN(const uint32_t (&v)[NSCAN], uint32_t (*wtot)[NSCAN],
-                                                 uint32_t (&ex)[NSCAN], uint32_t (&tot)[NSCAN]) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc[NSCAN];
+// ---------------------------------------------------------------------------- 1. tiles
+// Workgroup = 64 consecutive tiles of ONE view x HGS_ROW_GROUPS row groups (one wave each).
+// LDS path: thread (tile, rg) walks rows [rg*rpg, (rg+1)*rpg) of the view's histogram column in
+// place (hist[row][t] -> entries of tile t owned by earlier workgroups of the same group).
+// Global-atomic path (T > 16384): the counts are already in tile_count.
+extern "C" __global__ void __launch_bounds__(64 * HGS_ROW_GROUPS)
+hgs_k_tiles(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __restrict__ status_host) {
+  __shared__ uint32_t gt[HGS_ROW_GROUPS][HGS_TILES_PER_WG];     // group totals per tile
+  __shared__ uint32_t start_s[HGS_TILES_PER_WG];
+  __shared__ uint32_t cls_s[HGS_NCLS];
+  __shared__ uint32_t last_s;
+  const int tid = threadIdx.x, tl = tid & 63;
+  const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bpv = (v.T + HGS_TILES_PER_WG - 1) / HGS_TILES_PER_WG;      // workgroups per view
+  const int b = (int)blockIdx.x / bpv;
+  const int t = ((int)blockIdx.x % bpv) * HGS_TILES_PER_WG + tl;
+  const bool valid = t < v.T;
+  const size_t g = (size_t)b * v.T + t;
+  if (tid < HGS_NCLS) cls_s[tid] = 0;
+  uint32_t run = 0;
+  if (v.lds_bins) {
+    const int rpg = (v.nwg + HGS_ROW_GROUPS - 1) / HGS_ROW_GROUPS;
+    const int r0 = rg * rpg, r1 = min(v.nwg, r0 + rpg);
+    if (valid) {
+      uint32_t* col = L.hist + (size_t)b * v.nwg * v.T + t;
+      constexpr int BR = 16;
+      for (int r = r0; r < r1; r += BR) {
+        uint32_t c[BR];
 #pragma unroll
-  for (int q = 0; q < NSCAN; ++q) inc[q] = hgs_wave_incl_scan(v[q]);
-  __syncthreads();
-  if (lane == 63) {
+        for (int k = 0; k < BR; ++k) c[k] = (r + k < r1) ? col[(size_t)(r + k) * v.T] : 0u;
 #pragma unroll
-    for (int q = 0; q < NSCAN; ++q) wtot[w][q] = inc[q];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NSCAN; ++q) {
-    uint32_t b = 0, t = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_NT / 64; ++k) {
-      const uint32_t x = wtot[k][q];
-      if (k < w) b += x;
-      t += x;
-    }
-    ex[q] = b + inc[q] - v[q];
-    tot[q] = t;
-  }
-}
-}  // namespace
-
-// ---------------------------------------------------------------------------- 1. scan
-// One workgroup.  LDS-bin path: the per-tile count is the sum of the HGS_ROW_GROUPS group
-// totals hgs_k_colscan left in tile_grp[rg][t]; this kernel turns them into ABSOLUTE
-// bases tile_start[t] + (entries of earlier row groups).
-extern "C" __global__ void __launch_bounds__(SCAN_NT)
-hgs_k_scan(View v, Layout L, hgs_status* __restrict__ status,
-           hgs_status* __restrict__ status_host) {
-  __shared__ uint32_t wtot[SCAN_NT / 64];
-  __shared__ uint32_t wtotN[SCAN_NT / 64][NSCAN];
-  __shared__ uint32_t carry_s;
-  __shared__ uint32_t carry3[NSCAN];
-  __shared__ uint32_t cls_hist[33];
-  __shared__ uint32_t cls_base[33];
-  __shared__ uint32_t max_n_s;
-  // dynamic LDS (launched with 4*T bytes when T <= SCAN_LDS_TILES, else 0): the per-tile counts
-  // stay on chip for phase (c) - each global round trip of this single workgroup costs 1.5-3 us
-  extern __shared__ uint32_t s_dyn[];
-  const bool lds_tiles = v.T <= SCAN_LDS_TILES;
-  uint32_t* s_n = s_dyn;
-  const int tid = threadIdx.x;
-
-  // Three independent jobs.  On the LDS-bin path they run as three workgroups of one launch
-  // (role = blockIdx.x) so that their latency chains overlap; on the global-atomic path (one
-  // workgroup) they run one after the other.
-  //   role 1: (a) block_base      role 0: (b) tile tables + status      role 2: (c) tile_order
-  const int role = (gridDim.x > 1) ? (int)blockIdx.x : -1;
-  if (tid == 0) { carry_s = 0; carry3[0] = carry3[1] = carry3[2] = carry3[3] = 0; max_n_s = 0; }
-  if (tid < 33) cls_hist[tid] = 0;
-  __syncthreads();
-  // (a) exclusive scan of per-chunk tiles_touched sums -> block_base
-  if (role == -1 || role == 1)
-  for (int base = 0; base < v.nblk; base += SCAN_NT) {
-    const int k = base + tid;
-    const uint32_t val = (k < v.nblk) ? L.block_sums[k] : 0u;
-    uint32_t total;
-    const uint32_t ex = hgs_block_excl_scan<SCAN_NT>(val, wtot, total);
-    const uint32_t carry = carry_s;
-    if (k < v.nblk) L.block_base[k] = carry + ex;
-    __syncthreads();
-    if (tid == 0) carry_s = carry + total;
-    __syncthreads();
-  }
-  if (role == 1) return;
-
-  // (b) tile_start / bucket-state prefix / backward-workgroup prefix; class histogram
-  // (role 2 runs the same loop for the per-tile counts and the class histogram only)
-  for (int base = 0; base < v.T; base += SCAN_NT * SCAN_ITEMS) {
-    const int t0 = base + tid * SCAN_ITEMS;
-    uint32_t n[SCAN_ITEMS], grp[HGS_ROW_GROUPS][SCAN_ITEMS];
-    // one CU does all of this: 16 B/lane vector accesses (4 consecutive tiles per thread)
-    // keep its memory pipeline to a handful of fully coalesced instructions
-    const bool vec = ((v.T & 3) == 0) && (t0 + SCAN_ITEMS <= v.T);
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) n[k] = 0;
-    if (v.lds_bins) {
-#pragma unroll
-      for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
-        if (vec) {
-          const uint4 q = *reinterpret_cast<const uint4*>(L.tile_grp + (size_t)rg * v.T + t0);
-          grp[rg][0] = q.x; grp[rg][1] = q.y; grp[rg][2] = q.z; grp[rg][3] = q.w;
-        } else {
-#pragma unroll
-          for (int k = 0; k < SCAN_ITEMS; ++k)
-            grp[rg][k] = (t0 + k < v.T) ? L.tile_grp[(size_t)rg * v.T + t0 + k] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) n[k] += grp[rg][k];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < SCAN_ITEMS; ++k) n[k] = (t0 + k < v.T) ? L.tile_count[t0 + k] : 0u;
-    }
-    uint32_t mx = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) mx = max(mx, n[k]);
-    if (role != 2) {
-    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-    uint32_t p0[SCAN_ITEMS], p1[SCAN_ITEMS], p2[SCAN_ITEMS], p3[SCAN_ITEMS];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-      const uint32_t nb = (n[k] + HGS_BUCKET - 1) / HGS_BUCKET;
-      const uint32_t nseg = hgs_nseg(n[k]);
-      p0[k] = l0; p1[k] = l1; p2[k] = l2; p3[k] = l3;
-      l0 += n[k];
-      l1 += nb > 0 ? nb - 1 : 0;                               // stored bucket states
-      l2 += nb;                                                // backward workgroups (1 per bucket)
-      l3 += nseg > 1 ? nseg : 0;                               // segment planes of long lists
-    }
-    uint32_t ex[NSCAN], tot[NSCAN];
-    const uint32_t lv[NSCAN] = {l0, l1, l2, l3};
-    block_excl_scanN(lv, wtotN, ex, tot);
-    const uint32_t c0 = carry3[0], c1 = carry3[1], c2 = carry3[2];
-    const uint32_t c3 = carry3[3];
-    uint32_t ts[SCAN_ITEMS], tb[SCAN_ITEMS], tw[SCAN_ITEMS], tm[SCAN_ITEMS];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-      ts[k] = c0 + ex[0] + p0[k];
-      tb[k] = c1 + ex[1] + p1[k];
-      tw[k] = c2 + ex[2] + p2[k];
-      tm[k] = c3 + ex[3] + p3[k];
-    }
-    if (vec) {
-      *reinterpret_cast<uint4*>(L.tile_start + t0) = make_uint4(ts[0], ts[1], ts[2], ts[3]);
-      *reinterpret_cast<uint4*>(L.tile_bstart + t0) = make_uint4(tb[0], tb[1], tb[2], tb[3]);
-      *reinterpret_cast<uint4*>(L.tile_wgstart + t0) = make_uint4(tw[0], tw[1], tw[2], tw[3]);
-      *reinterpret_cast<uint4*>(L.tile_maxcontrib + t0) = make_uint4(0u, 0u, 0u, 0u);
-      *reinterpret_cast<uint4*>(L.tile_msegstart + t0) = make_uint4(tm[0], tm[1], tm[2], tm[3]);
-      if (v.lds_bins) {
-        uint32_t acc[SCAN_ITEMS] = {ts[0], ts[1], ts[2], ts[3]};
-#pragma unroll
-        for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
-          *reinterpret_cast<uint4*>(L.tile_gbase + (size_t)rg * v.T + t0) =
-              make_uint4(acc[0], acc[1], acc[2], acc[3]);
-#pragma unroll
-          for (int k = 0; k < SCAN_ITEMS; ++k) acc[k] += grp[rg][k];
-        }
-      } else {
-        *reinterpret_cast<uint4*>(L.tile_count + t0) = make_uint4(0u, 0u, 0u, 0u);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const int t = t0 + k;
-        if (t < v.T) {
-          L.tile_start[t] = ts[k];
-          L.tile_bstart[t] = tb[k];
-          L.tile_wgstart[t] = tw[k];
-          L.tile_maxcontrib[t] = 0;
-          L.tile_msegstart[t] = tm[k];
-          if (v.lds_bins) {
-            uint32_t acc = ts[k];
-#pragma unroll
-            for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) {
-              L.tile_gbase[(size_t)rg * v.T + t] = acc;
-              acc += grp[rg][k];
-            }
-          } else {
-            L.tile_count[t] = 0;            // becomes the fill cursor
-          }
+        for (int k = 0; k < BR; ++k) {
+          if (r + k < r1) col[(size_t)(r + k) * v.T] = run;
+          run += c[k];
         }
       }
     }
-    __syncthreads();
-    if (tid == 0) { carry3[0] = c0 + tot[0]; carry3[1] = c1 + tot[1]; carry3[2] = c2 + tot[2]; carry3[3] = c3 + tot[3]; }
-    }  // role != 2
-    if (lds_tiles) {
-#pragma unroll
-      for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (t0 + k < v.T) s_n[t0 + k] = n[k];
-    }
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-      if (t0 + k < v.T && n[k]) atomicAdd(&cls_hist[32 - __clz(n[k])], 1u);
-    {  // empty tiles are the bulk (80+ %): count them once per wave, not once per tile
-      uint32_t empties = 0;
-#pragma unroll
-      for (int k = 0; k < SCAN_ITEMS; ++k) empties += (t0 + k < v.T && n[k] == 0) ? 1u : 0u;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) empties += (uint32_t)__shfl_xor((int)empties, d, 64);
-      if ((tid & 63) == 0 && empties) atomicAdd(&cls_hist[0], empties);
-    }
-    if (mx) atomicMax(&max_n_s, mx);
-    __syncthreads();
+  } else if (rg == 0 && valid) {
+    run = L.tile_count[g];
+    L.tile_count[g] = 0;                 // becomes the fill cursor
   }
-  if (tid == 0 && role != 2) {
-    const uint32_t R = carry3[0];            // sum of the tile counts = sum of tiles_touched
-    L.tile_start[v.T] = carry3[0];
-    L.tile_bstart[v.T] = carry3[1];
-    L.tile_wgstart[v.T] = carry3[2];
-    L.tile_msegstart[v.T] = carry3[3];
+  gt[rg][tl] = run;
+  __syncthreads();
+  uint32_t gbase = 0;                    // entries of this tile in earlier row groups
+#pragma unroll
+  for (int k = 0; k < HGS_ROW_GROUPS; ++k) gbase += (k < rg) ? gt[k][tl] : 0u;
+  if (rg == 0) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < HGS_ROW_GROUPS; ++k) n += gt[k][tl];
+    if (!valid) n = 0;
+    const uint32_t nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
+    const uint32_t nseg = hgs_nseg(n);
+    const uint32_t v0 = n, v1 = nb > 0 ? nb - 1 : 0u, v2 = nb, v3 = nseg > 1 ? nseg : 0u;
+    const uint32_t i0 = hgs_wave_incl_scan(v0), i1 = hgs_wave_incl_scan(v1);
+    const uint32_t i2 = hgs_wave_incl_scan(v2), i3 = hgs_wave_incl_scan(v3);
+    // one bump allocation per counter pair for the 64 tiles (lane 63 holds the totals)
+    unsigned long long b_eb = 0, b_ws = 0;
+    if (tl == 63) {
+      const unsigned long long t_eb = (unsigned long long)i0 | ((unsigned long long)i1 << 32);
+      const unsigned long long t_ws = (unsigned long long)i2 | ((unsigned long long)i3 << 32);
+      if (t_eb) b_eb = atomicAdd(&L.ctr->alloc_eb, t_eb);
+      if (t_ws) b_ws = atomicAdd(&L.ctr->alloc_ws, t_ws);
+    }
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b_eb, 63);
+    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b_eb >> 32), 63);
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b_ws, 63);
+    const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b_ws >> 32), 63);
+    const uint32_t start = s0 + i0 - v0;
+    start_s[tl] = start;
+    if (valid) {
+      L.tile_n[g] = n;
+      L.tile_start[g] = start;
+      L.tile_bstart[g] = s1 + i1 - v1;
+      L.tile_wgstart[g] = s2 + i2 - v2;
+      L.tile_msegstart[g] = s3 + i3 - v3;
+      L.tile_maxcontrib[g] = 0;
+    }
+    // class histogram (class = bit length of n; 0 = empty); the empty class is counted per wave
+    const unsigned long long eb = __ballot(valid && n == 0);
+    if (tl == 0 && eb) atomicAdd(&cls_s[0], (uint32_t)__popcll(eb));
+    if (valid && n) atomicAdd(&cls_s[32 - __clz(n)], 1u);
+    const uint32_t mx = hgs_wave_max_u32(n);
+    if (tl == 0 && mx) atomicMax(&L.ctr->max_n, mx);
+  }
+  if (rg == 1) {
+    // entry-id bases of the 256-Gaussian chunks: this workgroup's share of the B*nblk chunks, one
+    // bump allocation per 64 chunks (runs beside wave 0's tile allocation)
+    const int nchunk = v.B * v.nblk;
+    const int per_wg = (nchunk + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int c_begin = (int)blockIdx.x * per_wg, c_end = min(nchunk, c_begin + per_wg);
+    for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+      const int c = c0 + tl;
+      const uint32_t sum = (c < c_end) ? L.chunk_sums[c] : 0u;
+      const uint32_t inc = hgs_wave_incl_scan(sum);
+      uint32_t base = 0;
+      if (tl == 63 && inc) base = atomicAdd(&L.ctr->entry_alloc, inc);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+      if (c < c_end) L.chunk_base[c] = base + inc - sum;
+    }
+  }
+  __syncthreads();
+  if (v.lds_bins && valid) L.tile_gbase[(size_t)rg * v.TT + g] = start_s[tl] + gbase;
+  if (tid < HGS_NCLS && cls_s[tid]) atomicAdd(&L.ctr->cls_hist[tid], cls_s[tid]);
+
+  // ---- ticket: the last workgroup publishes the status and the class bases.  Everything it
+  // reads was produced by device-scope atomics (performed at the point of coherence).
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    last_s = (atomicAdd(&L.ctr->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  // read the totals with one atomic per lane (33 sequential round trips cost ~20 us here)
+  __shared__ uint32_t tot_s[HGS_NCLS + 8];
+  __threadfence();
+  if (tid < HGS_NCLS) tot_s[tid] = atomicAdd(&L.ctr->cls_hist[tid], 0u);
+  if (tid == 64) { const unsigned long long a = atomicAdd(&L.ctr->alloc_eb, 0ull); tot_s[HGS_NCLS] = (uint32_t)a; tot_s[HGS_NCLS + 1] = (uint32_t)(a >> 32); }
+  if (tid == 128) { const unsigned long long a = atomicAdd(&L.ctr->alloc_ws, 0ull); tot_s[HGS_NCLS + 2] = (uint32_t)a; tot_s[HGS_NCLS + 3] = (uint32_t)(a >> 32); }
+  if (tid == 192) tot_s[HGS_NCLS + 4] = atomicMax(&L.ctr->max_n, 0u);
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t max_n = tot_s[HGS_NCLS + 4];
+    uint32_t acc = 0;
+    for (int c = HGS_NCLS - 1; c >= 0; --c) {      // heavy classes first; class 0 (empty tiles) last
+      L.ctr->cls_cur[c] = acc;
+      acc += tot_s[c];
+    }
+    const uint32_t empty = tot_s[0];
+    const unsigned long long a_eb = (unsigned long long)tot_s[HGS_NCLS] | ((unsigned long long)tot_s[HGS_NCLS + 1] << 32);
+    const unsigned long long a_ws = (unsigned long long)tot_s[HGS_NCLS + 2] | ((unsigned long long)tot_s[HGS_NCLS + 3] << 32);
     hgs_status st;
-    st.num_rendered = R;
-    st.active_tiles = (uint32_t)v.T - cls_hist[0];
-    st.num_buckets = carry3[1];
-    st.bwd_groups = carry3[2];
-    st.overflow = (R > v.entry_capacity) ? 1u : 0u;
-    if (v.max_tile_hint > 0 && max_n_s > (uint32_t)v.max_tile_hint) st.overflow |= 2u;
+    st.num_rendered = (uint32_t)a_eb;
+    st.active_tiles = (uint32_t)v.TT - empty;
+    st.num_buckets = (uint32_t)(a_eb >> 32);
+    st.bwd_groups = (uint32_t)a_ws;
+    st.overflow = (st.num_rendered > v.entry_capacity) ? 1u : 0u;
+    if (v.max_tile_hint > 0 && max_n > (uint32_t)v.max_tile_hint) st.overflow |= 2u;
     st.reserved[0] = v.entry_capacity;   // carve key for hgs_backward
-    st.reserved[1] = max_n_s;            // longest tile list
-    st.reserved[2] = 0;
+    st.reserved[1] = max_n;              // longest tile list
+    st.reserved[2] = (uint32_t)(a_ws >> 32);   // segment planes
     *status = st;
     if (status_host) {            // pinned, device-mapped host memory: no in-stream copy
       *status_host = st;
       __threadfence_system();
     }
   }
-  if (role == 0) return;
-  if (tid == 0) {   // heavy classes first; class 0 (empty tiles) last
-    uint32_t acc = 0;
-    for (int c = 32; c >= 0; --c) { cls_base[c] = acc; acc += cls_hist[c]; }
-  }
-  __syncthreads();
-  // (c) tile_order: a permutation of all tiles, heavy first (order inside a class is free).
-  // Non-empty tiles take a slot with one LDS atomic each; the empty class is handed out
-  // per wave (ballot + prefix popcount) - thousands of same-address atomics otherwise.
-  for (int base = 0; base < v.T; base += SCAN_NT) {
-    const int t = base + tid;
-    uint32_t n = 0;
-    if (t < v.T) {
-      if (lds_tiles) {
-        n = s_n[t];
-      } else if (role == 2) {     // tile_start belongs to another workgroup of this launch
-#pragma unroll
-        for (int rg = 0; rg < HGS_ROW_GROUPS; ++rg) n += L.tile_grp[(size_t)rg * v.T + t];
-      } else {
-        n = L.tile_start[t + 1] - L.tile_start[t];
-      }
-    }
-    const bool empty = (t < v.T) && (n == 0);
-    const unsigned long long ball = __ballot(empty);
-    uint32_t wbase = 0;
-    if ((tid & 63) == 0 && ball) wbase = atomicAdd(&cls_base[0], (uint32_t)__popcll(ball));
-    wbase = (uint32_t)__shfl((int)wbase, 0, 64);
-    if (t < v.T) {
-      uint32_t pos;
-      if (empty)
-        pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
-                                                __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-      else
-        pos = atomicAdd(&cls_base[32 - __clz(n)], 1u);
-      L.tile_order[pos] = (uint32_t)t;
-      L.tile_pos[t] = pos;
-      L.pos_wgstart[pos] = (n + HGS_BUCKET - 1) / HGS_BUCKET;      // buckets of the tile at this position
-    }
-  }
-  // Backward work items in tile_order too (heavy tiles first, a tile's buckets consecutive):
-  // pos_wgstart = exclusive prefix of the bucket counts over positions.  With ~5.6k items on
-  // 4096 wave slots the items that start late must be the light ones.
-  __syncthreads();
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < v.T; base += SCAN_NT * 4) {
-    const int p0 = base + tid * 4;
-    uint32_t nb[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (p0 + k < v.T) nb[k] = L.pos_wgstart[p0 + k];
-    uint32_t total;
-    const uint32_t ex = hgs_block_excl_scan<SCAN_NT>(nb[0] + nb[1] + nb[2] + nb[3], wtot, total);
-    uint32_t run = carry_s + ex;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (p0 + k < v.T) { L.pos_wgstart[p0 + k] = run; run += nb[k]; }
-    __syncthreads();
-    if (tid == 0) carry_s += total;
-    __syncthreads();
-  }
 }
 
 // ---------------------------------------------------------------------------- 2. fill
-// LDS path, part 1: grid (T/256, HGS_ROW_GROUPS).  Thread (t, rg) scans the rows of row group
-// rg of histogram column t in place (hist[g][t] -> entries of tile t owned by earlier
-// workgroups OF THE SAME GROUP) and leaves the group's total in tile_grp[rg][t].
-extern "C" __global__ void __launch_bounds__(256)
-hgs_k_colscan(View v, Layout L) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= v.T) return;
-  const int rg = blockIdx.y;
-  const int rpg = (v.nwg + HGS_ROW_GROUPS - 1) / HGS_ROW_GROUPS;
-  const int g0 = rg * rpg, g1 = min(v.nwg, g0 + rpg);
-  uint32_t run = 0;
-  uint32_t* col = L.hist + t;
-  constexpr int B = 16;
-  for (int g = g0; g < g1; g += B) {
-    uint32_t c[B];
-#pragma unroll
-    for (int k = 0; k < B; ++k) c[k] = (g + k < g1) ? col[(size_t)(g + k) * v.T] : 0u;
-#pragma unroll
-    for (int k = 0; k < B; ++k) {
-      if (g + k < g1) col[(size_t)(g + k) * v.T] = run;
-      run += c[k];
-    }
-  }
-  L.tile_grp[(size_t)rg * v.T + t] = run;
+// LDS path: same workgroup -> chunk ownership as hgs_k_preprocess_fwd.  Slot of an entry =
+// tile_gbase[rg][g] (list start + entries of earlier row groups) + hist[row][t] (entries of
+// earlier workgroups of the group) + an LDS cursor.  Workgroups beyond the binning ones place
+// tiles into tile_order: position = class base (heavy first) + a cursor; the order INSIDE a
+// class is free (it only schedules work).
+__device__ __forceinline__ void place_tiles(const View& v, const Layout& L, int blk) {
+  const int g = blk * HGS_BLOCK + (int)threadIdx.x;
+  const bool valid = g < v.TT;
+  const uint32_t n = valid ? L.tile_n[g] : 0u;
+  const bool empty = valid && n == 0;
+  const unsigned long long ball = __ballot(empty);
+  uint32_t wbase = 0;
+  if ((threadIdx.x & 63) == 0 && ball) wbase = atomicAdd(&L.ctr->cls_cur[0], (uint32_t)__popcll(ball));
+  wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+  if (!valid) return;
+  uint32_t pos;
+  if (empty)
+    pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+  else
+    pos = atomicAdd(&L.ctr->cls_cur[32 - __clz(n)], 1u);
+  L.tile_order[pos] = (uint32_t)g;
 }
 
-// LDS path, part 2: same workgroup -> chunk ownership as hgs_k_preprocess_fwd.  Slot of an
-// entry = tile_start[t] + hist[g][t] (entries of earlier workgroups) + an LDS cursor.
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
-hgs_k_fill(View v, Layout L, const hgs_status* __restrict__ status) {
+hgs_k_fill(View v, Layout L, const hgs_status* __restrict__ status, int nbin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
-  __shared__ uint32_t wtot[HGS_BLOCK / 64];
+  if ((int)blockIdx.x >= nbin) { place_tiles(v, L, (int)blockIdx.x - nbin); return; }
   if (status->overflow) return;
+  const int b = (int)blockIdx.x / v.nwg, lw = (int)blockIdx.x % v.nwg;
   const uint32_t* __restrict__ base_row = L.hist + (size_t)blockIdx.x * v.T;
   const int rpg = (v.nwg + HGS_ROW_GROUPS - 1) / HGS_ROW_GROUPS;
-  const uint32_t* __restrict__ grp_row = L.tile_gbase + (size_t)(blockIdx.x / rpg) * v.T;
+  const uint32_t* __restrict__ grp_row = L.tile_gbase + (size_t)(lw / rpg) * v.TT + (size_t)b * v.T;
   for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_cur[t] = grp_row[t] + base_row[t];
   __syncthreads();
+  const GeomRec* __restrict__ geom = L.geom + (size_t)b * v.P;
   for (int c = 0; c < v.cpw; ++c) {
-    const int chunk = blockIdx.x * v.cpw + c;
+    const int chunk = lw * v.cpw + c;
     if (chunk >= v.nblk) break;
     const int i = chunk * HGS_BLOCK + threadIdx.x;
-    uint32_t lo = 0, hi = 0, depth_bits = 0;
-    if (i < v.P) {
-      const uint4 q2 = reinterpret_cast<const uint4*>(&L.geom[i])[2];   // b, depth, rect_lo, rect_hi
-      depth_bits = q2.y; lo = q2.z; hi = q2.w;
-    }
+    if (i >= v.P) continue;
+    const uint4 q2 = reinterpret_cast<const uint4*>(&geom[i])[2];   // b, depth, rect_lo, rect_hi
+    const uint32_t depth_bits = q2.y, lo = q2.z, hi = q2.w;
     const int minx = lo & 0xffffu, miny = lo >> 16, maxx = hi & 0xffffu, maxy = hi >> 16;
-    const uint32_t tt = (uint32_t)((maxx - minx) * (maxy - miny));
-    uint32_t total;
-    const uint32_t ex = hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
-    if (i < v.P) {
-      L.geom[i].offset = L.block_base[chunk] + ex;
-      const unsigned long long key_hi = (unsigned long long)depth_bits << 32;
-      for (int ty = miny; ty < maxy; ++ty)
-        for (int tx = minx; tx < maxx; ++tx) {
-          const uint32_t slot = atomicAdd(&lds_cur[ty * v.grid_x + tx], 1u);
-          L.keys[slot] = key_hi | (uint32_t)i;
-        }
-    }
+    const unsigned long long key_hi = (unsigned long long)depth_bits << 32;
+    for (int ty = miny; ty < maxy; ++ty)
+      for (int tx = minx; tx < maxx; ++tx) {
+        const uint32_t slot = atomicAdd(&lds_cur[ty * v.grid_x + tx], 1u);
+        L.keys[slot] = key_hi | (uint32_t)i;
+      }
   }
 }
 
 // Fallback (global atomics) for T*4 > 64 KB.
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
-hgs_k_fill_ga(View v, Layout L, const hgs_status* __restrict__ status) {
-  __shared__ uint32_t wtot[HGS_BLOCK / 64];
+hgs_k_fill_ga(View v, Layout L, const hgs_status* __restrict__ status, int nbin) {
+  if ((int)blockIdx.x >= nbin) { place_tiles(v, L, (int)blockIdx.x - nbin); return; }
   if (status->overflow) return;
-  const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
-  uint32_t lo = 0, hi = 0, depth_bits = 0;
-  if (i < v.P) {
-    const uint4 q2 = reinterpret_cast<const uint4*>(&L.geom[i])[2];   // b, depth, rect_lo, rect_hi
-    depth_bits = q2.y; lo = q2.z; hi = q2.w;
-  }
-  const int minx = lo & 0xffffu, miny = lo >> 16, maxx = hi & 0xffffu, maxy = hi >> 16;
-  const uint32_t tt = (uint32_t)((maxx - minx) * (maxy - miny));
-  uint32_t total;
-  const uint32_t ex = hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
+  const int b = (int)blockIdx.x / v.nblk, chunk = (int)blockIdx.x % v.nblk;
+  const int i = chunk * HGS_BLOCK + threadIdx.x;
   if (i >= v.P) return;
-  L.geom[i].offset = L.block_base[blockIdx.x] + ex;
-  if (tt == 0) return;
+  const uint4 q2 = reinterpret_cast<const uint4*>(&L.geom[(size_t)b * v.P + i])[2];   // b, depth, rect_lo, rect_hi
+  const uint32_t depth_bits = q2.y, lo = q2.z, hi = q2.w;
+  const int minx = lo & 0xffffu, miny = lo >> 16, maxx = hi & 0xffffu, maxy = hi >> 16;
   const unsigned long long key_hi = (unsigned long long)depth_bits << 32;
   for (int ty = miny; ty < maxy; ++ty)
     for (int tx = minx; tx < maxx; ++tx) {
-      const int t = ty * v.grid_x + tx;
-      const uint32_t slot = L.tile_start[t] + atomicAdd(&L.tile_count[t], 1u);
+      const size_t g = (size_t)b * v.T + ty * v.grid_x + tx;
+      const uint32_t slot = L.tile_start[g] + atomicAdd(&L.tile_count[g], 1u);
       L.keys[slot] = key_hi | (uint32_t)i;
     }
 }
@@ -394,17 +249,20 @@ hgs_k_fill_ga(View v, Layout L, const hgs_status* __restrict__ status) {
 // ---------------------------------------------------------------------------- 3. sort
 namespace {
 
-__device__ __forceinline__ void gather_records(const View& v, const Layout& L, int t,
+__device__ __forceinline__ void gather_records(const View& v, const Layout& L, int g,
                                                uint32_t start, uint32_t n,
                                                const unsigned long long* sorted, int nt) {
+  const int t = g % v.T;
+  const GeomRec* __restrict__ geom = L.geom + (size_t)(g / v.T) * v.P;
+  const uint32_t* __restrict__ cbase = L.chunk_base + (size_t)(g / v.T) * v.nblk;
   const int tx = t % v.grid_x, ty = t / v.grid_x;
   const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
   {  // (tile, segment) table of the long lists: the segment kernels find their work with one load
     const uint32_t nseg = hgs_nseg(n);
     if (nseg > 1) {
-      const uint32_t ms0 = L.tile_msegstart[t], item_bound = 2u * (uint32_t)(v.entry_capacity / HGS_SEG) + 2u;
+      const uint32_t ms0 = L.tile_msegstart[g], item_bound = 2u * (uint32_t)(v.entry_capacity / HGS_SEG) + 2u;
       for (uint32_t sg = threadIdx.x; sg < nseg && ms0 + sg < item_bound; sg += nt)
-        L.seg_item[ms0 + sg] = make_uint2((uint32_t)t, sg);
+        L.seg_item[ms0 + sg] = make_uint2((uint32_t)g, sg);
     }
   }
   // GU records per thread in flight: the 64 B geom gathers are dependent random reads (~1-2 us
@@ -422,7 +280,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
     for (int u = 0; u < GU; ++u) {
       const uint32_t k = kb + (uint32_t)u * nt;
       if (k < n) {
-        const uint4* gp = reinterpret_cast<const uint4*>(&L.geom[idxv[u]]);
+        const uint4* gp = reinterpret_cast<const uint4*>(&geom[idxv[u]]);
         q0[u] = gp[0]; q1[u] = gp[1]; q2[u] = gp[2]; q3[u] = gp[3];
       }
     }
@@ -434,7 +292,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
       const uint4 g0 = q0[u], g1 = q1[u], g2 = q2[u], g3 = q3[u];
       // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | g3: offset radius ..
       const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
-      const uint32_t entry = g3.x + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+      const uint32_t entry = cbase[idx >> 8] + g3.x + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
       const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
       const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
       const float op = __uint_as_float(g1.y);
@@ -686,7 +544,7 @@ hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
   if (b >= status->active_tiles) return;
   const int t = (int)L.tile_order[b];
   const uint32_t start = L.tile_start[t];
-  const uint32_t n = L.tile_start[t + 1] - start;
+  const uint32_t n = L.tile_n[t];
   if (n == 0 || n > 4096u) return;
   constexpr int E0 = 1024 / HGS_SORT_NT;
   if (n <= 1024u) sort_one_tile<E0, HGS_SORT_NT>(v, L, t, start, n, keys);
@@ -702,7 +560,7 @@ hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   if (b >= status->active_tiles) return;
   const int t = (int)L.tile_order[b];
   const uint32_t start = L.tile_start[t];
-  const uint32_t n = L.tile_start[t + 1] - start;
+  const uint32_t n = L.tile_n[t];
   if (n <= 4096u || n > 16384u) return;
   // long lists: the plain LDS network with all 1024 threads on 2 comparators per stage
   // beats 16 keys per thread in registers (measured at 500k Gaussians: 181 vs 220 us) and ties
@@ -723,7 +581,7 @@ hgs_k_sort_huge(View v, Layout L, const hgs_status* __restrict__ status) {
   if (b >= status->active_tiles) return;
   const int t = (int)L.tile_order[b];
   const uint32_t start = L.tile_start[t];
-  const uint32_t n = L.tile_start[t + 1] - start;
+  const uint32_t n = L.tile_n[t];
   if (n <= 16384u) return;
   bitonic_sort<1024>(L.keys + start, n);
   gather_records(v, L, t, start, n, L.keys + start, 1024);

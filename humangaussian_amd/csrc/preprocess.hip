@@ -6,9 +6,13 @@
 // written in the exact left-to-right order of oracle/gs_oracle.py::preprocess and the
 // library is built with -ffp-contract=off, so radii / rects match the oracle bit-for-bit.
 //
+// Batched: the forward runs over the B*P (view, Gaussian) instances of a call; the backward runs
+// one thread per Gaussian that walks its B views in order and writes every parameter gradient
+// ONCE as the sum over the views (deterministic; dL/dmeans2D stays per view).
+//
 // Roofline: pure streaming, HBM-bound.  Forward reads 44+12*M' B and writes 64+4 B per
-// Gaussian (M' = active SH coefficients); backward reads 44+12*M' + 64 + 48*tiles_touched
-// and writes 56+12*M B.
+// (view, Gaussian) (M' = active SH coefficients); backward reads 44+12*M' + B*(64 +
+// 48*tiles_touched) and writes 44+12*M + 12*B bytes per Gaussian.
 #include "hgs_common.h"
 
 namespace {
@@ -82,7 +86,7 @@ __device__ __forceinline__ void view_point(const float* __restrict__ V, float x,
   tz = V[2] * x + V[6] * y + V[10] * z + V[14];
 }
 
-__device__ __forceinline__ void project_cov(const View& v, const float* __restrict__ V,
+__device__ __forceinline__ void project_cov(const Cam& v, const float* __restrict__ V,
                                             const Cov3& s, Proj2D& o) {
   const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
   const float txtz = o.tx0 / o.tz, tytz = o.ty0 / o.tz;
@@ -164,12 +168,12 @@ namespace {
 
 // Everything stage F1 computes for Gaussian i.  Returns tiles_touched.
 __device__ __forceinline__ uint32_t preprocess_one(
-    const View& v, int i, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const View& v, const Cam& cam, int i, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, GeomRec& rec) {
-  const float* __restrict__ V = v.viewmatrix;
-  const float* __restrict__ PM = v.projmatrix;
+  const float* __restrict__ V = cam.viewmatrix;
+  const float* __restrict__ PM = cam.projmatrix;
   rec.mx = rec.my = rec.ca = rec.cb = rec.cc = rec.op = 0.f;
   rec.r = rec.g = rec.b = rec.depth = 0.f;
   rec.rect_lo = rec.rect_hi = rec.offset = 0u;
@@ -191,7 +195,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
   } else {
     s = cov3d_from(make_rotscale(scales, rotations, i, v.scale_modifier));
   }
-  project_cov(v, V, s, pj);
+  project_cov(cam, V, s, pj);
   if (pj.det == 0.0f) return 0;
   const float det_inv = 1.0f / pj.det;
   const float mid = 0.5f * (pj.a + pj.c);
@@ -220,7 +224,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     rec.g = colors_precomp[3 * i + 1];
     rec.b = colors_precomp[3 * i + 2];
   } else {
-    const float* cp = v.campos;
+    const float* cp = cam.campos;
     const float ddx = x - cp[0], ddy = y - cp[1], ddz = z - cp[2];
     const float n = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
     float col[3];
@@ -251,10 +255,25 @@ __device__ __forceinline__ void store_geom(GeomRec* dstp, const GeomRec& rec) {
 
 }  // namespace
 
-// LDS-histogram variant (T*4 bytes of dynamic LDS <= 64 KB).  Workgroup g owns the
-// Gaussian chunks [g*cpw, (g+1)*cpw) (256 Gaussians each); it counts its tile hits with
-// LDS atomics and writes its histogram ROW hist[g][0..T) - no global atomics at all.
-// Also emits each chunk's sum of tiles_touched for the entry-id scan.
+// Entry ids: a Gaussian's tiles_touched entries get CONTIGUOUS ids = chunk base + exclusive prefix
+// inside its 256-Gaussian chunk.  The prefix is formed here; the chunk bases are bump-allocated by
+// hgs_k_tiles from the chunk sums written here (where a range lives is irrelevant: the rows of
+// one Gaussian are contiguous and summed in a fixed order by hgs_k_preprocess_bwd).
+__device__ __forceinline__ uint32_t chunk_prefix(uint32_t tt, uint32_t* wtot, uint32_t* chunk_sum) {
+  uint32_t total;
+  const uint32_t ex = hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
+  if (threadIdx.x == 0) *chunk_sum = total;
+  return ex;
+}
+
+// the first workgroup of the first kernel of a forward call clears the call's counters
+__device__ __forceinline__ void zero_counters(const Layout& L) {
+  if (blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) reinterpret_cast<uint32_t*>(L.ctr)[threadIdx.x] = 0u;
+}
+
+// LDS-histogram variant (T*4 bytes of dynamic LDS <= 64 KB).  Workgroup (view b, g) owns the
+// Gaussian chunks [g*cpw, (g+1)*cpw) of view b (256 Gaussians each); it counts its tile hits with
+// LDS atomics and writes its histogram ROW hist[b*nwg + g][0..T) - no global atomics per entry.
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
 hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
                      const float* __restrict__ shs, const float* __restrict__ colors_precomp,
@@ -263,20 +282,22 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
                      const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
+  zero_counters(L);
+  const int b = (int)blockIdx.x / v.nwg, lw = (int)blockIdx.x % v.nwg;
+  const Cam cam = v.cam[b];
   for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_hist[t] = 0u;
   __syncthreads();
   const int gxm = v.grid_x;
   for (int c = 0; c < v.cpw; ++c) {
-    const int chunk = blockIdx.x * v.cpw + c;
+    const int chunk = lw * v.cpw + c;
     if (chunk >= v.nblk) break;
     const int i = chunk * HGS_BLOCK + threadIdx.x;
     uint32_t tt = 0;
+    GeomRec rec;
     if (i < v.P) {
-      GeomRec rec;
-      tt = preprocess_one(v, i, means3D, shs, colors_precomp, opacities, scales, rotations,
+      tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
                           cov3D_precomp, rec);
-      radii[i] = rec.radius;
-      store_geom(&L.geom[i], rec);
+      radii[(size_t)b * v.P + i] = rec.radius;
       if (tt) {
         const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;
         const int maxx = rec.rect_hi & 0xffffu, maxy = rec.rect_hi >> 16;
@@ -284,9 +305,11 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
           for (int tx = minx; tx < maxx; ++tx) atomicAdd(&lds_hist[ty * gxm + tx], 1u);
       }
     }
-    uint32_t total;
-    (void)hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
-    if (threadIdx.x == 0) L.block_sums[chunk] = total;
+    const uint32_t off = chunk_prefix(tt, wtot, &L.chunk_sums[(size_t)b * v.nblk + chunk]);
+    if (i < v.P) {
+      rec.offset = off;
+      store_geom(&L.geom[(size_t)b * v.P + i], rec);
+    }
   }
   __syncthreads();
   uint32_t* row = L.hist + (size_t)blockIdx.x * v.T;
@@ -302,207 +325,226 @@ hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
                         const float* __restrict__ rotations,
                         const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
-  const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  zero_counters(L);
+  const int b = (int)blockIdx.x / v.nblk, chunk = (int)blockIdx.x % v.nblk;
+  const Cam cam = v.cam[b];
+  const int i = chunk * HGS_BLOCK + threadIdx.x;
   uint32_t tt = 0;
+  GeomRec rec;
   if (i < v.P) {
-    GeomRec rec;
-    tt = preprocess_one(v, i, means3D, shs, colors_precomp, opacities, scales, rotations,
+    tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
                         cov3D_precomp, rec);
-    radii[i] = rec.radius;
-    store_geom(&L.geom[i], rec);
+    radii[(size_t)b * v.P + i] = rec.radius;
     if (tt) {
       const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;
       const int maxx = rec.rect_hi & 0xffffu, maxy = rec.rect_hi >> 16;
+      uint32_t* cnt = L.tile_count + (size_t)b * v.T;
       for (int ty = miny; ty < maxy; ++ty)
-        for (int tx = minx; tx < maxx; ++tx) atomicAdd(&L.tile_count[ty * v.grid_x + tx], 1u);
+        for (int tx = minx; tx < maxx; ++tx) atomicAdd(&cnt[ty * v.grid_x + tx], 1u);
     }
   }
-  uint32_t total;
-  (void)hgs_block_excl_scan<HGS_BLOCK>(tt, wtot, total);
-  if (threadIdx.x == 0) L.block_sums[blockIdx.x] = total;
+  const uint32_t off = chunk_prefix(tt, wtot, &L.chunk_sums[blockIdx.x]);
+  if (i < v.P) {
+    rec.offset = off;
+    store_geom(&L.geom[(size_t)b * v.P + i], rec);
+  }
 }
 
 // ----------------------------------------------------------------------------- backward
-// One thread per Gaussian: sums its tiles_touched gradient rows (contiguous, fixed order
-// => deterministic), then chains through conic -> cov2D -> (cov3D, mean), projection,
-// depth, SH and Sigma = R S^2 R^T.  Every output element is written exactly once.
-extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
-hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
-                     const float* __restrict__ grad_rows,
-                     const float* __restrict__ means3D, const float* __restrict__ shs,
-                     const float* __restrict__ colors_precomp,
-                     const float* __restrict__ scales, const float* __restrict__ rotations,
-                     const float* __restrict__ cov3D_precomp,
-                     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
-                     float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
-                     float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,
-                     float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+// One thread per Gaussian.  For every view of the batch, in view order: sums the Gaussian's
+// tiles_touched gradient rows (contiguous, fixed order => deterministic), then chains through
+// conic -> cov2D -> (cov3D, mean), projection, depth, SH and Sigma = R S^2 R^T, and ADDS the
+// view's parameter gradients to running sums.  Every output element is written exactly once;
+// dL/dmeans2D is written per view.  Instantiated per active SH degree so that the (M,3)
+// gradient block accumulates in registers with constant indices.
+namespace {
+
+template <int DEG>
+__device__ __forceinline__ void preprocess_bwd_body(
+    const View& v, const Layout& L, const hgs_status* __restrict__ status,
+    const float* __restrict__ grad_rows, const float* __restrict__ means3D,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, float* __restrict__ dL_dmeans3D,
+    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
+    float* __restrict__ dL_dopac, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
+    float* __restrict__ dL_dcov3D) {
+  constexpr int NC = (DEG + 1) * (DEG + 1);       // active SH coefficients
   const int i = blockIdx.x * HGS_BLOCK + threadIdx.x;
   if (i >= v.P) return;
-  const float* __restrict__ V = v.viewmatrix;
-  const float* __restrict__ PM = v.projmatrix;
-  const GeomRec g = L.geom[i];
+  const bool ok = status->overflow == 0;
 
-  float gmx = 0.f, gmy = 0.f, gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f;
-  float gr = 0.f, gg = 0.f, gb = 0.f, gdep = 0.f;
-  float dmean[3] = {0.f, 0.f, 0.f};
-  float dsc[3] = {0.f, 0.f, 0.f};
-  float drot[4] = {0.f, 0.f, 0.f, 0.f};
-  float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float draw[3] = {0.f, 0.f, 0.f};     // gradient wrt the pre-clamp colour
-  const bool vis = (g.radius > 0) && (status->overflow == 0);
-
-  if (vis) {
-    const int rw = (int)(g.rect_hi & 0xffffu) - (int)(g.rect_lo & 0xffffu);
-    const int rh = (int)(g.rect_hi >> 16) - (int)(g.rect_lo >> 16);
-    const int tt = rw * rh;
-    const float4* rows = reinterpret_cast<const float4*>(grad_rows) + 3 * (size_t)g.offset;
-    for (int k = 0; k < tt; ++k) {
-      const float4 r0 = rows[3 * k + 0], r1 = rows[3 * k + 1], r2 = rows[3 * k + 2];
-      gmx += r0.x; gmy += r0.y; gA += r0.z; gB += r0.w;
-      gC += r1.x; gop += r1.y; gr += r1.z; gg += r1.w;
-      gb += r2.x; gdep += r2.y;
-    }
-
-    const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
-    Proj2D pj;
-    view_point(V, x, y, z, pj.tx0, pj.ty0, pj.tz);
-    Cov3 s;
-    RotScale rs;
-    if (cov3D_precomp) {
-      const float* c = cov3D_precomp + 6 * (size_t)i;
-      s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
+  // ---- view-independent inputs, loaded once
+  const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+  Cov3 s;
+  RotScale rs;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cov3D_precomp) {
+    const float* c = cov3D_precomp + 6 * (size_t)i;
+    s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
+  } else {
+    rs = make_rotscale(scales, rotations, i, v.scale_modifier);
+    s = cov3d_from(rs);
+    q = reinterpret_cast<const float4*>(rotations)[i];
+  }
+  const bool want_sh = dL_dshs != nullptr && shs != nullptr;
+  float sh48[48];
+  if (DEG > 0 && want_sh) {
+    if (sh_block_vectorisable(v.M)) {
+      load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
     } else {
-      rs = make_rotscale(scales, rotations, i, v.scale_modifier);
-      s = cov3d_from(rs);
-    }
-    project_cov(v, V, s, pj);
-
-    // ---- conic -> cov2D (a, b, c)
-    const float a = pj.a, b = pj.b, c = pj.c;
-    const float inv2 = 1.0f / (pj.det * pj.det);
-    const float dLa = inv2 * (-c * c * gA + b * c * gB - b * b * gC);
-    const float dLb = inv2 * (2.0f * b * c * gA - (pj.det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
-    const float dLc = inv2 * (-b * b * gA + a * b * gB - a * a * gC);
-
-    // ---- cov2D -> packed cov3D
-    const float M0[3] = {pj.M00, pj.M01, pj.M02}, M1[3] = {pj.M10, pj.M11, pj.M12};
-    dcov[0] = dLa * M0[0] * M0[0] + dLb * M0[0] * M1[0] + dLc * M1[0] * M1[0];
-    dcov[3] = dLa * M0[1] * M0[1] + dLb * M0[1] * M1[1] + dLc * M1[1] * M1[1];
-    dcov[5] = dLa * M0[2] * M0[2] + dLb * M0[2] * M1[2] + dLc * M1[2] * M1[2];
-    dcov[1] = 2.f * dLa * M0[0] * M0[1] + dLb * (M0[0] * M1[1] + M0[1] * M1[0]) + 2.f * dLc * M1[0] * M1[1];
-    dcov[2] = 2.f * dLa * M0[0] * M0[2] + dLb * (M0[0] * M1[2] + M0[2] * M1[0]) + 2.f * dLc * M1[0] * M1[2];
-    dcov[4] = 2.f * dLa * M0[1] * M0[2] + dLb * (M0[1] * M1[2] + M0[2] * M1[1]) + 2.f * dLc * M1[1] * M1[2];
-
-    // ---- cov2D -> M -> J -> t
-    const float u[3] = {pj.u0, pj.u1, pj.u2}, w[3] = {pj.w0, pj.w1, pj.w2};
-    float dM0[3], dM1[3];
+      const float* shp = shs + (size_t)i * v.M * 3;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      dM0[k] = 2.f * dLa * u[k] + dLb * w[k];
-      dM1[k] = 2.f * dLc * w[k] + dLb * u[k];
-    }
-    const float dJ00 = dM0[0] * V[0] + dM0[1] * V[4] + dM0[2] * V[8];
-    const float dJ02 = dM0[0] * V[2] + dM0[1] * V[6] + dM0[2] * V[10];
-    const float dJ11 = dM1[0] * V[1] + dM1[1] * V[5] + dM1[2] * V[9];
-    const float dJ12 = dM1[0] * V[2] + dM1[1] * V[6] + dM1[2] * V[10];
-    const float tzi = 1.0f / pj.tz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
-    const float fx = v.focal_x, fy = v.focal_y;
-    float dt[3];
-    dt[0] = pj.clx ? 0.f : -fx * tz2 * dJ02;
-    dt[1] = pj.cly ? 0.f : -fy * tz2 * dJ12;
-    dt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + 2.f * fx * pj.tx * tz3 * dJ02 +
-            2.f * fy * pj.ty * tz3 * dJ12;
-    // depth head: depth = t.z
-    dt[2] += gdep;
-#pragma unroll
-    for (int bq = 0; bq < 3; ++bq)
-      dmean[bq] += V[4 * bq + 0] * dt[0] + V[4 * bq + 1] * dt[1] + V[4 * bq + 2] * dt[2];
-
-    // ---- pixel mean -> NDC -> homogeneous -> mean
-    const float dpx = gmx * 0.5f * (float)v.W, dpy = gmy * 0.5f * (float)v.H;
-    const float hx = PM[0] * x + PM[4] * y + PM[8] * z + PM[12];
-    const float hy = PM[1] * x + PM[5] * y + PM[9] * z + PM[13];
-    const float hw = PM[3] * x + PM[7] * y + PM[11] * z + PM[15];
-    const float pw = 1.0f / (hw + 0.0000001f);
-    const float dhx = dpx * pw, dhy = dpy * pw;
-    const float dhw = -(dpx * hx + dpy * hy) * pw * pw;
-#pragma unroll
-    for (int bq = 0; bq < 3; ++bq)
-      dmean[bq] += PM[4 * bq + 0] * dhx + PM[4 * bq + 1] * dhy + PM[4 * bq + 3] * dhw;
-
-    // ---- colour
-    if (!colors_precomp) {
-      draw[0] = (g.clamped & 1u) ? 0.f : gr;
-      draw[1] = (g.clamped & 2u) ? 0.f : gg;
-      draw[2] = (g.clamped & 4u) ? 0.f : gb;
-    }
-
-    // ---- Sigma -> scale / rotation
-    if (!cov3D_precomp) {
-      const float G00 = dcov[0], G11 = dcov[3], G22 = dcov[5];
-      const float G01 = 0.5f * dcov[1], G02 = 0.5f * dcov[2], G12 = 0.5f * dcov[4];
-      const float Lm[3][3] = {{rs.R00 * rs.sx, rs.R01 * rs.sy, rs.R02 * rs.sz},
-                              {rs.R10 * rs.sx, rs.R11 * rs.sy, rs.R12 * rs.sz},
-                              {rs.R20 * rs.sx, rs.R21 * rs.sy, rs.R22 * rs.sz}};
-      const float Gm[3][3] = {{G00, G01, G02}, {G01, G11, G12}, {G02, G12, G22}};
-      const float Rm[3][3] = {{rs.R00, rs.R01, rs.R02}, {rs.R10, rs.R11, rs.R12},
-                              {rs.R20, rs.R21, rs.R22}};
-      const float sv[3] = {rs.sx, rs.sy, rs.sz};
-      float D[3][3];   // dL/dR
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float ds = 0.f;
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-          const float dLik = 2.f * (Gm[ii][0] * Lm[0][k] + Gm[ii][1] * Lm[1][k] + Gm[ii][2] * Lm[2][k]);
-          ds += dLik * Rm[ii][k];
-          D[ii][k] = dLik * sv[k];
-        }
-        dsc[k] = ds * v.scale_modifier;
-      }
-      const float4 q = reinterpret_cast<const float4*>(rotations)[i];
-      const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
-      drot[0] = 2.f * (-qz * D[0][1] + qy * D[0][2] + qz * D[1][0] - qx * D[1][2] - qy * D[2][0] + qx * D[2][1]);
-      drot[1] = 2.f * (qy * D[0][1] + qz * D[0][2] + qy * D[1][0] - 2.f * qx * D[1][1] - r * D[1][2] +
-                       qz * D[2][0] + r * D[2][1] - 2.f * qx * D[2][2]);
-      drot[2] = 2.f * (-2.f * qy * D[0][0] + qx * D[0][1] + r * D[0][2] + qx * D[1][0] + qz * D[1][2] -
-                       r * D[2][0] + qz * D[2][1] - 2.f * qy * D[2][2]);
-      drot[3] = 2.f * (-2.f * qz * D[0][0] - r * D[0][1] + qx * D[0][2] + r * D[1][0] - 2.f * qz * D[1][1] +
-                       qy * D[1][2] + qx * D[2][0] + qy * D[2][1]);
+      for (int k = 3; k < 48; ++k) sh48[k] = (k < 3 * NC) ? shp[k] : 0.f;   // degree >= 1 terms only
     }
   }
 
-  // ---- SH backward (writes dL_dshs for every Gaussian, zeros when culled)
-  if (dL_dshs) {
-    float* out = dL_dshs + (size_t)i * v.M * 3;
-    const int ncoef = (v.D + 1) * (v.D + 1);
-    if (vis && shs) {
-      const float* cp = v.campos;
-      const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
-      const float ox = x - cp[0], oy = y - cp[1], oz = z - cp[2];
-      const float n = sqrtf(ox * ox + oy * oy + oz * oz);
-      const float dx = ox / n, dy = oy / n, dz = oz / n;
-      float sh48[48];
-      if (sh_block_vectorisable(v.M)) {
-        load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
-      } else {
-        const float* shp = shs + (size_t)i * v.M * 3;
+  // ---- sums over the views
+  float a_mean[3] = {0.f, 0.f, 0.f}, a_sc[3] = {0.f, 0.f, 0.f}, a_rot[4] = {0.f, 0.f, 0.f, 0.f};
+  float a_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a_col[3] = {0.f, 0.f, 0.f}, a_op = 0.f;
+  float a_sh[3 * NC];
 #pragma unroll
-        for (int k = 3; k < 48; ++k) sh48[k] = (k < 3 * ncoef) ? shp[k] : 0.f;   // degree >= 1 terms only
+  for (int k = 0; k < 3 * NC; ++k) a_sh[k] = 0.f;
+
+  for (int b = 0; b < v.B; ++b) {
+    const Cam cam = v.cam[b];
+    const float* __restrict__ V = cam.viewmatrix;
+    const float* __restrict__ PM = cam.projmatrix;
+    const GeomRec g = L.geom[(size_t)b * v.P + i];
+    float gmx = 0.f, gmy = 0.f;
+    if ((g.radius > 0) && ok) {
+      float gA = 0.f, gB = 0.f, gC = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gdep = 0.f;
+      const int rw = (int)(g.rect_hi & 0xffffu) - (int)(g.rect_lo & 0xffffu);
+      const int rh = (int)(g.rect_hi >> 16) - (int)(g.rect_lo >> 16);
+      const int tt = rw * rh;
+      const float4* rows = reinterpret_cast<const float4*>(grad_rows) +
+                           3 * (size_t)(L.chunk_base[(size_t)b * v.nblk + (i >> 8)] + g.offset);
+      for (int k = 0; k < tt; ++k) {
+        const float4 r0 = rows[3 * k + 0], r1 = rows[3 * k + 1], r2 = rows[3 * k + 2];
+        gmx += r0.x; gmy += r0.y; gA += r0.z; gB += r0.w;
+        gC += r1.x; gop += r1.y; gr += r1.z; gg += r1.w;
+        gb += r2.x; gdep += r2.y;
       }
-      float basis[16];
-      basis[0] = SH_C0;
-      float ddir[3] = {0.f, 0.f, 0.f};
-      if (v.D > 0) {
-        basis[1] = -SH_C1 * dy; basis[2] = SH_C1 * dz; basis[3] = -SH_C1 * dx;
+      a_op += gop;
+      a_col[0] += gr; a_col[1] += gg; a_col[2] += gb;
+
+      Proj2D pj;
+      view_point(V, x, y, z, pj.tx0, pj.ty0, pj.tz);
+      project_cov(cam, V, s, pj);
+
+      // ---- conic -> cov2D (a, b, c)
+      const float a = pj.a, bq_ = pj.b, c = pj.c;
+      const float inv2 = 1.0f / (pj.det * pj.det);
+      const float dLa = inv2 * (-c * c * gA + bq_ * c * gB - bq_ * bq_ * gC);
+      const float dLb = inv2 * (2.0f * bq_ * c * gA - (pj.det + 2.0f * bq_ * bq_) * gB + 2.0f * a * bq_ * gC);
+      const float dLc = inv2 * (-bq_ * bq_ * gA + a * bq_ * gB - a * a * gC);
+
+      // ---- cov2D -> packed cov3D
+      const float M0[3] = {pj.M00, pj.M01, pj.M02}, M1[3] = {pj.M10, pj.M11, pj.M12};
+      float dcov[6];
+      dcov[0] = dLa * M0[0] * M0[0] + dLb * M0[0] * M1[0] + dLc * M1[0] * M1[0];
+      dcov[3] = dLa * M0[1] * M0[1] + dLb * M0[1] * M1[1] + dLc * M1[1] * M1[1];
+      dcov[5] = dLa * M0[2] * M0[2] + dLb * M0[2] * M1[2] + dLc * M1[2] * M1[2];
+      dcov[1] = 2.f * dLa * M0[0] * M0[1] + dLb * (M0[0] * M1[1] + M0[1] * M1[0]) + 2.f * dLc * M1[0] * M1[1];
+      dcov[2] = 2.f * dLa * M0[0] * M0[2] + dLb * (M0[0] * M1[2] + M0[2] * M1[0]) + 2.f * dLc * M1[0] * M1[2];
+      dcov[4] = 2.f * dLa * M0[1] * M0[2] + dLb * (M0[1] * M1[2] + M0[2] * M1[1]) + 2.f * dLc * M1[1] * M1[2];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          ddir[0] += draw[ch] * (-SH_C1 * sh48[9 + ch]);
-          ddir[1] += draw[ch] * (-SH_C1 * sh48[3 + ch]);
-          ddir[2] += draw[ch] * (SH_C1 * sh48[6 + ch]);
+      for (int k = 0; k < 6; ++k) a_cov[k] += dcov[k];
+
+      // ---- cov2D -> M -> J -> t
+      const float u[3] = {pj.u0, pj.u1, pj.u2}, w[3] = {pj.w0, pj.w1, pj.w2};
+      float dM0[3], dM1[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dM0[k] = 2.f * dLa * u[k] + dLb * w[k];
+        dM1[k] = 2.f * dLc * w[k] + dLb * u[k];
+      }
+      const float dJ00 = dM0[0] * V[0] + dM0[1] * V[4] + dM0[2] * V[8];
+      const float dJ02 = dM0[0] * V[2] + dM0[1] * V[6] + dM0[2] * V[10];
+      const float dJ11 = dM1[0] * V[1] + dM1[1] * V[5] + dM1[2] * V[9];
+      const float dJ12 = dM1[0] * V[2] + dM1[1] * V[6] + dM1[2] * V[10];
+      const float tzi = 1.0f / pj.tz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
+      const float fx = cam.focal_x, fy = cam.focal_y;
+      float dt[3];
+      dt[0] = pj.clx ? 0.f : -fx * tz2 * dJ02;
+      dt[1] = pj.cly ? 0.f : -fy * tz2 * dJ12;
+      dt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + 2.f * fx * pj.tx * tz3 * dJ02 +
+              2.f * fy * pj.ty * tz3 * dJ12;
+      // depth head: depth = t.z
+      dt[2] += gdep;
+      float dmean[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq)
+        dmean[bq] += V[4 * bq + 0] * dt[0] + V[4 * bq + 1] * dt[1] + V[4 * bq + 2] * dt[2];
+
+      // ---- pixel mean -> NDC -> homogeneous -> mean
+      const float dpx = gmx * 0.5f * (float)v.W, dpy = gmy * 0.5f * (float)v.H;
+      const float hx = PM[0] * x + PM[4] * y + PM[8] * z + PM[12];
+      const float hy = PM[1] * x + PM[5] * y + PM[9] * z + PM[13];
+      const float hw = PM[3] * x + PM[7] * y + PM[11] * z + PM[15];
+      const float pw = 1.0f / (hw + 0.0000001f);
+      const float dhx = dpx * pw, dhy = dpy * pw;
+      const float dhw = -(dpx * hx + dpy * hy) * pw * pw;
+#pragma unroll
+      for (int bq = 0; bq < 3; ++bq)
+        dmean[bq] += PM[4 * bq + 0] * dhx + PM[4 * bq + 1] * dhy + PM[4 * bq + 3] * dhw;
+
+      // ---- Sigma -> scale / rotation
+      if (!cov3D_precomp) {
+        const float G00 = dcov[0], G11 = dcov[3], G22 = dcov[5];
+        const float G01 = 0.5f * dcov[1], G02 = 0.5f * dcov[2], G12 = 0.5f * dcov[4];
+        const float Lm[3][3] = {{rs.R00 * rs.sx, rs.R01 * rs.sy, rs.R02 * rs.sz},
+                                {rs.R10 * rs.sx, rs.R11 * rs.sy, rs.R12 * rs.sz},
+                                {rs.R20 * rs.sx, rs.R21 * rs.sy, rs.R22 * rs.sz}};
+        const float Gm[3][3] = {{G00, G01, G02}, {G01, G11, G12}, {G02, G12, G22}};
+        const float Rm[3][3] = {{rs.R00, rs.R01, rs.R02}, {rs.R10, rs.R11, rs.R12},
+                                {rs.R20, rs.R21, rs.R22}};
+        const float sv[3] = {rs.sx, rs.sy, rs.sz};
+        float D[3][3];   // dL/dR
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float ds = 0.f;
+#pragma unroll
+          for (int ii = 0; ii < 3; ++ii) {
+            const float dLik = 2.f * (Gm[ii][0] * Lm[0][k] + Gm[ii][1] * Lm[1][k] + Gm[ii][2] * Lm[2][k]);
+            ds += dLik * Rm[ii][k];
+            D[ii][k] = dLik * sv[k];
+          }
+          a_sc[k] += ds * v.scale_modifier;
         }
-        if (v.D > 1) {
+        const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
+        a_rot[0] += 2.f * (-qz * D[0][1] + qy * D[0][2] + qz * D[1][0] - qx * D[1][2] - qy * D[2][0] + qx * D[2][1]);
+        a_rot[1] += 2.f * (qy * D[0][1] + qz * D[0][2] + qy * D[1][0] - 2.f * qx * D[1][1] - r * D[1][2] +
+                           qz * D[2][0] + r * D[2][1] - 2.f * qx * D[2][2]);
+        a_rot[2] += 2.f * (-2.f * qy * D[0][0] + qx * D[0][1] + r * D[0][2] + qx * D[1][0] + qz * D[1][2] -
+                           r * D[2][0] + qz * D[2][1] - 2.f * qy * D[2][2]);
+        a_rot[3] += 2.f * (-2.f * qz * D[0][0] - r * D[0][1] + qx * D[0][2] + r * D[1][0] - 2.f * qz * D[1][1] +
+                           qy * D[1][2] + qx * D[2][0] + qy * D[2][1]);
+      }
+
+      // ---- colour -> SH coefficients and the view direction (into the mean)
+      if (want_sh) {
+        float draw[3];                   // gradient wrt the pre-clamp colour
+        draw[0] = (g.clamped & 1u) ? 0.f : gr;
+        draw[1] = (g.clamped & 2u) ? 0.f : gg;
+        draw[2] = (g.clamped & 4u) ? 0.f : gb;
+        const float* cp = cam.campos;
+        const float ox = x - cp[0], oy = y - cp[1], oz = z - cp[2];
+        const float n = sqrtf(ox * ox + oy * oy + oz * oz);
+        const float dx = ox / n, dy = oy / n, dz = oz / n;
+        float basis[NC];
+        basis[0] = SH_C0;
+        float ddir[3] = {0.f, 0.f, 0.f};
+        if constexpr (DEG > 0) {
+          basis[1] = -SH_C1 * dy; basis[2] = SH_C1 * dz; basis[3] = -SH_C1 * dx;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            ddir[0] += draw[ch] * (-SH_C1 * sh48[9 + ch]);
+            ddir[1] += draw[ch] * (-SH_C1 * sh48[3 + ch]);
+            ddir[2] += draw[ch] * (SH_C1 * sh48[6 + ch]);
+          }
+        }
+        if constexpr (DEG > 1) {
           const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
           const float xy = dx * dy, yz = dy * dz, xz = dx * dz;
           basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz;
@@ -515,7 +557,7 @@ hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
             ddir[1] += draw[ch] * (SH_C2[0] * dx * s4 + SH_C2[1] * dz * s5 + SH_C2[2] * -2.f * dy * s6 + SH_C2[4] * -2.f * dy * s8);
             ddir[2] += draw[ch] * (SH_C2[1] * dy * s5 + SH_C2[2] * 4.f * dz * s6 + SH_C2[3] * dx * s7);
           }
-          if (v.D > 2) {
+          if constexpr (DEG > 2) {
             basis[9] = SH_C3[0] * dy * (3.f * xx - yy);
             basis[10] = SH_C3[1] * xy * dz;
             basis[11] = SH_C3[2] * dy * (4.f * zz - xx - yy);
@@ -539,67 +581,88 @@ hgs_k_preprocess_bwd(View v, Layout L, const hgs_status* __restrict__ status,
             }
           }
         }
-      }
-      if (sh_block_vectorisable(v.M)) {            // 16 B stores of the (M,3) gradient block
-        float o48[48];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const float bk = (k < ncoef) ? basis[k] : 0.f;
-          o48[3 * k + 0] = bk * draw[0];
-          o48[3 * k + 1] = bk * draw[1];
-          o48[3 * k + 2] = bk * draw[2];
+        for (int k = 0; k < NC; ++k) {
+          a_sh[3 * k + 0] += basis[k] * draw[0];
+          a_sh[3 * k + 1] += basis[k] * draw[1];
+          a_sh[3 * k + 2] += basis[k] * draw[2];
         }
-        float4* o4 = reinterpret_cast<float4*>(out);
-        const int nq = (v.M * 3) >> 2;
-#pragma unroll
-        for (int q = 0; q < 12; ++q)
-          if (q < nq) o4[q] = make_float4(o48[4 * q], o48[4 * q + 1], o48[4 * q + 2], o48[4 * q + 3]);
-      } else {
-        for (int k = 0; k < v.M; ++k) {
-          const float bk = (k < ncoef) ? basis[k] : 0.f;
-          out[3 * k + 0] = bk * draw[0];
-          out[3 * k + 1] = bk * draw[1];
-          out[3 * k + 2] = bk * draw[2];
-        }
+        // d(normalize)/d(dir_orig)
+        const float dot = dx * ddir[0] + dy * ddir[1] + dz * ddir[2];
+        dmean[0] += (ddir[0] - dx * dot) / n;
+        dmean[1] += (ddir[1] - dy * dot) / n;
+        dmean[2] += (ddir[2] - dz * dot) / n;
       }
-      // d(normalize)/d(dir_orig)
-      const float dot = dx * ddir[0] + dy * ddir[1] + dz * ddir[2];
-      dmean[0] += (ddir[0] - dx * dot) / n;
-      dmean[1] += (ddir[1] - dy * dot) / n;
-      dmean[2] += (ddir[2] - dz * dot) / n;
-    } else if (sh_block_vectorisable(v.M)) {
-      float4* o4 = reinterpret_cast<float4*>(out);
-      const int nq = (v.M * 3) >> 2;
-#pragma unroll
-      for (int q = 0; q < 12; ++q)
-        if (q < nq) o4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      for (int k = 0; k < 3 * v.M; ++k) out[k] = 0.f;
+      a_mean[0] += dmean[0]; a_mean[1] += dmean[1]; a_mean[2] += dmean[2];
+    }
+    if (dL_dmeans2D) {
+      float* o = dL_dmeans2D + ((size_t)b * v.P + i) * 3;
+      o[0] = gmx * 0.5f * (float)v.W;
+      o[1] = gmy * 0.5f * (float)v.H;
+      o[2] = 0.f;
     }
   }
 
-  if (dL_dmeans3D) {
-    dL_dmeans3D[3 * i + 0] = dmean[0]; dL_dmeans3D[3 * i + 1] = dmean[1]; dL_dmeans3D[3 * i + 2] = dmean[2];
+  // ---- one write per output element
+  if (dL_dshs) {
+    float* out = dL_dshs + (size_t)i * v.M * 3;
+    if (sh_block_vectorisable(v.M)) {            // 16 B stores of the (M,3) gradient block
+      float4* o4 = reinterpret_cast<float4*>(out);
+      const int nq = (v.M * 3) >> 2;
+#pragma unroll
+      for (int qd = 0; qd < 12; ++qd)
+        if (qd < nq) {
+          float4 t;
+          t.x = (4 * qd + 0 < 3 * NC) ? a_sh[(4 * qd + 0) % (3 * NC)] : 0.f;
+          t.y = (4 * qd + 1 < 3 * NC) ? a_sh[(4 * qd + 1) % (3 * NC)] : 0.f;
+          t.z = (4 * qd + 2 < 3 * NC) ? a_sh[(4 * qd + 2) % (3 * NC)] : 0.f;
+          t.w = (4 * qd + 3 < 3 * NC) ? a_sh[(4 * qd + 3) % (3 * NC)] : 0.f;
+          o4[qd] = t;
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3 * NC; ++k)
+        if (k < 3 * v.M) out[k] = a_sh[k];
+      for (int k = 3 * NC; k < 3 * v.M; ++k) out[k] = 0.f;
+    }
   }
-  if (dL_dmeans2D) {
-    dL_dmeans2D[3 * i + 0] = gmx * 0.5f * (float)v.W;
-    dL_dmeans2D[3 * i + 1] = gmy * 0.5f * (float)v.H;
-    dL_dmeans2D[3 * i + 2] = 0.f;
+  if (dL_dmeans3D) {
+    dL_dmeans3D[3 * i + 0] = a_mean[0]; dL_dmeans3D[3 * i + 1] = a_mean[1]; dL_dmeans3D[3 * i + 2] = a_mean[2];
   }
   if (dL_dcolors) {
-    dL_dcolors[3 * i + 0] = gr; dL_dcolors[3 * i + 1] = gg; dL_dcolors[3 * i + 2] = gb;
+    dL_dcolors[3 * i + 0] = a_col[0]; dL_dcolors[3 * i + 1] = a_col[1]; dL_dcolors[3 * i + 2] = a_col[2];
   }
-  if (dL_dopac) dL_dopac[i] = gop;
+  if (dL_dopac) dL_dopac[i] = a_op;
   if (dL_dscales) {
-    dL_dscales[3 * i + 0] = dsc[0]; dL_dscales[3 * i + 1] = dsc[1]; dL_dscales[3 * i + 2] = dsc[2];
+    dL_dscales[3 * i + 0] = a_sc[0]; dL_dscales[3 * i + 1] = a_sc[1]; dL_dscales[3 * i + 2] = a_sc[2];
   }
-  if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+  if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(a_rot[0], a_rot[1], a_rot[2], a_rot[3]);
   if (dL_dcov3D) {
     float* o = dL_dcov3D + 6 * (size_t)i;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = dcov[k];
+    for (int k = 0; k < 6; ++k) o[k] = a_cov[k];
   }
 }
+
+}  // namespace
+
+#define HGS_PRE_BWD_KERNEL(DEG)                                                                     \
+  extern "C" __global__ void __launch_bounds__(HGS_BLOCK) hgs_k_preprocess_bwd_d##DEG(             \
+      View v, Layout L, const hgs_status* __restrict__ status, const float* __restrict__ grad_rows, \
+      const float* __restrict__ means3D, const float* __restrict__ shs,                             \
+      const float* __restrict__ colors_precomp, const float* __restrict__ scales,                   \
+      const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,                 \
+      float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, \
+      float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,  \
+      float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {                                \
+    preprocess_bwd_body<DEG>(v, L, status, grad_rows, means3D, shs, colors_precomp, scales,         \
+                             rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, dL_dshs,           \
+                             dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D);                \
+  }
+HGS_PRE_BWD_KERNEL(0)
+HGS_PRE_BWD_KERNEL(1)
+HGS_PRE_BWD_KERNEL(2)
+HGS_PRE_BWD_KERNEL(3)
 
 // ------------------------------------------------------------------------- mark visible
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)

@@ -91,13 +91,22 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #define HGS_TACC(i)
 #define HGS_TSTART()
 #endif
-  if (status->overflow || g >= L.tile_wgstart[v.T]) return;   // surplus workgroup
+  if (status->overflow || g >= status->bwd_groups) return;   // surplus workgroup
   const uint2 item = L.wg_tile[g];
-  const int t = (int)item.x;
+  const int gt = (int)item.x;                               // global tile = view * T + tile
   const uint32_t b = item.y;
-  const uint32_t start = L.tile_start[t];
-  const uint32_t n = L.tile_start[t + 1] - start;
-  const uint32_t maxc = L.tile_maxcontrib[t];
+  const uint32_t start = L.tile_start[gt];
+  const uint32_t n = L.tile_n[gt];
+  const uint32_t maxc = L.tile_maxcontrib[gt];
+  const int bview = gt / v.T, t = gt % v.T;
+  {   // this view's planes
+    const size_t HW = (size_t)v.H * v.W;
+    out_color += (size_t)bview * 3 * HW; out_depth += (size_t)bview * HW; out_alpha += (size_t)bview * HW;
+    if (dL_dcolor) dL_dcolor += (size_t)bview * 3 * HW;
+    if (dL_ddepth) dL_ddepth += (size_t)bview * HW;
+    if (dL_dalpha) dL_dalpha += (size_t)bview * HW;
+  }
+  const uint32_t* __restrict__ n_contrib = L.n_contrib + (size_t)bview * v.H * v.W;
   const uint32_t q0 = b * HGS_BUCKET;
   const uint32_t m = min((uint32_t)HGS_BUCKET, n - q0);      // entries in this bucket
   const int lane = (int)threadIdx.x & 63;
@@ -122,9 +131,9 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #pragma unroll
     for (int k = 0; k < HGS_PART_FLOATS; ++k) z[k * 64 + lane] = 0.0f;
   }
-  const uint32_t bs_index = L.tile_bstart[t] + b - 1;
+  const uint32_t bs_index = L.tile_bstart[gt] + b - 1;
   const uint32_t kseg = (hgs_nseg(n) > 1) ? q0 / HGS_SEG : 0u;
-  const uint32_t ms_index = (kseg > 0) ? L.tile_msegstart[t] + kseg : 0u;
+  const uint32_t ms_index = (kseg > 0) ? L.tile_msegstart[gt] + kseg : 0u;
   const int mrow = lane & 15, kk = lane >> 4;
   const int tile_x0 = (t % v.grid_x) * HGS_TILE, tile_y0 = (t / v.grid_x) * HGS_TILE;
   HGS_TM(1);
@@ -173,13 +182,11 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   for (int j = 0; j < QW; ++j) {
     const int w = w_begin + j;
     const int px = tile_x0 + ((w & 1) << 3) + (lane & 7), py = tile_y0 + ((w >> 1) << 3) + (lane >> 3);
-    ncq[j] = (px < v.W && py < v.H) ? L.n_contrib[(size_t)py * v.W + px] : 0u;
+    ncq[j] = (px < v.W && py < v.H) ? n_contrib[(size_t)py * v.W + px] : 0u;
   }
 #pragma unroll
   for (int j = 0; j < QW; ++j) {
-    uint32_t mx = ncq[j];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    const uint32_t mx = hgs_wave_max_u32(ncq[j]);
     const int w = w_begin + j;
     ballq[j] = __ballot(((uint32_t)lane < m) && ((__float_as_uint(c2.w) >> (28 + w)) & 1u) &&
                         (q0 + (uint32_t)lane < mx));

@@ -171,14 +171,15 @@ hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
                const SortRec* __restrict__ recs_all, float* __restrict__ segT) {
   __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * HGS_FWD_UNROLL)];
   const uint32_t ms = blockIdx.x;
-  if (status->overflow || ms >= L.tile_msegstart[v.T]) return;
-  const uint2 item = L.seg_item[ms];                // (tile, segment): one load, no search
-  const int t = (int)item.x;
+  if (status->overflow || ms >= status->reserved[2]) return;
+  const uint2 item = L.seg_item[ms];                // (global tile, segment): one load, no search
+  const int g = (int)item.x;
   const uint32_t k = item.y;
-  const uint32_t start = L.tile_start[t];
-  const uint32_t n = L.tile_start[t + 1] - start;
+  const uint32_t start = L.tile_start[g];
+  const uint32_t n = L.tile_n[g];
   const uint32_t nseg = hgs_nseg(n);
   if (k + 1 >= nseg) return;                       // the last segment has no successor
+  const int t = g % v.T;
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -203,7 +204,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
                                                 float* __restrict__ out_alpha) {
   __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * HGS_FWD_UNROLL)];
   const bool overflow = status->overflow != 0;
-  int t;
+  int g;                                            // global tile = view * T + tile
   uint32_t k = 0;
   // Work items, in dispatch order: first the segments of the long lists (the heaviest tiles: their
   // chains start first), then one workgroup per remaining tile, heavy first.  The first
@@ -211,15 +212,22 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   const bool LONG = blockIdx.x < seg_bound;
   if (LONG) {
     const uint32_t ms = blockIdx.x;
-    if (overflow || ms >= L.tile_msegstart[v.T]) return;
-    const uint2 item = L.seg_item[ms];              // (tile, segment): one load, no search
-    t = (int)item.x;
+    if (overflow || ms >= status->reserved[2]) return;
+    const uint2 item = L.seg_item[ms];              // (global tile, segment): one load, no search
+    g = (int)item.x;
     k = item.y;
   } else {
     const uint32_t p = blockIdx.x - seg_bound;
-    if (p >= (uint32_t)v.T) return;
-    t = overflow ? (int)p : (int)L.tile_order[p];   // lists are invalid on overflow: background only
+    if (p >= (uint32_t)v.TT) return;
+    g = overflow ? (int)p : (int)L.tile_order[p];   // lists are invalid on overflow: background only
   }
+  const int bview = g / v.T, t = g % v.T;
+  const size_t HW = (size_t)v.H * v.W;
+  out_color += (size_t)bview * 3 * HW;
+  out_depth += (size_t)bview * HW;
+  out_alpha += (size_t)bview * HW;
+  uint32_t* __restrict__ n_contrib = L.n_contrib + (size_t)bview * HW;
+  const float* __restrict__ bg = v.cam[bview].bg;
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -230,19 +238,17 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   const bool inside = (px < v.W) && (py < v.H);
   const float pxf = (float)px, pyf = (float)py;
 
-  const uint32_t start = overflow ? 0u : L.tile_start[t];
-  const uint32_t n = overflow ? 0u : (L.tile_start[t + 1] - start);
+  const uint32_t start = overflow ? 0u : L.tile_start[g];
+  const uint32_t n = overflow ? 0u : L.tile_n[g];
   const uint32_t nseg = hgs_nseg(n);
   if (!LONG && nseg > 1) return;
-  const uint32_t bstart = overflow ? 0u : L.tile_bstart[t];
-  const uint32_t ms0 = (nseg > 1) ? L.tile_msegstart[t] : 0u;
+  const uint32_t bstart = overflow ? 0u : L.tile_bstart[g];
+  const uint32_t ms0 = (nseg > 1) ? L.tile_msegstart[g] : 0u;
   if (STORE && !overflow && k == 0) {
-    // backward work item -> (tile, bucket) map, one item per 64-entry bucket, in tile_order (heavy
-    // tiles first): spares the backward a dependent binary search at the start of every wave and
-    // puts the light items at the end of its dispatch order
-    const uint32_t pos = LONG ? L.tile_pos[t] : (blockIdx.x - seg_bound);
-    const uint32_t w0 = L.pos_wgstart[pos], nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
-    for (uint32_t bb = tid; bb < nb; bb += HGS_FWD_THREADS) L.wg_tile[w0 + bb] = make_uint2((uint32_t)t, bb);
+    // backward work item -> (global tile, bucket) map, one item per 64-entry bucket: spares the
+    // backward a dependent binary search at the start of every wave
+    const uint32_t w0 = L.tile_wgstart[g], nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
+    for (uint32_t bb = tid; bb < nb; bb += HGS_FWD_THREADS) L.wg_tile[w0 + bb] = make_uint2((uint32_t)g, bb);
   }
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
 
@@ -282,13 +288,12 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   if (nseg == 1) {
     if (inside) {
       const size_t pix = (size_t)py * v.W + px;
-      const size_t HW = (size_t)v.H * v.W;
-      out_color[0 * HW + pix] = s.C0 + s.T * v.bg[0];
-      out_color[1 * HW + pix] = s.C1 + s.T * v.bg[1];
-      out_color[2 * HW + pix] = s.C2 + s.T * v.bg[2];
+      out_color[0 * HW + pix] = s.C0 + s.T * bg[0];
+      out_color[1 * HW + pix] = s.C1 + s.T * bg[1];
+      out_color[2 * HW + pix] = s.C2 + s.T * bg[2];
       out_depth[pix] = s.D;
       out_alpha[pix] = s.Wt;
-      L.n_contrib[pix] = s.last;
+      n_contrib[pix] = s.last;
     }
   } else {
     // partial sums of this segment; Tend < 0 marks "terminated (or already finished) here"
@@ -303,10 +308,8 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   }
   if (STORE && !overflow) {
     // tile-wide max of n_contrib: buckets at or beyond it are skipped by the backward
-    uint32_t mx = s.last;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    if ((tid & 63) == 0 && mx > 0) atomicMax(&L.tile_maxcontrib[t], mx);
+    const uint32_t mx = hgs_wave_max_u32(s.last);
+    if ((tid & 63) == 0 && mx > 0) atomicMax(&L.tile_maxcontrib[g], mx);
   }
 }
 
@@ -335,12 +338,13 @@ hgs_k_fwd_combine(View v, Layout L, const hgs_status* __restrict__ status,
                   float* __restrict__ segP, float* __restrict__ out_color,
                   float* __restrict__ out_depth, float* __restrict__ out_alpha) {
   if (status->overflow) return;
-  const int t = blockIdx.x;
-  const uint32_t n = L.tile_start[t + 1] - L.tile_start[t];
+  const int g = blockIdx.x;
+  const uint32_t n = L.tile_n[g];
   const uint32_t nseg = hgs_nseg(n);
   if (nseg <= 1) return;
+  const int bview = g / v.T, t = g % v.T;
   const int tid = threadIdx.x;
-  const uint32_t ms0 = L.tile_msegstart[t];
+  const uint32_t ms0 = L.tile_msegstart[g];
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, Wt = 0.f, Tf = 1.0f;
   uint32_t last = 0;
   bool stopped = false;
@@ -362,11 +366,13 @@ hgs_k_fwd_combine(View v, Layout L, const hgs_status* __restrict__ status,
   if (px < v.W && py < v.H) {
     const size_t pix = (size_t)py * v.W + px;
     const size_t HW = (size_t)v.H * v.W;
-    out_color[0 * HW + pix] = C0 + Tf * v.bg[0];
-    out_color[1 * HW + pix] = C1 + Tf * v.bg[1];
-    out_color[2 * HW + pix] = C2 + Tf * v.bg[2];
-    out_depth[pix] = D;
-    out_alpha[pix] = Wt;
-    L.n_contrib[pix] = last;
+    const float* __restrict__ bg = v.cam[bview].bg;
+    float* oc = out_color + (size_t)bview * 3 * HW;
+    oc[0 * HW + pix] = C0 + Tf * bg[0];
+    oc[1 * HW + pix] = C1 + Tf * bg[1];
+    oc[2 * HW + pix] = C2 + Tf * bg[2];
+    out_depth[(size_t)bview * HW + pix] = D;
+    out_alpha[(size_t)bview * HW + pix] = Wt;
+    L.n_contrib[(size_t)bview * HW + pix] = last;
   }
 }

@@ -18,7 +18,8 @@
 
 #include <algorithm>
 #include <chrono>
-#include <deque>
+#include <map>
+#include <tuple>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -32,7 +33,7 @@ using torch::Tensor;
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
-constexpr int RING = 8;
+constexpr int RING = 4;
 
 // Switch the current HIP device only when it is not already the tensors' device.  (torch's own
 // HIPGuard types are keyed on DeviceType::HIP, which the ROCm build masquerades as CUDA.)
@@ -50,34 +51,32 @@ void hip_ok(hipError_t e, const char* what) {
     throw std::runtime_error(std::string("humangaussian_amd: ") + what + ": " + hipGetErrorString(e));
 }
 
-struct Pending {
-  hipEvent_t event;
-  int slot;
-  int64_t cap;
-  int32_t hint;
+// Workload estimate for one (views, height, width) shape on one device: entry capacity of the bin
+// buffer and the longest tile list (sort-class / segment hint).  Both follow the workload with a
+// DECAYING maximum, so alternating cameras (wide / head zoom, train / eval resolution) neither
+// trip the device-side overflow check every other call nor pin the buffers at a one-off peak.
+struct Estimate {
+  int64_t capacity = 0;       // entries; 0 = unknown
+  int64_t tile_hint = 0;      // 0 = unknown
 };
 
-// Per-device grow-only estimates (entry capacity, longest tile list) and a small ring of
-// pinned, device-mapped status mirrors the scan kernel stores into directly.
 struct DevState {
-  int64_t capacity = 0;
-  int32_t tile_hint = 0;      // longest tile list of the last call (with margin); 0 = unknown
-  int64_t max_R = 0;
-  int64_t max_tile = 0;
+  std::map<std::tuple<int64_t, int64_t, int64_t>, Estimate> est;   // (B, H, W) -> estimate
+  int64_t max_R = 0;          // of the last call
+  int64_t max_tile = 0;       // of the last call
+  int64_t last_capacity = 0, last_hint = 0;
   Tensor status_ring;         // pinned int32 [RING][8]
   hgs_status* ring = nullptr;
-  hipEvent_t status_event = nullptr;          // recorded by the library right behind the scan stage
-  hipEvent_t pend_events[RING] = {};
+  hipEvent_t status_event = nullptr;          // recorded by the library right behind the tiles stage
   int ring_pos = 0;
-  std::deque<Pending> pending;
-  int64_t synced_calls = 0;
+  int64_t calls = 0;
+  int64_t retries = 0;        // forwards that had to be re-run (capacity or hint exceeded)
   int64_t wait_ns = 0;        // host time blocked in the per-forward status wait (diagnostic)
   std::mutex mu;
 };
 
 std::mutex g_mu;
 std::vector<DevState*> g_states(64, nullptr);
-bool g_async = false;
 std::vector<void*> g_stage_fwd, g_stage_bwd;
 
 DevState& state_for(int dev) {
@@ -89,7 +88,6 @@ DevState& state_for(int dev) {
     static_assert(sizeof(hgs_status) == 32, "hgs_status is 8 words");
     st->ring = reinterpret_cast<hgs_status*>(st->status_ring.data_ptr<int32_t>());
     hip_ok(hipEventCreateWithFlags(&st->status_event, hipEventDisableTiming), "hipEventCreate");
-    for (auto& e : st->pend_events) hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     g_states[dev] = st;
   }
   return *g_states[dev];
@@ -108,66 +106,43 @@ Tensor f32c(const Tensor& t, const c10::Device& dev, const char* name) {
 const float* fptr(const Tensor& t) { return t.defined() && t.numel() > 0 ? t.data_ptr<float>() : nullptr; }
 float* fptr_mut(Tensor& t) { return t.defined() && t.numel() > 0 ? t.data_ptr<float>() : nullptr; }
 
+// B camera blocks: settings[b] points into the batched tensors (kept alive here)
 struct Settings {
-  hgs_settings s;
-  Tensor bg, vm, pm, cp;    // keep-alive
+  std::vector<hgs_settings> s;
+  Tensor bg, vm, pm, cp;    // (B,3), (B,16), (B,16), (B,3)
 };
 
-Settings make_settings(const Tensor& bg, const Tensor& vm, const Tensor& pm, const Tensor& cp, int64_t H,
-                       int64_t W, double tanfovx, double tanfovy, double scale_modifier, int64_t sh_degree,
-                       bool prefiltered, bool debug, const c10::Device& dev) {
+Settings make_settings(const Tensor& bg, const Tensor& vm, const Tensor& pm, const Tensor& cp, int64_t B, int64_t H,
+                       int64_t W, const double* tanfovx, const double* tanfovy, double scale_modifier,
+                       int64_t sh_degree, bool prefiltered, bool debug, const c10::Device& dev) {
+  if (B < 1 || B > HGS_MAX_VIEWS)
+    throw std::runtime_error("a batched call takes 1.." + std::to_string(HGS_MAX_VIEWS) + " views, got " + std::to_string(B));
   Settings r;
-  r.bg = f32c(bg, dev, "bg");
   r.vm = f32c(vm, dev, "viewmatrix");
   r.pm = f32c(pm, dev, "projmatrix");
   r.cp = f32c(cp, dev, "campos");
-  if (r.bg.numel() != 3 || r.vm.numel() != 16 || r.pm.numel() != 16 || r.cp.numel() != 3)
-    throw std::runtime_error("bg/campos must have 3 elements, viewmatrix/projmatrix 16");
-  r.s.image_height = (int32_t)H;
-  r.s.image_width = (int32_t)W;
-  r.s.tanfovx = (float)tanfovx;
-  r.s.tanfovy = (float)tanfovy;
-  r.s.bg = r.bg.data_ptr<float>();
-  r.s.scale_modifier = (float)scale_modifier;
-  r.s.viewmatrix = r.vm.data_ptr<float>();
-  r.s.projmatrix = r.pm.data_ptr<float>();
-  r.s.sh_degree = (int32_t)sh_degree;
-  r.s.campos = r.cp.data_ptr<float>();
-  r.s.prefiltered = prefiltered ? 1 : 0;
-  r.s.debug = debug ? 1 : 0;
-  return r;
-}
-
-void observe(DevState& st, const hgs_status& h) {
-  st.max_R = std::max<int64_t>(st.max_R, h.num_rendered);
-  st.max_tile = std::max<int64_t>(st.max_tile, h.reserved[1]);
-}
-
-// Inspect the status of earlier async forwards whose status has landed.
-void drain_pending(DevState& st, bool block) {
-  while (!st.pending.empty()) {
-    Pending p = st.pending.front();
-    if (block) {
-      hip_ok(hipEventSynchronize(p.event), "hipEventSynchronize");
-    } else {
-      hipError_t q = hipEventQuery(p.event);
-      if (q == hipErrorNotReady) break;
-      hip_ok(q, "hipEventQuery");
-    }
-    st.pending.pop_front();
-    const hgs_status h = st.ring[p.slot];
-    observe(st, h);
-    if (h.overflow) {
-      st.capacity = std::max(st.capacity, round_capacity(2 * (int64_t)h.num_rendered));
-      st.tile_hint = 0;
-      throw std::runtime_error(
-          "humangaussian_amd (async mode): an earlier render overflowed its buffers (num_rendered=" +
-          std::to_string(h.num_rendered) + ", capacity=" + std::to_string(p.cap) + ", longest tile list=" +
-          std::to_string(h.reserved[1]) + ", hint=" + std::to_string(p.hint) +
-          "); its outputs and gradients were invalid.  Capacity has been raised; re-run the step "
-          "(or disable async mode).");
-    }
+  Tensor bgc = f32c(bg, dev, "bg");
+  if (bgc.numel() == 3 && B > 1) bgc = bgc.reshape({1, 3}).expand({B, 3}).contiguous();
+  r.bg = bgc;
+  if (r.bg.numel() != 3 * B || r.vm.numel() != 16 * B || r.pm.numel() != 16 * B || r.cp.numel() != 3 * B)
+    throw std::runtime_error("bg/campos must have 3 elements (per view), viewmatrix/projmatrix 16");
+  r.s.resize(B);
+  for (int64_t b = 0; b < B; ++b) {
+    hgs_settings& s = r.s[b];
+    s.image_height = (int32_t)H;
+    s.image_width = (int32_t)W;
+    s.tanfovx = (float)tanfovx[b];
+    s.tanfovy = (float)tanfovy[b];
+    s.bg = r.bg.data_ptr<float>() + 3 * b;
+    s.scale_modifier = (float)scale_modifier;
+    s.viewmatrix = r.vm.data_ptr<float>() + 16 * b;
+    s.projmatrix = r.pm.data_ptr<float>() + 16 * b;
+    s.sh_degree = (int32_t)sh_degree;
+    s.campos = r.cp.data_ptr<float>() + 3 * b;
+    s.prefiltered = prefiltered ? 1 : 0;
+    s.debug = debug ? 1 : 0;
   }
+  return r;
 }
 
 void check_rc(int rc, const char* what) {
@@ -176,40 +151,55 @@ void check_rc(int rc, const char* what) {
   if (rc != HGS_OK) throw std::runtime_error(std::string("libhgs_rast: ") + what + " failed with code " + std::to_string(rc));
 }
 
-// What the backward call needs, prepared while the GPU runs the forward.
+void need_numel(const Tensor& t, int64_t n, const char* name, const char* shape) {
+  if (t.numel() != n)
+    throw std::runtime_error(std::string(name) + " must have dimensions " + shape + " (got " + std::to_string(t.numel()) +
+                             " elements, expected " + std::to_string(n) + ")");
+}
+
+// What the backward call needs.  The plan stays alive as long as the autograd node does, so the
+// backward can run more than once (retain_graph=True, torch.autograd.grad per loss term) like
+// upstream's Python autograd.Function; gradient tensors are allocated per backward call.
 struct BwdPlan : torch::CustomClassHolder {
   Settings settings;
   Tensor work, work2;                 // [geom | img | bin | rows] (work2: bin | rows after a retry)
   char *geom = nullptr, *bin = nullptr, *img = nullptr, *rows = nullptr;
   int64_t cap = 0;
-  bool have_status = false;
   hgs_status status{};
-  Tensor d_means3D, d_means2D, d_sh, d_cp, d_opac, d_sc, d_ro, d_cv;
-  int32_t P = 0, M = 0;
+  int32_t B = 1, P = 0, M = 0;
+  bool batched = false;
   bool has_sh = false, has_cp = false, has_sr = false, has_cv = false;
+  std::vector<int64_t> opac_sizes;
 };
 
 struct Rasterize : public torch::autograd::Function<Rasterize> {
+  // 21 arguments after ctx (backward returns one slot per argument).  `tanfov` is a CPU double
+  // tensor [2][B] (x row, y row); `batch` = 0 for the single-view API, else the number of views.
   static variable_list forward(AutogradContext* ctx, const Tensor& means3D, const Tensor& means2D,
                                const Tensor& sh, const Tensor& colors_precomp, const Tensor& opacities,
                                const Tensor& scales, const Tensor& rotations, const Tensor& cov3D,
                                const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
-                               const Tensor& campos, int64_t H, int64_t W, double tanfovx, double tanfovy,
+                               const Tensor& campos, const Tensor& tanfov, int64_t H, int64_t W,
                                double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
-                               bool want_grad) {
+                               bool want_grad, int64_t batch) {
     (void)means2D;
     const c10::Device dev = means3D.device();
     if (!dev.is_cuda())
       throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device (torch device type 'cuda'); "
                                "there is no CPU path");
+    const bool batched = batch > 0;
+    const int64_t B = batched ? batch : 1;
     const int64_t P = means3D.size(0);
     if (P != 0 && (means3D.dim() != 2 || means3D.size(1) != 3))
       throw std::runtime_error("means3D must have dimensions (num_points, 3)");
+    if (tanfov.device().is_cuda() || tanfov.scalar_type() != at::kDouble || tanfov.numel() != 2 * B || !tanfov.is_contiguous())
+      throw std::runtime_error("tanfov must be a contiguous CPU double tensor of shape (2, views)");
     DeviceSwitch guard(dev.index());
 
     auto plan = c10::make_intrusive<BwdPlan>();
-    plan->settings = make_settings(bg, viewmatrix, projmatrix, campos, H, W, tanfovx, tanfovy, scale_modifier,
-                                   sh_degree, prefiltered, debug, dev);
+    const double* tf = tanfov.data_ptr<double>();
+    plan->settings = make_settings(bg, viewmatrix, projmatrix, campos, B, H, W, tf, tf + B, scale_modifier, sh_degree,
+                                   prefiltered, debug, dev);
     const Tensor m3 = f32c(means3D, dev, "means3D");
     const bool has_sh = sh.defined() && sh.numel() > 0, has_cp = colors_precomp.defined() && colors_precomp.numel() > 0;
     const bool has_sc = scales.defined() && scales.numel() > 0, has_ro = rotations.defined() && rotations.numel() > 0;
@@ -223,28 +213,34 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     if (has_sh && (sh_.dim() != 3 || sh_.size(0) != P || sh_.size(2) != 3))
       throw std::runtime_error("shs must have dimensions (num_points, M, 3)");
     const int32_t M = has_sh ? (int32_t)sh_.size(1) : 0;
+    // the kernels index every per-Gaussian tensor by P: a stale tensor (captured before a
+    // densification / pruning step) must fail here, not read out of bounds on the device
+    need_numel(op_, P, "opacities", "(num_points, 1)");
+    if (has_cp) need_numel(cp_, 3 * P, "colors_precomp", "(num_points, 3)");
+    if (has_sc) need_numel(sc_, 3 * P, "scales", "(num_points, 3)");
+    if (has_ro) need_numel(ro_, 4 * P, "rotations", "(num_points, 4)");
+    if (has_cv) need_numel(cv_, 6 * P, "cov3D_precomp", "(num_points, 6)");
 
     const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
-    Tensor color = at::empty({3, H, W}, fopt), depth = at::empty({1, H, W}, fopt), alpha = at::empty({1, H, W}, fopt);
-    Tensor radii = at::empty({P}, fopt.dtype(at::kInt));
+    Tensor color, depth, alpha, radii;
+    if (batched) {
+      color = at::empty({B, 3, H, W}, fopt); depth = at::empty({B, 1, H, W}, fopt); alpha = at::empty({B, 1, H, W}, fopt);
+      radii = at::empty({B, P}, fopt.dtype(at::kInt));
+    } else {
+      color = at::empty({3, H, W}, fopt); depth = at::empty({1, H, W}, fopt); alpha = at::empty({1, H, W}, fopt);
+      radii = at::empty({P}, fopt.dtype(at::kInt));
+    }
 
     DevState& st = state_for(dev.index());
     std::lock_guard<std::mutex> lk(st.mu);
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-    if (!st.pending.empty()) drain_pending(st, false);
-    const bool go_async = g_async && want_grad && P > 0 && st.synced_calls >= 2;
-    int64_t cap;
-    int32_t hint;
-    if (go_async) {
-      cap = std::max(st.capacity, round_capacity(2 * st.max_R));
-      hint = (int32_t)std::max<int64_t>(1024, 2 * st.max_tile + 64);
-    } else {
-      cap = P > 0 ? std::max(st.capacity, round_capacity(4 * P)) : 0;
-      hint = st.tile_hint;
-    }
+    Estimate& est = st.est[std::make_tuple(B, H, W)];
+    int64_t cap = P > 0 ? (est.capacity > 0 ? est.capacity : round_capacity(4 * P * B)) : 0;
+    int32_t hint = (int32_t)est.tile_hint;
     // one allocation for the four opaque regions [geom | img | bin | backward rows] (the fork keeps
     // three such byte tensors for its backward); a capacity retry re-allocates only the last two
-    const int64_t g_sz = al256(hgs_geom_bytes((int32_t)P, (int32_t)H, (int32_t)W)), i_sz = al256(hgs_img_bytes((int32_t)H, (int32_t)W));
+    const int64_t g_sz = al256(hgs_geom_bytes_batch((int32_t)B, (int32_t)P, (int32_t)H, (int32_t)W));
+    const int64_t i_sz = al256(hgs_img_bytes_batch((int32_t)B, (int32_t)H, (int32_t)W));
     int64_t b_sz = al256(hgs_bin_bytes(cap)), s_sz = want_grad ? al256(hgs_bwd_scratch_bytes(cap)) : 0;
     const auto bopt = at::TensorOptions().dtype(at::kByte).device(dev);
     plan->work = at::empty({g_sz + i_sz + b_sz + s_sz}, bopt);
@@ -254,50 +250,29 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     plan->bin = base + g_sz + i_sz;
     plan->rows = base + g_sz + i_sz + b_sz;
 
-    bool have_status = false;
     hgs_status h{};
-    bool grads_ready = false;
     int attempt = 0;
     for (; attempt < 4; ++attempt) {
       const int slot = st.ring_pos;
       st.ring_pos = (st.ring_pos + 1) % RING;
-      const int rc = hgs_forward(&plan->settings.s, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_),
-                                 fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth), fptr_mut(alpha),
-                                 P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom, plan->bin, cap, plan->img,
-                                 want_grad ? 1 : 0, hint, &st.ring[slot], /*mapped=*/1,
-                                 go_async ? nullptr : st.status_event,
-                                 g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(), stream);
-      check_rc(rc, "hgs_forward");
+      const int rc = hgs_forward_batch(plan->settings.s.data(), (int32_t)B, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_),
+                                       fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth),
+                                       fptr_mut(alpha), P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom, plan->bin,
+                                       cap, plan->img, want_grad ? 1 : 0, hint, &st.ring[slot], /*mapped=*/1,
+                                       st.status_event, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(), stream);
+      check_rc(rc, "hgs_forward_batch");
       // `debug=True` is upstream's switch for surfacing device errors at the call that caused
       // them (std::runtime_error): synchronise and report
       if (debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer forward (debug=True)");
-      // host work that does not depend on the result runs HERE, while the GPU is busy
-      if (want_grad && !grads_ready) {
-        plan->d_means3D = at::empty({P, 3}, fopt);
-        plan->d_means2D = at::empty({P, 3}, fopt);
-        plan->d_opac = at::empty(opacities.sizes(), fopt);
-        if (has_sh) plan->d_sh = at::empty({P, M, 3}, fopt);
-        if (has_cp) plan->d_cp = at::empty({P, 3}, fopt);
-        if (has_sc) { plan->d_sc = at::empty({P, 3}, fopt); plan->d_ro = at::empty({P, 4}, fopt); }
-        if (has_cv) plan->d_cv = at::empty({P, 6}, fopt);
-        grads_ready = true;
-      }
-      if (go_async) {
-        Pending p{st.pend_events[slot], slot, cap, hint};
-        hip_ok(hipEventRecord(p.event, stream), "hipEventRecord");
-        st.pending.push_back(p);
-        if ((int)st.pending.size() >= RING - 1) drain_pending(st, true);   // never let the ring wrap
-        break;
-      }
       // One host wait per forward, like upstream's blocking read of num_rendered - but only for
-      // the status (stored by the scan kernel): fill, sort and blend are already enqueued and keep
+      // the status (stored by the tiles kernel): fill, sort and blend are already enqueued and keep
       // the GPU busy while the host goes on to autograd and the backward launch.
       const auto tw = std::chrono::steady_clock::now();
       hip_ok(hipEventSynchronize(st.status_event), "hipEventSynchronize");
       st.wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw).count();
       h = st.ring[slot];
-      have_status = true;
       if (!h.overflow) break;
+      st.retries += 1;
       if (h.overflow & 1u) {                    // R exceeded the capacity: grow, re-run
         cap = round_capacity((int64_t)(h.num_rendered * 1.25) + 1);
         b_sz = al256(hgs_bin_bytes(cap));
@@ -309,23 +284,32 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       if (h.overflow & 2u) hint = 0;            // a tile list outgrew the hint
     }
     if (attempt == 4) throw std::runtime_error("libhgs_rast: entry capacity did not converge");
-    if (have_status) {
-      observe(st, h);
-      st.synced_calls += 1;
-      st.capacity = std::max(st.capacity, cap);
-      st.tile_hint = (int32_t)std::max<int64_t>(1024, (int64_t)(h.reserved[1] * 1.5) + 64);
+    st.calls += 1;
+    st.max_R = h.num_rendered;
+    st.max_tile = h.reserved[1];
+    st.last_capacity = cap;
+    st.last_hint = hint;
+    if (P > 0) {
+      // decaying maxima: follow the workload down slowly, up at once
+      est.capacity = std::max<int64_t>(round_capacity((int64_t)(h.num_rendered * 1.25) + 1),
+                                       est.capacity > 0 ? round_capacity((int64_t)(est.capacity * 0.9)) : 0);
+      est.tile_hint = std::max<int64_t>(std::max<int64_t>(1024, (int64_t)(h.reserved[1] * 1.5) + 64),
+                                        (int64_t)(est.tile_hint * 0.9));
     }
     ctx->set_materialize_grads(false);
     if (want_grad) {
       plan->cap = cap;
-      plan->have_status = have_status;
       plan->status = h;
+      plan->B = (int32_t)B;
       plan->P = (int32_t)P;
       plan->M = M;
+      plan->batched = batched;
       plan->has_sh = has_sh; plan->has_cp = has_cp; plan->has_sr = has_sc; plan->has_cv = has_cv;
+      plan->opac_sizes = opacities.sizes().vec();
       ctx->saved_data["plan"] = c10::IValue::make_capsule(plan);
-      // inputs and outputs go through save_for_backward (version checks, no reference cycle
-      // through the outputs); the opaque work buffers ride in the plan
+      // inputs and outputs go through save_for_backward (version checks: the backward reads the
+      // forward's outputs, so they must not be modified in place before backward()); the opaque
+      // work buffers ride in the plan
       variable_list saved = {m3, op_, radii, color, depth, alpha};
       for (const Tensor* t : {&sh_, &cp_, &sc_, &ro_, &cv_})
         if (t->defined()) saved.push_back(*t);
@@ -336,7 +320,11 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    auto holder = ctx->saved_data["plan"].toCapsule();
+    auto it = ctx->saved_data.find("plan");
+    if (it == ctx->saved_data.end() || it->second.isNone())
+      throw std::runtime_error("humangaussian_amd: the rasterizer's backward state is gone (the forward ran without "
+                               "gradient tracking)");
+    auto holder = it->second.toCapsule();
     BwdPlan* plan = static_cast<BwdPlan*>(holder.get());
     const auto saved = ctx->get_saved_variables();
     const Tensor &m3 = saved[0], &op_ = saved[1], &radii = saved[2], &color = saved[3], &depth = saved[4], &alpha = saved[5];
@@ -348,23 +336,31 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     const Tensor cv_ = plan->has_cv ? saved[k++] : Tensor();
     const c10::Device dev = m3.device();
     DeviceSwitch guard(dev.index());
-    const Tensor gc = grads[0].defined() ? f32c(grads[0], dev, "grad_color") : at::zeros_like(color);
-    const Tensor gd = grads[2].defined() ? f32c(grads[2], dev, "grad_depth") : at::zeros_like(depth);
-    const Tensor ga = grads[3].defined() ? f32c(grads[3], dev, "grad_alpha") : at::zeros_like(alpha);
+    const Tensor gc = grads[0].defined() ? f32c(grads[0], dev, "grad_color") : Tensor();
+    const Tensor gd = grads[2].defined() ? f32c(grads[2], dev, "grad_depth") : Tensor();
+    const Tensor ga = grads[3].defined() ? f32c(grads[3], dev, "grad_alpha") : Tensor();
+    const int64_t P = plan->P, B = plan->B, M = plan->M;
+    const auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    Tensor d_means3D = at::empty({P, 3}, fopt);
+    Tensor d_means2D = plan->batched ? at::empty({B, P, 3}, fopt) : at::empty({P, 3}, fopt);
+    Tensor d_opac = at::empty(plan->opac_sizes, fopt);
+    Tensor d_sh, d_cp, d_sc, d_ro, d_cv;
+    if (plan->has_sh) d_sh = at::empty({P, M, 3}, fopt);
+    if (plan->has_cp) d_cp = at::empty({P, 3}, fopt);
+    if (plan->has_sr) { d_sc = at::empty({P, 3}, fopt); d_ro = at::empty({P, 4}, fopt); }
+    if (plan->has_cv) d_cv = at::empty({P, 6}, fopt);
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-    const int rc = hgs_backward(
-        &plan->settings.s, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_),
-        plan->P > 0 ? radii.data_ptr<int32_t>() : nullptr, fptr(color), fptr(depth), fptr(alpha), fptr(gc), fptr(gd),
-        fptr(ga), plan->geom, plan->bin, plan->img, plan->have_status ? &plan->status : nullptr, plan->cap, plan->rows,
-        fptr_mut(plan->d_means3D), fptr_mut(plan->d_means2D), fptr_mut(plan->d_sh), fptr_mut(plan->d_cp),
-        fptr_mut(plan->d_opac), fptr_mut(plan->d_sc), fptr_mut(plan->d_ro), fptr_mut(plan->d_cv),
-        g_stage_bwd.empty() ? nullptr : g_stage_bwd.data(), stream);
-    check_rc(rc, "hgs_backward");
-    if (plan->settings.s.debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer backward (debug=True)");
+    const int rc = hgs_backward_batch(
+        plan->settings.s.data(), plan->B, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_), fptr(ro_),
+        fptr(cv_), plan->P > 0 ? radii.data_ptr<int32_t>() : nullptr, fptr(color), fptr(depth), fptr(alpha), fptr(gc),
+        fptr(gd), fptr(ga), plan->geom, plan->bin, plan->img, &plan->status, plan->cap, plan->rows, fptr_mut(d_means3D),
+        fptr_mut(d_means2D), fptr_mut(d_sh), fptr_mut(d_cp), fptr_mut(d_opac), fptr_mut(d_sc), fptr_mut(d_ro),
+        fptr_mut(d_cv), g_stage_bwd.empty() ? nullptr : g_stage_bwd.data(), stream);
+    check_rc(rc, "hgs_backward_batch");
+    if (plan->settings.s[0].debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer backward (debug=True)");
     variable_list out(21);
-    out[0] = plan->d_means3D; out[1] = plan->d_means2D; out[2] = plan->d_sh; out[3] = plan->d_cp;
-    out[4] = plan->d_opac; out[5] = plan->d_sc; out[6] = plan->d_ro; out[7] = plan->d_cv;
-    ctx->saved_data.erase("plan");
+    out[0] = d_means3D; out[1] = d_means2D; out[2] = d_sh; out[3] = d_cp;
+    out[4] = d_opac; out[5] = d_sc; out[6] = d_ro; out[7] = d_cv;
     return out;
   }
 };
@@ -376,6 +372,15 @@ Tensor opt(const c10::optional<Tensor>& t) {
   return t.has_value() ? *t : empty;
 }
 
+Tensor tanfov_tensor(const std::vector<double>& x, const std::vector<double>& y) {
+  if (x.size() != y.size() || x.empty()) throw std::runtime_error("tanfovx / tanfovy: one value per view");
+  Tensor t = at::empty({2, (int64_t)x.size()}, at::TensorOptions().dtype(at::kDouble));
+  double* d = t.data_ptr<double>();
+  for (size_t i = 0; i < x.size(); ++i) { d[i] = x[i]; d[x.size() + i] = y[i]; }
+  return t;
+}
+
+// single view: the signature of upstream's _C.rasterize_gaussians call
 std::vector<Tensor> rasterize(const Tensor& means3D, const Tensor& means2D, const c10::optional<Tensor>& sh,
                               const c10::optional<Tensor>& colors_precomp, const Tensor& opacities,
                               const c10::optional<Tensor>& scales, const c10::optional<Tensor>& rotations,
@@ -384,8 +389,26 @@ std::vector<Tensor> rasterize(const Tensor& means3D, const Tensor& means2D, cons
                               double tanfovy, double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
                               bool want_grad) {
   return Rasterize::apply(means3D, means2D, opt(sh), opt(colors_precomp), opacities, opt(scales), opt(rotations),
-                          opt(cov3D), bg, viewmatrix, projmatrix, campos, H, W, tanfovx, tanfovy, scale_modifier,
-                          sh_degree, prefiltered, debug, want_grad);
+                          opt(cov3D), bg, viewmatrix, projmatrix, campos, tanfov_tensor({tanfovx}, {tanfovy}), H, W,
+                          scale_modifier, sh_degree, prefiltered, debug, want_grad, (int64_t)0);
+}
+
+// B views in one launch set: bg (3) or (B,3), viewmatrix / projmatrix (B,4,4), campos (B,3), means2D (B,P,3);
+// returns color (B,3,H,W), radii (B,P), depth (B,1,H,W), alpha (B,1,H,W)
+std::vector<Tensor> rasterize_batch(const Tensor& means3D, const Tensor& means2D, const c10::optional<Tensor>& sh,
+                                    const c10::optional<Tensor>& colors_precomp, const Tensor& opacities,
+                                    const c10::optional<Tensor>& scales, const c10::optional<Tensor>& rotations,
+                                    const c10::optional<Tensor>& cov3D, const Tensor& bg, const Tensor& viewmatrix,
+                                    const Tensor& projmatrix, const Tensor& campos, int64_t H, int64_t W,
+                                    const std::vector<double>& tanfovx, const std::vector<double>& tanfovy,
+                                    double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
+                                    bool want_grad) {
+  const int64_t B = (int64_t)tanfovx.size();
+  if (means2D.defined() && means2D.numel() > 0 && means2D.numel() != B * means3D.size(0) * 3)
+    throw std::runtime_error("means2D must have dimensions (views, num_points, 3) for a batched call");
+  return Rasterize::apply(means3D, means2D, opt(sh), opt(colors_precomp), opacities, opt(scales), opt(rotations),
+                          opt(cov3D), bg, viewmatrix, projmatrix, campos, tanfov_tensor(tanfovx, tanfovy), H, W,
+                          scale_modifier, sh_degree, prefiltered, debug, want_grad, B);
 }
 
 Tensor mark_visible(const Tensor& positions, const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
@@ -395,13 +418,13 @@ Tensor mark_visible(const Tensor& positions, const Tensor& bg, const Tensor& vie
   const c10::Device dev = positions.device();
   if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
   DeviceSwitch guard(dev.index());
-  Settings s = make_settings(bg, viewmatrix, projmatrix, campos, H, W, tanfovx, tanfovy, scale_modifier, sh_degree,
+  Settings s = make_settings(bg, viewmatrix, projmatrix, campos, 1, H, W, &tanfovx, &tanfovy, scale_modifier, sh_degree,
                              prefiltered, debug, dev);
   const Tensor pos = f32c(positions, dev, "positions");
   const int64_t P = pos.size(0);
   Tensor present = at::zeros({P}, at::TensorOptions().dtype(at::kByte).device(dev));
   if (P > 0) {
-    const int rc = hgs_mark_visible(&s.s, (int32_t)P, pos.data_ptr<float>(), present.data_ptr<uint8_t>(),
+    const int rc = hgs_mark_visible(s.s.data(), (int32_t)P, pos.data_ptr<float>(), present.data_ptr<uint8_t>(),
                                     c10::hip::getCurrentHIPStream(dev.index()).stream());
     check_rc(rc, "hgs_mark_visible");
   }
@@ -480,20 +503,19 @@ py::dict device_state(int64_t dev) {
   DevState& st = state_for((int)dev);
   std::lock_guard<std::mutex> lk(st.mu);
   py::dict d;
-  d["capacity"] = st.capacity;
-  d["tile_hint"] = st.tile_hint;
+  d["capacity"] = st.last_capacity;
+  d["tile_hint"] = st.last_hint;
   d["max_R"] = st.max_R;
   d["max_tile"] = st.max_tile;
-  d["pending"] = (int64_t)st.pending.size();
-  d["synced_calls"] = st.synced_calls;
+  d["calls"] = st.calls;
+  d["retries"] = st.retries;
   d["wait_ns"] = st.wait_ns;
+  py::dict e;
+  for (const auto& kv : st.est)
+    e[py::make_tuple(std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first))] =
+        py::make_tuple(kv.second.capacity, kv.second.tile_hint);
+  d["estimates"] = e;
   return d;
-}
-
-void drain(int64_t dev, bool block) {
-  DevState& st = state_for((int)dev);
-  std::lock_guard<std::mutex> lk(st.mu);
-  drain_pending(st, block);
 }
 
 }  // namespace
@@ -501,14 +523,12 @@ void drain(int64_t dev, bool block) {
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "torch binding of libhgs_rast.so (include/hgs_rast.h): autograd node, capacity logic, the one host wait";
   m.def("rasterize", &rasterize, py::call_guard<py::gil_scoped_release>());
+  m.def("rasterize_batch", &rasterize_batch, py::call_guard<py::gil_scoped_release>());
   m.def("mark_visible", &mark_visible, py::call_guard<py::gil_scoped_release>());
   m.def("knn_mean_dist2", &knn_mean_dist2, py::call_guard<py::gil_scoped_release>());
   m.def("reduce_view_packs", &reduce_view_packs, py::call_guard<py::gil_scoped_release>());
   m.def("pack_view_contribution", &pack_view_contribution, py::call_guard<py::gil_scoped_release>());
-  m.def("set_async", [](bool on) { g_async = on; });
-  m.def("get_async", []() { return g_async; });
   m.def("set_stage_events", &set_stage_events);
   m.def("device_state", &device_state);
-  m.def("drain_pending", &drain, py::call_guard<py::gil_scoped_release>());
   m.def("abi_version", []() { return hgs_abi_version(); });
 }

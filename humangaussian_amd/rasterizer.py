@@ -13,7 +13,6 @@ There is no CPU path: non-HIP tensors raise.
 """
 from __future__ import annotations
 
-import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -45,22 +44,6 @@ class GaussianRasterizationSettings(NamedTuple):
 import types
 
 
-def set_async(enabled: bool):
-    """Opt-in asynchronous mode.  Default (False) mirrors upstream: one host wait per
-    forward to read num_rendered, overflow handled transparently by re-running.  With
-    async enabled a forward that needs gradients returns WITHOUT waiting once the
-    workload is known (two synchronous calls first): buffers are sized with a 2x margin over
-    the largest R seen, the backward needs nothing from the host, and the status words of
-    earlier calls are inspected lazily - an overflow (R more than doubled between
-    consecutive calls) is then reported as a RuntimeError on a later call, after that
-    call's outputs were already handed out.  Use for steady-state training loops."""
-    _lib.load_binding().set_async(bool(enabled))
-
-
-if os.environ.get("HGS_ASYNC", "0") not in ("", "0"):
-    set_async(True)
-
-
 def set_stage_events(fwd=None, bwd=None):
     """Measurement hook (bench.py only): sequences of raw hipEvent_t handles (ints) recorded
     after each stage of the following forward / backward calls (HGS_FWD_STAGES /
@@ -74,17 +57,13 @@ def _dev_index(device: torch.device) -> int:
 
 
 def _state(device: torch.device):
-    """Snapshot of the per-device estimates (capacity, tile_hint, max_R, max_tile, pending,
-    synced_calls) kept by the binding."""
+    """Snapshot of the per-device bookkeeping of the binding: capacity / tile_hint used by the
+    last call, max_R / max_tile it reported, calls, retries (forwards re-run after a device-side
+    overflow), wait_ns, and the decaying per-(views, H, W) estimates."""
     idx = _dev_index(device)
     ns = types.SimpleNamespace(**_lib.load_binding().device_state(idx))
     ns.index = idx
     return ns
-
-
-def _drain_pending(st, block: bool = False):
-    """Inspect the status of earlier async forwards (raises if one overflowed)."""
-    _lib.load_binding().drain_pending(st.index, bool(block))
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -105,6 +84,44 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
         float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
         bool(rs.prefiltered), bool(rs.debug), want_grad)
     return color, radii, depth, alpha
+
+
+def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                              cov3Ds_precomp, raster_settings_list):
+    """B views of the same Gaussians in ONE launch set (include/hgs_rast.h: hgs_forward_batch /
+    hgs_backward_batch) - what the reference does with a Python loop over
+    `render()` at threestudio/systems/GaussianDreamer.py:244-266.
+
+    raster_settings_list  sequence of GaussianRasterizationSettings that agree in image size,
+                          sh_degree and scale_modifier (cameras, fov and bg may differ)
+    means2D               (B, P, 3) zeros whose .grad receives the per-view screen-space gradient
+                          (may be None under no_grad)
+    Returns color (B,3,H,W), radii (B,P) int32, depth (B,1,H,W), alpha (B,1,H,W); every view is
+    bit-identical to a separate single-view call, parameter gradients are the sum over the views."""
+    rsl = list(raster_settings_list)
+    if not rsl:
+        raise ValueError("rasterize_gaussians_batch needs at least one view")
+    r0 = rsl[0]
+    for rs in rsl[1:]:
+        if (int(rs.image_height), int(rs.image_width), int(rs.sh_degree), float(rs.scale_modifier)) != \
+                (int(r0.image_height), int(r0.image_width), int(r0.sh_degree), float(r0.scale_modifier)):
+            raise ValueError("all views of a batch must share image size, sh_degree and scale_modifier")
+    B = len(rsl)
+    dev = means3D.device
+    vm = torch.stack([rs.viewmatrix.to(dev, torch.float32).reshape(4, 4) for rs in rsl])
+    pm = torch.stack([rs.projmatrix.to(dev, torch.float32).reshape(4, 4) for rs in rsl])
+    cp = torch.stack([rs.campos.to(dev, torch.float32).reshape(3) for rs in rsl])
+    bg = torch.stack([rs.bg.to(dev, torch.float32).reshape(3) for rs in rsl])
+    if means2D is None:
+        means2D = means3D.new_zeros((0,))
+    want_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad
+        for t in (means3D, means2D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp))
+    return _lib.load_binding().rasterize_batch(
+        means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, bg, vm, pm, cp,
+        int(r0.image_height), int(r0.image_width), [float(rs.tanfovx) for rs in rsl],
+        [float(rs.tanfovy) for rs in rsl], float(r0.scale_modifier), int(r0.sh_degree),
+        bool(r0.prefiltered), any(bool(rs.debug) for rs in rsl), want_grad)
 
 
 class _RasterizeGaussians:

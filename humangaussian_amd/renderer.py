@@ -144,3 +144,67 @@ class Renderer:
                 "viewspace_points": out["viewspace_points"],
                 "visibility_filter": out["visibility_filter"],
                 "radii": out["radii"]}
+
+
+def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
+                 override_color=None):
+    """All views of one training step in ONE rasterize call - the batched form of the loop
+    `for id in range(B): render(Camera(...), gaussian, pipe, bg)` at
+    /root/reference/threestudio/systems/GaussianDreamer.py:244-266.
+
+    The model's activations (`get_opacity / get_scaling / get_rotation / get_features`,
+    scene/gaussian_model.py:95-115) are evaluated once for the batch instead of once per view, the
+    per-view launch sets collapse into one, and parameter gradients arrive summed over the views.
+    Every view's image / depth / alpha / radii is bit-identical to `render()` of that view.
+
+    Returns the reference's dict with a leading view axis:
+      render (B,3,H,W), depth_3dgs (B,1,H,W), alpha_3dgs (B,1,H,W), radii (B,P),
+      visibility_filter (B,P), viewspace_points (B,P,3)  [its .grad[b] is view b's screen-space
+      gradient: GaussianDreamer.py:385-387 sums them],
+    plus what the caller accumulates by hand over the loop (GaussianDreamer.py:253-256,289):
+      radii_max (P,) = max over views, visibility_any (P,) = radii_max > 0."""
+    from .rasterizer import rasterize_gaussians_batch
+    cams = list(viewpoint_cameras)
+    xyz = pc.get_xyz
+    B, P = len(cams), xyz.shape[0]
+    screenspace_points = torch.zeros((B, P, 3), dtype=xyz.dtype, device=xyz.device, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    bg_color = bg_color.to(xyz.device)
+    settings = [GaussianRasterizationSettings(
+        image_height=int(c.image_height), image_width=int(c.image_width),
+        tanfovx=_tan_half(c.FoVx), tanfovy=_tan_half(c.FoVy),
+        bg=bg_color if bg_color.dim() == 1 else bg_color[i], scale_modifier=scaling_modifier,
+        viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=c.camera_center, prefiltered=False,
+        debug=bool(getattr(pipe, "debug", False))) for i, c in enumerate(cams)]
+
+    opacity = pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is not None:
+        colors_precomp = override_color
+    elif getattr(pipe, "convert_SHs_python", False):
+        raise ValueError("convert_SHs_python gives view-dependent colours: render those views with render()")
+    else:
+        shs = pc.get_features
+
+    f = lambda t: None if t is None else t.float()  # noqa: E731  (AMP: kernels are fp32)
+    image, radii, depth, alpha = rasterize_gaussians_batch(
+        f(xyz), f(screenspace_points), f(shs), f(colors_precomp), f(opacity), f(scales), f(rotations),
+        f(cov3D_precomp), settings)
+    radii_max = radii.max(dim=0).values if B > 0 else radii.new_zeros((P,))
+    return {"render": image,
+            "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0,
+            "radii": radii,
+            "depth_3dgs": depth,
+            "alpha_3dgs": alpha,
+            "radii_max": radii_max,
+            "visibility_any": radii_max > 0}

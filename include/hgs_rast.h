@@ -26,6 +26,8 @@
 extern "C" {
 #endif
 
+#define HGS_MAX_VIEWS 16  /* views (cameras) one batched call can take */
+
 #define HGS_OK 0
 #define HGS_EINVAL (-1)   /* bad argument (null pointer, negative size, ...) */
 #define HGS_ESHAPE (-2)   /* "exactly one of shs / colors_precomp", "scales+rotations / cov3D" */
@@ -60,7 +62,7 @@ typedef struct hgs_status {
                            /* entry_capacity (retry with >= num_rendered); bit1: a tile */
                            /* list exceeded max_tile_entries_hint (retry with hint 0)   */
   uint32_t reserved[3];    /* [0] = entry_capacity the bin buffer was carved with,      */
-                           /* [1] = longest tile list                                   */
+                           /* [1] = longest tile list, [2] = forward segments of long lists */
 } hgs_status;
 
 /* ---- buffer sizing (host-side arithmetic, no device work) --------------------------
@@ -72,6 +74,10 @@ size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t hgs_bin_bytes(int64_t entry_capacity);
 size_t hgs_img_bytes(int32_t image_height, int32_t image_width);
 size_t hgs_bwd_scratch_bytes(int64_t num_rendered);
+/* the same for a batch of B views (geom / img scale with B; the bin buffer and the backward
+ * scratch are sized by the entry capacity / num_rendered of ALL views together) */
+size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t image_height, int32_t image_width);
+size_t hgs_img_bytes_batch(int32_t B, int32_t image_height, int32_t image_width);
 
 /* Optional per-stage timing (measurement only; pass NULL in production): `stage_events`
  * is a HOST array of hipEvent_t handles; entry k (if non-NULL) is recorded on `stream`
@@ -106,6 +112,44 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M,
                 int32_t store_bwd_state, int32_t max_tile_entries_hint,
                 hgs_status* status_host, int32_t status_host_mapped, void* status_event,
                 void* const* stage_events, void* stream);
+
+/* ---- batched forward: B views of the same Gaussians in ONE launch set ----------------
+ * Replaces the per-view Python loop around _C.rasterize_gaussians at
+ * /root/reference/threestudio/systems/GaussianDreamer.py:244-266 (8 views per training step).
+ * `views` is a HOST array of B settings (1 <= B <= HGS_MAX_VIEWS) that must agree in
+ * image_height / image_width / sh_degree / scale_modifier and may differ in everything a camera
+ * carries (tanfov, matrices, campos, bg).  Outputs are [B][3][H][W], [B][1][H][W], [B][1][H][W]
+ * and radii [B][P]; each view's result is bit-identical to a separate hgs_forward call.  One
+ * status for the whole batch (num_rendered = sum over views).  hgs_forward IS this function
+ * with B = 1; buffers are sized with the *_batch sizing functions. */
+int hgs_forward_batch(const hgs_settings* views, int32_t B, int32_t P, int32_t M,
+                      const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, const float* rotations,
+                      const float* cov3D_precomp,
+                      float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                      void* geom, void* bin, int64_t entry_capacity, void* img,
+                      int32_t store_bwd_state, int32_t max_tile_entries_hint,
+                      hgs_status* status_host, int32_t status_host_mapped, void* status_event,
+                      void* const* stage_events, void* stream);
+
+/* ---- batched backward ----------------------------------------------------------------
+ * dL_dout_* are [B][..] like the outputs.  Parameter gradients are the SUM over the views, formed
+ * in view order 0..B-1 inside one kernel (deterministic; what autograd accumulates over the
+ * reference's loop); dL_dmeans2D stays per view, [B][P][3], because the caller consumes it per
+ * view (GaussianDreamer.py:385-387).  radii is [B][P]. */
+int hgs_backward_batch(const hgs_settings* views, int32_t B, int32_t P, int32_t M,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, const int32_t* radii,
+                       const float* out_color, const float* out_depth, const float* out_alpha,
+                       const float* dL_dout_color, const float* dL_dout_depth,
+                       const float* dL_dout_alpha,
+                       const void* geom, const void* bin, const void* img,
+                       const hgs_status* status, int64_t entry_capacity, void* bwd_scratch,
+                       float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                       float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D_precomp,
+                       void* const* stage_events, void* stream);
 
 /* ---- backward: replaces _C.rasterize_gaussians_backward ----------------------------
  * `status` is a HOST copy of what hgs_forward reported (read after the stream has passed

@@ -77,12 +77,18 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
       power <= 0, test_T >= 1e-4) lies within rounding distance of its threshold, so that two
       correct fp32 evaluations (exp2-folded conic here, exp there) may take different branches;
       flagged pixels must stay below two minimal contributions (2/255) and stay a tiny minority;
-    * gradients vs the fp64 oracle: per Gaussian max |g - g64| <= grad_tol * max |g64| (per tensor)
-      and cosine >= 1 - cos_tol.  The hard alpha threshold makes the gradient DISCONTINUOUS: one
-      flipped (pixel, Gaussian) pair moves that Gaussian's gradient by up to
-      |dL/dalpha| / 255 * |conic d| * W/2 - a few 1e-3 of max|g| here - so the Gaussians the oracle
-      flagged as involved in a threshold decision (fp32 or fp64 run; a few hundred of 10^5) are
-      gated at 10 * grad_tol instead and counted.
+    * gradients, per tensor and per Gaussian, relative to max |g64|:
+        A. vs the fp32 oracle <= grad_tol          (parity in the arithmetic the reference uses)
+        B. vs the fp64 oracle <= max(grad_tol, 1.25 x the fp32 oracle's own distance to fp64)
+      and cosine(g, g64) >= 1 - max(cos_tol, 2 x (1 - cosine(g32, g64))).  B's second term exists
+      because fp32 itself - the oracle included, and upstream's fp32 CUDA kernels with it - is not
+      within 1e-3 of the exact gradient on every workload: at configs[3] (500k sub-pixel Gaussians,
+      the 0.3 px low-pass dominates cov2D) the conic chain amplifies rounding to ~2e-2 of max|g|;
+      at configs[1] it is 9e-4.  Both distances are recorded.
+      The hard alpha threshold makes the gradient DISCONTINUOUS: one flipped (pixel, Gaussian)
+      pair moves that Gaussian's gradient by up to |dL/dalpha| / 255 * |conic d| * W/2 - a few
+      1e-3 of max|g| here - so the Gaussians the oracle flagged as involved in a threshold decision
+      (fp32 or fp64 run; a few hundred of 10^5) are gated at 10 x the bound instead and counted.
     The images are gated against the fp32 oracle because fp32 itself (any implementation, the
     oracle included) is not within 1e-4 of an fp64 evaluation on every pixel of a million:
     ill-conditioned conics carry alpha errors of ~1e-4 relative; how far the fp32 oracle and this
@@ -90,6 +96,9 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
     Returns the statistics (also appended to PARITY_LOG / $HGS_PARITY_STATS)."""
     import os
     import oracle
+    if not torch.is_grad_enabled():          # the oracle differentiates with autograd
+        with torch.enable_grad():
+            return check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol, grad_tol, cos_tol, threads)
     torch.set_num_threads(threads or max(1, min(os.cpu_count() or 1, 64)))
     c, r, d, a, g = hip
     st = settings_fp32
@@ -139,19 +148,27 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
             scale = max(float(ref.abs().max()), 1e-300)
             err = (got - ref).abs().reshape(Pn, -1).amax(dim=1)
             cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
-            e_solid = float(err[~flipg].max()) / scale
-            e_flip = float(err[flipg].max()) / scale if stats["flagged_flip_gaussians"] else 0.0
-            stats[f"grad_{k}_relerr_nonflip"] = e_solid
-            stats[f"grad_{k}_relerr_flip"] = e_flip
-            stats[f"grad_{k}_flip_gaussians_above_tol"] = int((err[flipg] > grad_tol * scale).sum())
-            stats[f"grad_{k}_1-cos"] = 1.0 - cos
-            # informational: distance to the fp32 oracle, and of the fp32 oracle to fp64
             r32 = o32["grads"][k].double().reshape(ref.shape)
-            stats[f"grad_{k}_relerr_vs_fp32oracle"] = float((got - r32).abs().max()) / scale
-            stats[f"grad_{k}_fp32oracle_vs_fp64_nonflip"] = float((r32 - ref).abs().reshape(Pn, -1).amax(dim=1)[~flipg].max()) / scale
-            gate(e_solid <= grad_tol, k, "non-flip Gaussian gradient", e_solid)
-            gate(e_flip <= 10 * grad_tol, k, "flip Gaussian gradient", e_flip)
-            gate(cos >= 1.0 - cos_tol, k, "cosine", cos)
+            e32 = (r32 - ref).abs().reshape(Pn, -1).amax(dim=1)             # fp32 oracle vs fp64
+            eA = (got - r32).abs().reshape(Pn, -1).amax(dim=1)              # this implementation vs fp32 oracle
+            cos32 = float(torch.nn.functional.cosine_similarity(r32.flatten(), ref.flatten(), dim=0))
+            nf = ~flipg
+            has_flip = stats["flagged_flip_gaussians"] > 0
+            st_ = {"vs_fp64_nonflip": float(err[nf].max()) / scale,
+                   "vs_fp64_flip": float(err[flipg].max()) / scale if has_flip else 0.0,
+                   "vs_fp32oracle_nonflip": float(eA[nf].max()) / scale,
+                   "vs_fp32oracle_flip": float(eA[flipg].max()) / scale if has_flip else 0.0,
+                   "fp32oracle_vs_fp64_nonflip": float(e32[nf].max()) / scale,
+                   "flip_gaussians_above_tol": int((err[flipg] > grad_tol * scale).sum()),
+                   "1-cos": 1.0 - cos, "fp32oracle_1-cos": 1.0 - cos32}
+            for kk, vv in st_.items():
+                stats[f"grad_{k}_{kk}"] = vv
+            boundB = max(grad_tol, 1.25 * st_["fp32oracle_vs_fp64_nonflip"])
+            gate(st_["vs_fp32oracle_nonflip"] <= grad_tol, k, "A: vs fp32 oracle", st_["vs_fp32oracle_nonflip"])
+            gate(st_["vs_fp32oracle_flip"] <= 10 * grad_tol, k, "A: vs fp32 oracle (flip Gaussians)", st_["vs_fp32oracle_flip"])
+            gate(st_["vs_fp64_nonflip"] <= boundB, k, "B: vs fp64 oracle", st_["vs_fp64_nonflip"], boundB)
+            gate(st_["vs_fp64_flip"] <= 10 * boundB, k, "B: vs fp64 oracle (flip Gaussians)", st_["vs_fp64_flip"])
+            gate(1.0 - cos <= max(cos_tol, 2.0 * (1.0 - cos32)), k, "cosine", cos, cos32)
     stats["failures"] = [list(map(str, f)) for f in failures]
     PARITY_LOG.append(stats)
     print("PARITY", stats)

@@ -116,10 +116,13 @@ def test_preprocess_records_bitwise():
     assert np.array_equal(rec["rect_lo"][vis] >> 16, rect[:, 1])
     assert np.array_equal(rec["rect_hi"][vis] & 0xFFFF, rect[:, 2])
     assert np.array_equal(rec["rect_hi"][vis] >> 16, rect[:, 3])
-    # entry-id prefix = exclusive scan of tiles_touched in index order
+    # entry ids: `offset` = exclusive prefix of tiles_touched inside the Gaussian's 256-chunk (the chunk
+    # bases are bump-allocated on the device; the gradient tests prove the ranges tile [0, R))
     tt = pre["tiles_touched"].numpy()
-    off = np.cumsum(tt) - tt
-    assert np.array_equal(rec["offset"][vis], off[vis].astype(np.uint32))
+    for c0 in range(0, len(tt), 256):
+        seg = tt[c0:c0 + 256]
+        assert np.array_equal(rec["offset"][c0:c0 + 256], (np.cumsum(seg) - seg).astype(np.uint32))
+    assert int(tt.sum()) == rc.status[0]
 
 
 @pytest.mark.parametrize("H,W", [(16, 16), (17, 33), (100, 60), (1, 1)])
@@ -345,43 +348,6 @@ def test_backward_without_host_status_matches():
     for k in a:
         if a[k] is not None:
             assert torch.equal(a[k], b[k]), k
-
-
-def test_async_mode_python_api_matches_sync_mode():
-    import math
-    from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
-    from humangaussian_amd import rasterizer as R
-    dev = torch.device("cuda")
-    sc = make_scene(P=700, sh_degree=1, seed=71, H=64, W=64, spread=0.2)
-    cam = sc["cam"]
-    rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx / 2),
-                                       math.tan(cam.FoVy / 2), sc["bg"].to(dev), 1.0,
-                                       cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev),
-                                       1, cam.camera_center.to(dev), False, False)
-    gcol, gdep, galp = (g.to(dev) for g in rand_grads(64, 64, seed=8))
-
-    def run():
-        ins = {k: sc[k].to(dev).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
-        m2 = torch.zeros_like(ins["means3D"], requires_grad=True)
-        c, r, d, a = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"],
-                                            opacities=ins["opacities"], scales=ins["scales"],
-                                            rotations=ins["rotations"])
-        torch.autograd.backward([c, d, a], [gcol, gdep, galp])
-        return [c.detach(), d.detach(), a.detach(), r] + [t.grad for t in ins.values()] + [m2.grad]
-
-    ref = run()
-    ref = run()
-    R.set_async(True)
-    try:
-        for _ in range(3):
-            got = run()
-        torch.cuda.synchronize()
-        assert not R._state(dev).pending or True
-        for x, y in zip(ref, got):
-            assert torch.equal(x, y)
-    finally:
-        R.set_async(False)
-        R._drain_pending(R._state(dev), block=True)
 
 
 def test_status_via_mapped_pinned_memory_equals_copied_status():
