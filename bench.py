@@ -221,6 +221,35 @@ def main():
                  "event_wait_us": round((st_now.wait_ns - w0) / nhost * 1e-3, 1),
                  "forward_retries_total": int(st_now.retries), "forward_calls_total": int(st_now.calls)}
 
+    # ---------------- N > 1: what the one collective of a step costs (outside the timed region)
+    collective = None
+    if world > 1:
+        L = main_wl.leaves
+        grads = {k: torch.zeros_like(L[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        grads["means2D"] = torch.zeros_like(L["means3D"])
+        rad = torch.ones(P, dtype=torch.int32, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        acc = [0.0, 0.0, 0.0]
+        nrep = 20
+        for it in range(nrep + 3):
+            fence()
+            ev[0].record()
+            pack = vp.pack_contribution(grads, rad)
+            ev[1].record()
+            gathered = vp.allgather(pack)
+            ev[2].record()
+            vp.reduce_gathered(gathered)
+            ev[3].record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                for i in range(3):
+                    acc[i] += ev[i].elapsed_time(ev[i + 1])
+        tt = torch.tensor(acc, dtype=torch.float64, device=dev) / nrep * 1e3
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        collective = {"pack_us": float(tt[0]), "allgather_us": float(tt[1]), "reduce_us": float(tt[2]),
+                      "bytes_per_rank": int(pack.numel() * 4), "note": "one all_gather_into_tensor of the per-rank "
+                      "gradient pack per step, then a rank-ordered local reduction (max over ranks of each phase)"}
+
     # ---------------- per-kernel timing (outside the timed region; library-recorded events)
     stage_us = main_wl.stage_times()
     R = int(_rast._state(dev).max_R)
@@ -332,6 +361,7 @@ def main():
                                   "kernels": "render_fwd + render_bwd"}},
             "stage_us": stage_us,
             "host": host_info,
+            "collective": collective,
             "cpu_baseline": cpu,
             "extra": extra,
         }

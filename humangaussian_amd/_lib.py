@@ -69,6 +69,13 @@ EXPORTS = {
     "hgs_knn_mean_dist2": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "hgs_reduce_view_packs": (ctypes.c_int, [c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "hgs_pack_view_contribution": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 9),
+    "hgs_densify_stats": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 9),
+    "hgs_densify_masks": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p]
+                          + [c_float] * 6 + [c_void_p] * 5),
+    "hgs_compact_scratch_bytes": (c_size_t, [c_int32]),
+    "hgs_compact_index": (ctypes.c_int, [c_int32] + [c_void_p] * 5),
+    "hgs_gather_rows": (ctypes.c_int, [c_int64, c_int32] + [c_void_p] * 4),
+    "hgs_reanchor": (ctypes.c_int, [c_int32] + [c_void_p] * 7),
 }
 
 

@@ -13,6 +13,7 @@
 #include "binning.hip"
 #include "render_fwd.hip"
 #include "knn.hip"
+#include "bookkeeping.hip"
 
 // render_bwd.hip is a separate translation unit (different optimisation flags)
 extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*,
@@ -22,6 +23,9 @@ extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, con
 
 namespace {
 
+#ifndef HGS_SEG_RECOMPUTE_MAX
+#define HGS_SEG_RECOMPUTE_MAX 12   // longest list (in segments) for which segments recompute their predecessors' products
+#endif
 constexpr size_t ALIGN = 256;
 constexpr size_t HGS_LDS_BINS_MAX = 16384;   // T*4 bytes of LDS <= 64 KB
 constexpr int HGS_MAX_BIN_WGS_PER_VIEW = 256;
@@ -162,7 +166,7 @@ View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_
   v.seg_off = (max_tile_hint > 0 && max_tile_hint <= HGS_SEG_THRESH) ? 1 : 0;
   // few segments per list: a segment recomputes its predecessors' transmittance products itself
   // (work quadratic in the segment count, hence the bound) and hgs_k_fwd_segT is not launched
-  v.seg_recompute = (max_tile_hint > 0 && max_tile_hint <= 12 * HGS_SEG) ? 1 : 0;
+  v.seg_recompute = (max_tile_hint > 0 && max_tile_hint <= HGS_SEG_RECOMPUTE_MAX * HGS_SEG) ? 1 : 0;
   return v;
 }
 
@@ -309,12 +313,23 @@ int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, co
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(1);
-  // tile tables + status: 64 tiles per workgroup, all views in one launch
+  // tile tables: 64 tiles per workgroup, all views in one launch
   const unsigned bpv = (unsigned)((v.T + HGS_TILES_PER_WG - 1) / HGS_TILES_PER_WG);
-  hipLaunchKernelGGL(hgs_k_tiles, dim3(bpv * (unsigned)v.B), dim3(64 * HGS_ROW_GROUPS), 0, stream, v, L,
-                     status_dev, status_host_mapped ? status_host : nullptr);
+  hipLaunchKernelGGL(hgs_k_tiles, dim3(bpv * (unsigned)v.B), dim3(64 * HGS_ROW_GROUPS), 0, stream, v, L);
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
+  // binning workgroups scatter the keys; `order_wgs` more place the tiles into tile_order, hand out
+  // the chunks' entry-id bases and publish the status (device copy, pinned host mirror)
+  const unsigned order_wgs = (unsigned)((v.TT + HGS_BLOCK - 1) / HGS_BLOCK);
+  hgs_status* status_mapped = status_host_mapped ? status_host : nullptr;
+  const unsigned nbin = entry_capacity > 0 ? (unsigned)(v.B * (v.lds_bins ? v.nwg : v.nblk)) : 0u;
+  if (v.lds_bins && nbin)
+    hipLaunchKernelGGL(hgs_k_fill, dim3(nbin + order_wgs), dim3(HGS_BLOCK), lds_bytes, stream, v, L, status_dev,
+                       status_mapped, (int)nbin);
+  else
+    hipLaunchKernelGGL(hgs_k_fill_ga, dim3(nbin + order_wgs), dim3(HGS_BLOCK), 0, stream, v, L, status_dev,
+                       status_mapped, (int)nbin);
+  HGS_LAUNCH_CHECK();
   // the status is final here: publish it now so the host can wait for it alone
   if (status_host && !status_host_mapped) {
     e = hipMemcpyAsync(status_host, status_dev, sizeof(hgs_status), hipMemcpyDeviceToHost, stream);
@@ -324,16 +339,7 @@ int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, co
     e = hipEventRecord(static_cast<hipEvent_t>(status_event), stream);
     if (e != hipSuccess) return hip_rc(e);
   }
-  const unsigned order_wgs = (unsigned)((v.TT + HGS_BLOCK - 1) / HGS_BLOCK);
   if (entry_capacity > 0) {
-    // binning workgroups scatter the keys; `order_wgs` more place the tiles into tile_order
-    if (v.lds_bins)
-      hipLaunchKernelGGL(hgs_k_fill, dim3((unsigned)(v.B * v.nwg) + order_wgs), dim3(HGS_BLOCK), lds_bytes,
-                         stream, v, L, status_dev, v.B * v.nwg);
-    else
-      hipLaunchKernelGGL(hgs_k_fill_ga, dim3((unsigned)(v.B * v.nblk) + order_wgs), dim3(HGS_BLOCK), 0, stream,
-                         v, L, status_dev, v.B * v.nblk);
-    HGS_LAUNCH_CHECK();
     HGS_STAGE(3);
     // tiles are ordered heavy-first, so a class with more than LO entries per tile can only
     // occupy the first capacity/LO positions of tile_order
@@ -355,8 +361,6 @@ int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, co
     hipLaunchKernelGGL(hgs_k_sort_lds, dim3(class_grid(1)), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
   } else {
-    hipLaunchKernelGGL(hgs_k_fill_ga, dim3(order_wgs), dim3(HGS_BLOCK), 0, stream, v, L, status_dev, 0);   // tile order only
-    HGS_LAUNCH_CHECK();
     HGS_STAGE(3);
   }
   HGS_STAGE(4);
@@ -482,6 +486,87 @@ int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means
                             dL_dout_depth, dL_dout_alpha, geom, bin, img, status, entry_capacity, bwd_scratch,
                             dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales,
                             dL_drotations, dL_dcov3D_precomp, stage_events, stream_);
+}
+
+int hgs_densify_stats(int32_t B, int32_t P, const float* dL_dmeans2D, const int32_t* radii, const uint8_t* keep,
+                      float* xyz_gradient_accum, float* denom, float* max_radii2D, int32_t* radii_max,
+                      uint8_t* visibility, void* stream_) {
+  if (B < 1 || P < 0) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!dL_dmeans2D || !radii || !xyz_gradient_accum || !denom || !max_radii2D) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(hgs_k_densify_stats, dim3((P + 255) / 256), dim3(256), 0, stream, (int)B, (int)P, dL_dmeans2D,
+                     radii, keep, xyz_gradient_accum, denom, max_radii2D, radii_max, visibility);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+int hgs_densify_masks(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scales,
+                      int32_t scales_are_log, const float* opacity, int32_t opacity_is_logit,
+                      const float* max_radii2D, float grad_threshold, float percent_dense, float extent,
+                      float min_opacity, float max_screen_size, float size_thresh, uint8_t* clone_mask,
+                      uint8_t* split_mask, uint8_t* prune_mask, uint32_t* counts, void* stream_) {
+  if (P < 0) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (counts) {
+    hipError_t e = hipMemsetAsync(counts, 0, 3 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  if (P == 0) return HGS_OK;
+  if (!xyz_gradient_accum || !denom || !scales || !opacity || (max_screen_size > 0.0f && !max_radii2D)) return HGS_EINVAL;
+  hipLaunchKernelGGL(hgs_k_densify_masks, dim3((P + 255) / 256), dim3(256), 0, stream, (int)P, xyz_gradient_accum, denom,
+                     scales, (int)scales_are_log, opacity, (int)opacity_is_logit, max_radii2D, grad_threshold,
+                     percent_dense, extent, min_opacity, max_screen_size, size_thresh, clone_mask, split_mask, prune_mask,
+                     counts);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+size_t hgs_compact_scratch_bytes(int32_t P) {
+  return hgs_align_up(((size_t)(P > 0 ? P : 0) + 1023) / 1024 * 4 + 4, ALIGN);
+}
+
+int hgs_compact_index(int32_t P, const uint8_t* keep, int32_t* src_of_dst, uint32_t* num_kept, void* scratch,
+                      void* stream_) {
+  if (P < 0 || !num_kept) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (P == 0) {
+    hipError_t e = hipMemsetAsync(num_kept, 0, 4, stream);
+    return e == hipSuccess ? HGS_OK : hip_rc(e);
+  }
+  if (!keep || !src_of_dst || !scratch) return HGS_EINVAL;
+  const int nb = (P + 1023) / 1024;
+  uint32_t* blocks = static_cast<uint32_t*>(scratch);
+  hipLaunchKernelGGL(hgs_k_keep_count, dim3(nb), dim3(1024), 0, stream, (int)P, keep, blocks);
+  hipLaunchKernelGGL(hgs_k_keep_scan, dim3(1), dim3(1024), 0, stream, nb, blocks, num_kept);
+  hipLaunchKernelGGL(hgs_k_keep_index, dim3(nb), dim3(1024), 0, stream, (int)P, keep, blocks, src_of_dst);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+int hgs_gather_rows(int64_t n_out, int32_t row_floats, const int32_t* src_of_dst, const float* src, float* dst,
+                    void* stream_) {
+  if (n_out < 0 || row_floats < 1) return HGS_EINVAL;
+  if (n_out == 0) return HGS_OK;
+  if (!src_of_dst || !src || !dst) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const long long n = (long long)n_out * row_floats;
+  hipLaunchKernelGGL(hgs_k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, (int)row_floats,
+                     src_of_dst, src, dst);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+int hgs_reanchor(int32_t P, const float* vertices, const int32_t* faces, const int32_t* mapping_face,
+                 const float* mapping_uvw, const float* mapping_dist, float* xyz, void* stream_) {
+  if (P < 0) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!vertices || !faces || !mapping_face || !mapping_uvw || !mapping_dist || !xyz) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  hipLaunchKernelGGL(hgs_k_reanchor, dim3((P + 255) / 256), dim3(256), 0, stream, (int)P, vertices, faces, mapping_face,
+                     mapping_uvw, mapping_dist, xyz);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
 }
 
 int hgs_mark_visible(const hgs_settings* s, int32_t P, const float* means3D, uint8_t* present,

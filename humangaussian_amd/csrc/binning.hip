@@ -8,12 +8,11 @@
 //                      rows turned into exclusive bases in place), and hands every tile its list
 //                      range, bucket-state range, backward work-item range and segment-plane range
 //                      by BUMP ALLOCATION (two 64-bit atomics per 64 tiles) - no prefix scan
-//                      over the tiles, no single-workgroup latency chain.  The last workgroup to
-//                      finish (ticket) publishes hgs_status and the class bases of the
-//                      heavy-first tile order.
+//                      over the tiles, no single-workgroup latency chain, no ticket.
 //   2. hgs_k_fill      per Gaussian: scatter (depth_bits<<32 | idx) keys into its tiles' list
 //                      ranges (order inside a tile is arbitrary here); extra workgroups of the same
-//                      launch place the tiles into tile_order (heavy classes first).
+//                      launch place the tiles into tile_order (heavy classes first), hand out the
+//                      entry-id bases of the Gaussian chunks and publish hgs_status.
 //   3. hgs_k_sort_*    per tile: bitonic sort of the tile's keys IN LDS (unique keys =>
 //                      deterministic result = upstream's stable order: depth, ties by index),
 //                      then gathers the Gaussians into a depth-ordered, contiguous 48-byte
@@ -29,11 +28,10 @@
 // place (hist[row][t] -> entries of tile t owned by earlier workgroups of the same group).
 // Global-atomic path (T > 16384): the counts are already in tile_count.
 extern "C" __global__ void __launch_bounds__(64 * HGS_ROW_GROUPS)
-hgs_k_tiles(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __restrict__ status_host) {
+hgs_k_tiles(View v, Layout L) {
   __shared__ uint32_t gt[HGS_ROW_GROUPS][HGS_TILES_PER_WG];     // group totals per tile
   __shared__ uint32_t start_s[HGS_TILES_PER_WG];
   __shared__ uint32_t cls_s[HGS_NCLS];
-  __shared__ uint32_t last_s;
   const int tid = threadIdx.x, tl = tid & 63;
   const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bpv = (v.T + HGS_TILES_PER_WG - 1) / HGS_TILES_PER_WG;      // workgroups per view
@@ -108,69 +106,10 @@ hgs_k_tiles(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __res
     const uint32_t mx = hgs_wave_max_u32(n);
     if (tl == 0 && mx) atomicMax(&L.ctr->max_n, mx);
   }
-  if (rg == 1) {
-    // entry-id bases of the 256-Gaussian chunks: this workgroup's share of the B*nblk chunks, one
-    // bump allocation per 64 chunks (runs beside wave 0's tile allocation)
-    const int nchunk = v.B * v.nblk;
-    const int per_wg = (nchunk + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int c_begin = (int)blockIdx.x * per_wg, c_end = min(nchunk, c_begin + per_wg);
-    for (int c0 = c_begin; c0 < c_end; c0 += 64) {
-      const int c = c0 + tl;
-      const uint32_t sum = (c < c_end) ? L.chunk_sums[c] : 0u;
-      const uint32_t inc = hgs_wave_incl_scan(sum);
-      uint32_t base = 0;
-      if (tl == 63 && inc) base = atomicAdd(&L.ctr->entry_alloc, inc);
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
-      if (c < c_end) L.chunk_base[c] = base + inc - sum;
-    }
-  }
   __syncthreads();
   if (v.lds_bins && valid) L.tile_gbase[(size_t)rg * v.TT + g] = start_s[tl] + gbase;
   if (tid < HGS_NCLS && cls_s[tid]) atomicAdd(&L.ctr->cls_hist[tid], cls_s[tid]);
 
-  // ---- ticket: the last workgroup publishes the status and the class bases.  Everything it
-  // reads was produced by device-scope atomics (performed at the point of coherence).
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    last_s = (atomicAdd(&L.ctr->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!last_s) return;
-  // read the totals with one atomic per lane (33 sequential round trips cost ~20 us here)
-  __shared__ uint32_t tot_s[HGS_NCLS + 8];
-  __threadfence();
-  if (tid < HGS_NCLS) tot_s[tid] = atomicAdd(&L.ctr->cls_hist[tid], 0u);
-  if (tid == 64) { const unsigned long long a = atomicAdd(&L.ctr->alloc_eb, 0ull); tot_s[HGS_NCLS] = (uint32_t)a; tot_s[HGS_NCLS + 1] = (uint32_t)(a >> 32); }
-  if (tid == 128) { const unsigned long long a = atomicAdd(&L.ctr->alloc_ws, 0ull); tot_s[HGS_NCLS + 2] = (uint32_t)a; tot_s[HGS_NCLS + 3] = (uint32_t)(a >> 32); }
-  if (tid == 192) tot_s[HGS_NCLS + 4] = atomicMax(&L.ctr->max_n, 0u);
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t max_n = tot_s[HGS_NCLS + 4];
-    uint32_t acc = 0;
-    for (int c = HGS_NCLS - 1; c >= 0; --c) {      // heavy classes first; class 0 (empty tiles) last
-      L.ctr->cls_cur[c] = acc;
-      acc += tot_s[c];
-    }
-    const uint32_t empty = tot_s[0];
-    const unsigned long long a_eb = (unsigned long long)tot_s[HGS_NCLS] | ((unsigned long long)tot_s[HGS_NCLS + 1] << 32);
-    const unsigned long long a_ws = (unsigned long long)tot_s[HGS_NCLS + 2] | ((unsigned long long)tot_s[HGS_NCLS + 3] << 32);
-    hgs_status st;
-    st.num_rendered = (uint32_t)a_eb;
-    st.active_tiles = (uint32_t)v.TT - empty;
-    st.num_buckets = (uint32_t)(a_eb >> 32);
-    st.bwd_groups = (uint32_t)a_ws;
-    st.overflow = (st.num_rendered > v.entry_capacity) ? 1u : 0u;
-    if (v.max_tile_hint > 0 && max_n > (uint32_t)v.max_tile_hint) st.overflow |= 2u;
-    st.reserved[0] = v.entry_capacity;   // carve key for hgs_backward
-    st.reserved[1] = max_n;              // longest tile list
-    st.reserved[2] = (uint32_t)(a_ws >> 32);   // segment planes
-    *status = st;
-    if (status_host) {            // pinned, device-mapped host memory: no in-stream copy
-      *status_host = st;
-      __threadfence_system();
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------- 2. fill
@@ -179,29 +118,93 @@ hgs_k_tiles(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __res
 // earlier workgroups of the group) + an LDS cursor.  Workgroups beyond the binning ones place
 // tiles into tile_order: position = class base (heavy first) + a cursor; the order INSIDE a
 // class is free (it only schedules work).
-__device__ __forceinline__ void place_tiles(const View& v, const Layout& L, int blk) {
-  const int g = blk * HGS_BLOCK + (int)threadIdx.x;
+// overflow word of this call, recomputed from the counters hgs_k_tiles left (the status itself is
+// published by the first tile-order workgroup of the SAME launch, so fill cannot read it yet)
+__device__ __forceinline__ uint32_t overflow_from_counters(const View& v, const Layout& L) {
+  const uint32_t R = (uint32_t)L.ctr->alloc_eb;
+  uint32_t o = (R > v.entry_capacity) ? 1u : 0u;
+  if (v.max_tile_hint > 0 && L.ctr->max_n > (uint32_t)v.max_tile_hint) o |= 2u;
+  return o;
+}
+
+// The workgroups behind the binning ones ("order" workgroups, 256 tiles each):
+//  * place their tiles into tile_order (class base, heavy classes first, + a cursor per class);
+//  * bump-allocate the entry-id bases of their share of the 256-Gaussian chunks;
+//  * the first of them publishes hgs_status (device copy + pinned host mirror).
+// All of this used to sit at the end of the tile kernel behind a ticket; here it costs no extra
+// latency chain (it runs beside the key scatter).
+__device__ __forceinline__ void place_tiles(const View& v, const Layout& L, int blk, int nblks,
+                                            hgs_status* __restrict__ status,
+                                            hgs_status* __restrict__ status_host) {
+  __shared__ uint32_t cls_base[HGS_NCLS];
+  __shared__ uint32_t cls_cnt[HGS_NCLS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < HGS_NCLS) cls_cnt[tid] = L.ctr->cls_hist[tid];
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int c = HGS_NCLS - 1; c >= 0; --c) { cls_base[c] = acc; acc += cls_cnt[c]; }   // heavy classes first
+  }
+  if (blk == 0 && tid == 64) {
+    const unsigned long long a_eb = L.ctr->alloc_eb, a_ws = L.ctr->alloc_ws;
+    hgs_status st;
+    st.num_rendered = (uint32_t)a_eb;
+    st.active_tiles = (uint32_t)v.TT - cls_cnt[0];
+    st.num_buckets = (uint32_t)(a_eb >> 32);
+    st.bwd_groups = (uint32_t)a_ws;
+    st.overflow = overflow_from_counters(v, L);
+    st.reserved[0] = v.entry_capacity;   // carve key for hgs_backward
+    st.reserved[1] = L.ctr->max_n;       // longest tile list
+    st.reserved[2] = (uint32_t)(a_ws >> 32);   // segment planes
+    *status = st;
+    if (status_host) {            // pinned, device-mapped host memory: no in-stream copy
+      *status_host = st;
+      __threadfence_system();
+    }
+  }
+  if (tid >= 128 && tid < 192) {
+    // entry-id bases of this workgroup's share of the B*nblk chunks: one bump allocation per 64 chunks
+    const int nchunk = v.B * v.nblk;
+    const int per_wg = (nchunk + nblks - 1) / nblks;
+    const int c_begin = blk * per_wg, c_end = min(nchunk, c_begin + per_wg);
+    for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+      const int c = c0 + lane;
+      const uint32_t sum = (c < c_end) ? L.chunk_sums[c] : 0u;
+      const uint32_t inc = hgs_wave_incl_scan(sum);
+      uint32_t base = 0;
+      if (lane == 63 && inc) base = atomicAdd(&L.ctr->entry_alloc, inc);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+      if (c < c_end) L.chunk_base[c] = base + inc - sum;
+    }
+  }
+  __syncthreads();
+  const int g = blk * HGS_BLOCK + tid;
   const bool valid = g < v.TT;
   const uint32_t n = valid ? L.tile_n[g] : 0u;
   const bool empty = valid && n == 0;
   const unsigned long long ball = __ballot(empty);
   uint32_t wbase = 0;
-  if ((threadIdx.x & 63) == 0 && ball) wbase = atomicAdd(&L.ctr->cls_cur[0], (uint32_t)__popcll(ball));
+  if (lane == 0 && ball) wbase = atomicAdd(&L.ctr->cls_cur[0], (uint32_t)__popcll(ball));
   wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
   if (!valid) return;
   uint32_t pos;
   if (empty)
-    pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-  else
-    pos = atomicAdd(&L.ctr->cls_cur[32 - __clz(n)], 1u);
+    pos = cls_base[0] + wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+  else {
+    const int c = 32 - __clz(n);
+    pos = cls_base[c] + atomicAdd(&L.ctr->cls_cur[c], 1u);
+  }
   L.tile_order[pos] = (uint32_t)g;
 }
 
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
-hgs_k_fill(View v, Layout L, const hgs_status* __restrict__ status, int nbin) {
+hgs_k_fill(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __restrict__ status_host, int nbin) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_cur[];
-  if ((int)blockIdx.x >= nbin) { place_tiles(v, L, (int)blockIdx.x - nbin); return; }
-  if (status->overflow) return;
+  if ((int)blockIdx.x >= nbin) {
+    place_tiles(v, L, (int)blockIdx.x - nbin, (int)gridDim.x - nbin, status, status_host);
+    return;
+  }
+  if (overflow_from_counters(v, L)) return;
   const int b = (int)blockIdx.x / v.nwg, lw = (int)blockIdx.x % v.nwg;
   const uint32_t* __restrict__ base_row = L.hist + (size_t)blockIdx.x * v.T;
   const int rpg = (v.nwg + HGS_ROW_GROUPS - 1) / HGS_ROW_GROUPS;
@@ -228,9 +231,12 @@ hgs_k_fill(View v, Layout L, const hgs_status* __restrict__ status, int nbin) {
 
 // Fallback (global atomics) for T*4 > 64 KB.
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
-hgs_k_fill_ga(View v, Layout L, const hgs_status* __restrict__ status, int nbin) {
-  if ((int)blockIdx.x >= nbin) { place_tiles(v, L, (int)blockIdx.x - nbin); return; }
-  if (status->overflow) return;
+hgs_k_fill_ga(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __restrict__ status_host, int nbin) {
+  if ((int)blockIdx.x >= nbin) {
+    place_tiles(v, L, (int)blockIdx.x - nbin, (int)gridDim.x - nbin, status, status_host);
+    return;
+  }
+  if (overflow_from_counters(v, L)) return;
   const int b = (int)blockIdx.x / v.nblk, chunk = (int)blockIdx.x % v.nblk;
   const int i = chunk * HGS_BLOCK + threadIdx.x;
   if (i >= v.P) return;
@@ -377,13 +383,52 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* keys, uint32_t 
 // ---- register / wave-shuffle / LDS hybrid of the same network -------------------------
 // Thread t owns E consecutive keys (indices t*E .. t*E+E-1) in REGISTERS.  A comparator
 // of stride < E stays inside the thread; stride < 64*E pairs lanes of one wave and goes
-// through ds_bpermute (no barrier); only strides >= 64*E (a handful of the ~50-80 stages)
-// exchange through LDS with barriers.  Padding is explicit (+inf keys).
+// through DPP / permlane-swap lane exchanges (no LDS, no barrier); only strides >= 64*E (a
+// handful of the ~50-80 stages) exchange through LDS with barriers.  Padding is explicit (+inf keys).
 typedef unsigned long long u64;
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
-  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64);
-  const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+// Lane exchange i <-> i ^ M inside a wave WITHOUT the LDS pipe: every mask the network needs
+// (xor strides 1..32 and the mirror masks 3, 7, 15, 31, 63) maps to DPP controls or to gfx950's
+// v_permlane16_swap / v_permlane32_swap.  (The first version used ds_bpermute for all of them: a
+// dependent LDS round trip per stage, ~600 cycles per stage on the heaviest tile.)
+typedef unsigned hgs_u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef HGS_SORT_XCHG
+#define HGS_SORT_XCHG 0      // 0: ds_bpermute for every mask, 1: DPP inside a 16-lane row + ds_bpermute across rows,
+#endif                       // 2: DPP + v_permlane16/32_swap for every mask.  Measured: see DESIGN.md section 4.
+
+template <int M>
+__device__ __forceinline__ uint32_t xchg_xor32(uint32_t x, int lane) {
+  const int xi = (int)x;
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_QUAD_PERM(1, 0, 3, 2), 0xf, 0xf, false);
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_QUAD_PERM(2, 3, 0, 1), 0xf, 0xf, false);
+  else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_QUAD_PERM(3, 2, 1, 0), 0xf, 0xf, false);
+  else if constexpr (M == 4) {
+    // banks 0 and 2 of every row read 4 lanes up, banks 1 and 3 read 4 lanes down (bank masks)
+    const int t = __builtin_amdgcn_update_dpp(xi, xi, 0x100 + 4 /* row_shl:4 */, 0xf, 0x5, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(t, xi, HGS_DPP_ROW_SHR(4), 0xf, 0xa, false);
+  } else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+  else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_ROW_ROR(8), 0xf, 0xf, false);
+  else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_ROW_MIRROR, 0xf, 0xf, false);
+  else if constexpr (M == 16) {
+    // v_permlane16_swap: odd rows of the first operand <-> even rows of the second
+    const hgs_u32x2 s2 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return (lane & 16) ? s2.x : s2.y;
+  } else if constexpr (M == 32) {
+    // v_permlane32_swap: upper half of the first operand <-> lower half of the second
+    const hgs_u32x2 s2 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (lane & 32) ? s2.x : s2.y;
+  } else if constexpr (M == 31) return xchg_xor32<16>(xchg_xor32<15>(x, lane), lane);
+  else {
+    static_assert(M == 63, "unsupported lane mask");
+    return xchg_xor32<32>(xchg_xor32<16>(xchg_xor32<15>(x, lane), lane), lane);
+  }
+}
+
+template <int M>
+__device__ __forceinline__ u64 xchg_xor64(u64 v, int lane) {
+  const uint32_t lo = xchg_xor32<M>((uint32_t)v, lane);
+  const uint32_t hi = xchg_xor32<M>((uint32_t)(v >> 32), lane);
   return ((u64)hi << 32) | lo;
 }
 
@@ -412,12 +457,58 @@ __device__ __forceinline__ void reg_stage_mirror(u64 (&k)[E], int kk) {   // kk 
   }
 }
 
-// one stage whose partner lives in another lane of the same wave
+// One stage whose partner lives in another lane of the same wave (lane ^ lane_mask).  Only the
+// exchange differs between the masks; the compare/select code behind it is shared (a switch
+// over whole stages tripled the kernel's code size and cost 10 us in instruction fetch).
+template <int E, int M>
+__device__ __forceinline__ void xchg_all(const u64 (&src)[E], u64 (&o)[E], int lane) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) o[e] = xchg_xor64<M>(src[e], lane);
+}
+
 template <int E>
 __device__ __forceinline__ void lane_stage(u64 (&k)[E], int lane_mask, bool mirror, bool keep_min) {
-  u64 o[E];
+  const int lane = (int)threadIdx.x & 63;
+  u64 src[E], o[E];
 #pragma unroll
-  for (int e = 0; e < E; ++e) o[e] = shfl_xor_u64(mirror ? k[E - 1 - e] : k[e], lane_mask);
+  for (int e = 0; e < E; ++e) src[e] = mirror ? k[E - 1 - e] : k[e];
+#if HGS_SORT_XCHG == 0
+  {
+    const int addr = (lane ^ lane_mask) << 2;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)src[e]);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(src[e] >> 32));
+      o[e] = ((u64)hi << 32) | lo;
+    }
+  }
+#else
+  switch (lane_mask) {                     // wave-uniform
+    case 1: xchg_all<E, 1>(src, o, lane); break;
+    case 2: xchg_all<E, 2>(src, o, lane); break;
+    case 3: xchg_all<E, 3>(src, o, lane); break;
+    case 4: xchg_all<E, 4>(src, o, lane); break;
+    case 7: xchg_all<E, 7>(src, o, lane); break;
+    case 8: xchg_all<E, 8>(src, o, lane); break;
+    case 15: xchg_all<E, 15>(src, o, lane); break;
+#if HGS_SORT_XCHG == 2
+    case 16: xchg_all<E, 16>(src, o, lane); break;
+    case 31: xchg_all<E, 31>(src, o, lane); break;
+    case 32: xchg_all<E, 32>(src, o, lane); break;
+    default: xchg_all<E, 63>(src, o, lane); break;
+#else
+    default: {                             // across 16-lane rows: one ds_bpermute pair per key
+      const int addr = (lane ^ lane_mask) << 2;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)src[e]);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(src[e] >> 32));
+        o[e] = ((u64)hi << 32) | lo;
+      }
+    }
+#endif
+  }
+#endif
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const u64 a = k[e], c = o[e];

@@ -293,11 +293,12 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
     if (chunk >= v.nblk) break;
     const int i = chunk * HGS_BLOCK + threadIdx.x;
     uint32_t tt = 0;
-    GeomRec rec;
     if (i < v.P) {
+      GeomRec rec;
       tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
                           cov3D_precomp, rec);
       radii[(size_t)b * v.P + i] = rec.radius;
+      store_geom(&L.geom[(size_t)b * v.P + i], rec);      // the record leaves the registers now ...
       if (tt) {
         const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;
         const int maxx = rec.rect_hi & 0xffffu, maxy = rec.rect_hi >> 16;
@@ -306,10 +307,7 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
       }
     }
     const uint32_t off = chunk_prefix(tt, wtot, &L.chunk_sums[(size_t)b * v.nblk + chunk]);
-    if (i < v.P) {
-      rec.offset = off;
-      store_geom(&L.geom[(size_t)b * v.P + i], rec);
-    }
+    if (i < v.P && tt) L.geom[(size_t)b * v.P + i].offset = off;      // ... its entry-id prefix follows
   }
   __syncthreads();
   uint32_t* row = L.hist + (size_t)blockIdx.x * v.T;
@@ -330,11 +328,12 @@ hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
   const Cam cam = v.cam[b];
   const int i = chunk * HGS_BLOCK + threadIdx.x;
   uint32_t tt = 0;
-  GeomRec rec;
   if (i < v.P) {
+    GeomRec rec;
     tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
                         cov3D_precomp, rec);
     radii[(size_t)b * v.P + i] = rec.radius;
+    store_geom(&L.geom[(size_t)b * v.P + i], rec);
     if (tt) {
       const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;
       const int maxx = rec.rect_hi & 0xffffu, maxy = rec.rect_hi >> 16;
@@ -344,10 +343,7 @@ hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
     }
   }
   const uint32_t off = chunk_prefix(tt, wtot, &L.chunk_sums[blockIdx.x]);
-  if (i < v.P) {
-    rec.offset = off;
-    store_geom(&L.geom[(size_t)b * v.P + i], rec);
-  }
+  if (i < v.P && tt) L.geom[(size_t)b * v.P + i].offset = off;
 }
 
 // ----------------------------------------------------------------------------- backward

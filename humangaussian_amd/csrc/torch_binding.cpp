@@ -490,6 +490,124 @@ Tensor reduce_view_packs(const Tensor& gathered) {
   return out;
 }
 
+// ---- bookkeeping either side of the path (include/hgs_rast.h: hgs_densify_*, hgs_compact_*, hgs_reanchor)
+void need_dev(const Tensor& t, const c10::Device& dev, at::ScalarType ty, const char* name) {
+  if (t.device() != dev || t.scalar_type() != ty || !t.is_contiguous())
+    throw std::runtime_error(std::string(name) + ": expected a contiguous tensor of the right dtype on " + dev.str());
+}
+
+// in-place update of xyz_gradient_accum / denom / max_radii2D; returns (radii_max int32 [P], visibility bool [P])
+std::vector<Tensor> densify_stats(const Tensor& grad_means2D, const Tensor& radii, const c10::optional<Tensor>& keep,
+                                  Tensor accum, Tensor denom, Tensor max_radii2D) {
+  at::NoGradGuard ng;
+  const c10::Device dev = radii.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  DeviceSwitch guard(dev.index());
+  const Tensor r = radii.dim() == 1 ? radii.unsqueeze(0) : radii;
+  const int64_t B = r.size(0), P = r.size(1);
+  const Tensor g = f32c(grad_means2D, dev, "viewspace gradient");
+  const Tensor rc = r.contiguous();
+  if (rc.scalar_type() != at::kInt) throw std::runtime_error("radii must be int32");
+  if (g.numel() != B * P * 3) throw std::runtime_error("viewspace gradient must have dimensions (views, num_points, 3)");
+  need_dev(accum, dev, at::kFloat, "xyz_gradient_accum");
+  need_dev(denom, dev, at::kFloat, "denom");
+  need_dev(max_radii2D, dev, at::kFloat, "max_radii2D");
+  if (accum.numel() != P || denom.numel() != P || max_radii2D.numel() != P)
+    throw std::runtime_error("xyz_gradient_accum / denom / max_radii2D must have num_points elements");
+  Tensor keep_u8;
+  if (keep.has_value() && keep->defined()) {
+    keep_u8 = keep->to(at::kByte).contiguous();
+    if (keep_u8.device() != dev || keep_u8.numel() != P) throw std::runtime_error("keep mask must have num_points elements on the device");
+  }
+  Tensor rmax = at::empty({P}, rc.options());
+  Tensor vis = at::empty({P}, rc.options().dtype(at::kByte));
+  const int rcode = hgs_densify_stats((int32_t)B, (int32_t)P, fptr(g), P > 0 ? rc.data_ptr<int32_t>() : nullptr,
+                                      keep_u8.defined() && P > 0 ? keep_u8.data_ptr<uint8_t>() : nullptr, fptr_mut(accum),
+                                      fptr_mut(denom), fptr_mut(max_radii2D), P > 0 ? rmax.data_ptr<int32_t>() : nullptr,
+                                      P > 0 ? vis.data_ptr<uint8_t>() : nullptr,
+                                      c10::hip::getCurrentHIPStream(dev.index()).stream());
+  check_rc(rcode, "hgs_densify_stats");
+  return {rmax, vis.to(at::kBool)};
+}
+
+// returns (clone bool [P], split bool [P], prune bool [P], counts int32 [3] on the device)
+std::vector<Tensor> densify_masks(const Tensor& accum, const Tensor& denom, const Tensor& scales, bool scales_are_log,
+                                  const Tensor& opacity, bool opacity_is_logit, const Tensor& max_radii2D,
+                                  double grad_threshold, double percent_dense, double extent, double min_opacity,
+                                  double max_screen_size, double size_thresh) {
+  at::NoGradGuard ng;
+  const c10::Device dev = accum.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  DeviceSwitch guard(dev.index());
+  const Tensor a = f32c(accum, dev, "xyz_gradient_accum"), d = f32c(denom, dev, "denom"), sc = f32c(scales, dev, "scales");
+  const Tensor op = f32c(opacity, dev, "opacity"), mr = f32c(max_radii2D, dev, "max_radii2D");
+  const int64_t P = a.numel();
+  if (d.numel() != P || sc.numel() != 3 * P || op.numel() != P || mr.numel() != P)
+    throw std::runtime_error("densify_masks: inconsistent shapes");
+  const auto bopt = at::TensorOptions().dtype(at::kByte).device(dev);
+  Tensor cl = at::empty({P}, bopt), sp = at::empty({P}, bopt), pr = at::empty({P}, bopt);
+  Tensor counts = at::empty({3}, bopt.dtype(at::kInt));
+  const int rc = hgs_densify_masks((int32_t)P, fptr(a), fptr(d), fptr(sc), scales_are_log ? 1 : 0, fptr(op),
+                                   opacity_is_logit ? 1 : 0, fptr(mr), (float)grad_threshold, (float)percent_dense,
+                                   (float)extent, (float)min_opacity, (float)max_screen_size, (float)size_thresh,
+                                   P > 0 ? cl.data_ptr<uint8_t>() : nullptr, P > 0 ? sp.data_ptr<uint8_t>() : nullptr,
+                                   P > 0 ? pr.data_ptr<uint8_t>() : nullptr,
+                                   reinterpret_cast<uint32_t*>(counts.data_ptr<int32_t>()),
+                                   c10::hip::getCurrentHIPStream(dev.index()).stream());
+  check_rc(rc, "hgs_densify_masks");
+  return {cl.to(at::kBool), sp.to(at::kBool), pr.to(at::kBool), counts};
+}
+
+// keeps the rows where keep[i] of every tensor in `tensors` (all [P, ...] fp32), order preserved: the
+// pruning of all parameters and of both Adam moments with ONE index computation (one D2H read: the count)
+std::vector<Tensor> compact_rows(const Tensor& keep, const std::vector<Tensor>& tensors) {
+  at::NoGradGuard ng;
+  const c10::Device dev = keep.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  DeviceSwitch guard(dev.index());
+  const Tensor k = keep.to(at::kByte).contiguous();
+  const int64_t P = k.numel();
+  hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+  Tensor idx = at::empty({P}, at::TensorOptions().dtype(at::kInt).device(dev));
+  Tensor cnt = at::empty({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+  Tensor scratch = at::empty({(int64_t)hgs_compact_scratch_bytes((int32_t)P)}, at::TensorOptions().dtype(at::kByte).device(dev));
+  check_rc(hgs_compact_index((int32_t)P, P > 0 ? k.data_ptr<uint8_t>() : nullptr, P > 0 ? idx.data_ptr<int32_t>() : nullptr,
+                             reinterpret_cast<uint32_t*>(cnt.data_ptr<int32_t>()), scratch.data_ptr(), stream),
+           "hgs_compact_index");
+  const int64_t n = cnt.item<int32_t>();
+  std::vector<Tensor> out;
+  for (const Tensor& t : tensors) {
+    if (t.size(0) != P) throw std::runtime_error("compact_rows: every tensor needs num_points rows");
+    const Tensor src = f32c(t, dev, "tensor");
+    const int64_t rf = P > 0 ? src.numel() / P : 1;
+    std::vector<int64_t> shape = src.sizes().vec();
+    shape[0] = n;
+    Tensor dst = at::empty(shape, src.options());
+    check_rc(hgs_gather_rows(n, (int32_t)std::max<int64_t>(rf, 1), n > 0 ? idx.data_ptr<int32_t>() : nullptr, fptr(src),
+                             fptr_mut(dst), stream), "hgs_gather_rows");
+    out.push_back(dst);
+  }
+  return out;
+}
+
+Tensor reanchor(const Tensor& vertices, const Tensor& faces, const Tensor& mapping_face, const Tensor& mapping_uvw,
+                const Tensor& mapping_dist) {
+  at::NoGradGuard ng;
+  const c10::Device dev = vertices.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  DeviceSwitch guard(dev.index());
+  const Tensor v = f32c(vertices, dev, "vertices"), uvw = f32c(mapping_uvw, dev, "mapping_uvw"), dist = f32c(mapping_dist, dev, "mapping_dist");
+  const Tensor f = faces.to(at::kInt).contiguous(), mf = mapping_face.to(at::kInt).contiguous();
+  if (f.device() != dev || mf.device() != dev) throw std::runtime_error("faces / mapping_face must live on the same device");
+  const int64_t P = mf.numel();
+  if (uvw.numel() != 3 * P || dist.numel() != P || v.numel() % 3 || f.numel() % 3) throw std::runtime_error("reanchor: inconsistent shapes");
+  Tensor xyz = at::empty({P, 3}, v.options());
+  check_rc(hgs_reanchor((int32_t)P, fptr(v), f.numel() ? f.data_ptr<int32_t>() : nullptr, P > 0 ? mf.data_ptr<int32_t>() : nullptr,
+                        fptr(uvw), fptr(dist), fptr_mut(xyz), c10::hip::getCurrentHIPStream(dev.index()).stream()),
+           "hgs_reanchor");
+  return xyz;
+}
+
 void set_stage_events(const c10::optional<std::vector<int64_t>>& fwd, const c10::optional<std::vector<int64_t>>& bwd) {
   g_stage_fwd.clear();
   g_stage_bwd.clear();
@@ -528,6 +646,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("knn_mean_dist2", &knn_mean_dist2, py::call_guard<py::gil_scoped_release>());
   m.def("reduce_view_packs", &reduce_view_packs, py::call_guard<py::gil_scoped_release>());
   m.def("pack_view_contribution", &pack_view_contribution, py::call_guard<py::gil_scoped_release>());
+  m.def("densify_stats", &densify_stats, py::call_guard<py::gil_scoped_release>());
+  m.def("densify_masks", &densify_masks, py::call_guard<py::gil_scoped_release>());
+  m.def("compact_rows", &compact_rows, py::call_guard<py::gil_scoped_release>());
+  m.def("reanchor", &reanchor, py::call_guard<py::gil_scoped_release>());
   m.def("set_stage_events", &set_stage_events);
   m.def("device_state", &device_state);
   m.def("abi_version", []() { return hgs_abi_version(); });

@@ -37,10 +37,14 @@ def save_ply(path, xyz, features_dc, features_rest, opacity, scaling, rotation):
         f.write(rows.astype("<f4").tobytes())
 
 
-def load_ply(path, max_sh_degree=None):
+def load_ply(path, max_sh_degree=None, kiui_axes=False):
     """Returns a dict of RAW parameter arrays shaped like the reference's nn.Parameters:
     xyz (P,3), features_dc (P,1,3), features_rest (P,M-1,3), opacity (P,1), scaling (P,3),
-    rotation (P,4), plus max_sh_degree."""
+    rotation (P,4), plus max_sh_degree.
+
+    kiui_axes=True applies the fix-ups of the animation-side loader
+    (/root/reference/gs_renderer.py:576-581): y and z of the positions and of the scales are
+    swapped, the quaternion's y and z components are swapped and its w is negated."""
     with open(path, "rb") as f:
         data = f.read()
     end = data.index(b"end_header\n") + len(b"end_header\n")
@@ -67,9 +71,15 @@ def load_ply(path, max_sh_degree=None):
     rot_names = sorted((n for n in names if n.startswith("rot")), key=lambda n: int(n.split("_")[-1]))
     f_dc = take(["f_dc_0", "f_dc_1", "f_dc_2"]).reshape(P, 3, 1).transpose(0, 2, 1)
     f_rest = (take(rest).reshape(P, 3, -1).transpose(0, 2, 1) if rest else np.zeros((P, 0, 3), np.float32))
-    return dict(xyz=take(["x", "y", "z"]), features_dc=np.ascontiguousarray(f_dc),
+    xyz, scaling, rotation = take(["x", "y", "z"]), take(scale_names), take(rot_names)
+    if kiui_axes:
+        xyz[:, [1, 2]] = xyz[:, [2, 1]]               # coordinate shift
+        scaling[:, [1, 2]] = scaling[:, [2, 1]]
+        rotation[:, [2, 3]] = rotation[:, [3, 2]]     # (w, x, y, z) -> (w, x, z, y) ...
+        rotation[:, [0]] *= -1                        # ... and the handedness flip
+    return dict(xyz=xyz, features_dc=np.ascontiguousarray(f_dc),
                 features_rest=np.ascontiguousarray(f_rest), opacity=take(["opacity"]),
-                scaling=take(scale_names), rotation=take(rot_names), max_sh_degree=deg)
+                scaling=scaling, rotation=rotation, max_sh_degree=deg)
 
 
 def math_sqrt(x):

@@ -56,18 +56,21 @@ def unpack_contribution(pack: torch.Tensor, shapes: Dict[str, torch.Size]):
     return out, radii
 
 
-def allgather_reduce(pack: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather every rank's pack, then reduce locally in rank order:
-    gradient columns are summed, the last column (radii) takes the max."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return pack
+def allgather(pack: torch.Tensor, group=None) -> torch.Tensor:
+    """THE collective of a step: every rank's (P, F) pack -> (world, P, F) on every rank."""
     world = dist.get_world_size(group)
     # flat (world*P, F) output: the concatenation form is accepted by both RCCL and gloo
     flat = torch.empty((world * pack.shape[0],) + tuple(pack.shape[1:]), dtype=pack.dtype,
                        device=pack.device)
     dist.all_gather_into_tensor(flat, pack, group=group)
-    gathered = flat.view((world,) + tuple(pack.shape))
-    if pack.is_cuda and pack.dim() == 2:
+    return flat.view((world,) + tuple(pack.shape))
+
+
+def reduce_gathered(gathered: torch.Tensor) -> torch.Tensor:
+    """Local reduction in rank order (bit-identical on every rank): gradient columns are summed,
+    the last column (radii) takes the max."""
+    world = gathered.shape[0]
+    if gathered.is_cuda and gathered.dim() == 3:
         # one HIP pass (rank-order sum, max on the radii column) instead of 2 (world - 1) strided
         # torch kernels launched from a Python loop
         from . import _lib
@@ -77,6 +80,13 @@ def allgather_reduce(pack: torch.Tensor, group=None) -> torch.Tensor:
         total[:, :-1] += gathered[r][:, :-1]
         total[:, -1] = torch.maximum(total[:, -1], gathered[r][:, -1])
     return total
+
+
+def allgather_reduce(pack: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather every rank's pack, then reduce locally in rank order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return pack
+    return reduce_gathered(allgather(pack, group))
 
 
 def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg: torch.Tensor,

@@ -202,6 +202,47 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
                                const float* g_sh, const float* g_opac, const float* g_scales,
                                const float* g_rot, const int32_t* radii, float* out, void* stream);
 
+/* ---- bookkeeping either side of the path ------------------------------
+ * Densification statistics of one training step over B views
+ * (/root/reference/threestudio/systems/GaussianDreamer.py:253-256,289,385-391 and
+ * gaussiansplatting/scene/gaussian_model.py:434-438), one pass:
+ *   radii_max = max_b radii[b];  visible = radii_max > 0 (&& keep[i] if keep != NULL);
+ *   g = sum_b dL_dmeans2D[b] (view order);  for visible Gaussians:
+ *   max_radii2D = max(max_radii2D, radii_max), xyz_gradient_accum += |g.xy|, denom += 1.
+ * dL_dmeans2D [B][P][3], radii [B][P]; accum / denom / max_radii2D [P] fp32 updated in place;
+ * radii_max [P] int32 and visibility [P] uint8 are optional outputs. */
+int hgs_densify_stats(int32_t B, int32_t P, const float* dL_dmeans2D, const int32_t* radii, const uint8_t* keep,
+                      float* xyz_gradient_accum, float* denom, float* max_radii2D, int32_t* radii_max,
+                      uint8_t* visibility, void* stream);
+
+/* Clone / split / prune masks (gaussian_model.py:359-438): grad = accum / denom (NaN -> 0),
+ * big = max scale > percent_dense * extent;  clone = grad >= thr && !big;  split = grad >= thr && big;
+ * prune = opacity < min_opacity || (max_screen_size > 0 && (max_radii2D > max_screen_size ||
+ * max scale > 0.1 * extent)) || (size_thresh > 0 && max scale > size_thresh)  [prune_only: size_thresh].
+ * scales [P][3] / opacity [P] may be the RAW parameters (log-scale / logit; flags) - the activations are
+ * fused.  Masks are uint8 [P] (any may be NULL); counts (3 x uint32, optional) receives the number of
+ * set clone / split / prune bits. */
+int hgs_densify_masks(int32_t P, const float* xyz_gradient_accum, const float* denom, const float* scales,
+                      int32_t scales_are_log, const float* opacity, int32_t opacity_is_logit,
+                      const float* max_radii2D, float grad_threshold, float percent_dense, float extent,
+                      float min_opacity, float max_screen_size, float size_thresh, uint8_t* clone_mask,
+                      uint8_t* split_mask, uint8_t* prune_mask, uint32_t* counts, void* stream);
+
+/* Stable compaction for the pruning of every parameter tensor and both Adam moments
+ * (gaussian_model.py:283-337): hgs_compact_index turns keep[P] into the list of kept source rows
+ * (order preserved) and their number; hgs_gather_rows then moves any [P][row_floats] fp32 tensor. */
+size_t hgs_compact_scratch_bytes(int32_t P);
+int hgs_compact_index(int32_t P, const uint8_t* keep, int32_t* src_of_dst, uint32_t* num_kept, void* scratch,
+                      void* stream);
+int hgs_gather_rows(int64_t n_out, int32_t row_floats, const int32_t* src_of_dst, const float* src, float* dst,
+                    void* stream);
+
+/* Re-anchoring of the Gaussians on a posed mesh (/root/reference/animation.py:384-403, a numpy pass on the
+ * CPU plus an H2D copy per frame there): xyz[i] = uvw[i] . (v0,v1,v2) + dist[i] * unit normal of face
+ * mapping_face[i].  vertices [V][3] fp32, faces [F][3] int32, mapping_* [P]. */
+int hgs_reanchor(int32_t P, const float* vertices, const int32_t* faces, const int32_t* mapping_face,
+                 const float* mapping_uvw, const float* mapping_dist, float* xyz, void* stream);
+
 /* Library / ABI version (bumped on any signature change). */
 int hgs_abi_version(void);
 

@@ -69,3 +69,29 @@ def test_renderer_python_sh_matches_reference_goldens():
     for deg in range(4):
         got = _eval_sh_python(deg, sh, d)
         assert np.abs(got.numpy() - ref[f"sh_eval_deg{deg}"]).max() < 2e-6, deg
+
+
+def test_load_ply_kiui_axes_fixups_match_gs_renderer(tmp_path):
+    """ply_io.load_ply(kiui_axes=True) == the fix-ups of the animation-side loader
+    (/root/reference/gs_renderer.py:576-581) applied to the plain load."""
+    import numpy as np
+    from humangaussian_amd import ply_io
+    rng = np.random.default_rng(4)
+    P = 50
+    xyz, dc, rest = rng.normal(size=(P, 3)), rng.normal(size=(P, 1, 3)), rng.normal(size=(P, 3, 3))
+    op, sc, rot = rng.normal(size=(P, 1)), rng.normal(size=(P, 3)), rng.normal(size=(P, 4))
+    path = tmp_path / "a.ply"
+    ply_io.save_ply(path, xyz, dc, rest, op, sc, rot)
+    plain = ply_io.load_ply(path)
+    fixed = ply_io.load_ply(path, kiui_axes=True)
+    # the reference's four lines, verbatim semantics
+    xyz_r, scales_r, rots_r = plain["xyz"].copy(), plain["scaling"].copy(), plain["rotation"].copy()
+    xyz_r[:, [1, 2]] = xyz_r[:, [2, 1]]
+    scales_r[:, [1, 2]] = scales_r[:, [2, 1]]
+    rots_r[:, [2, 3]] = rots_r[:, [3, 2]]
+    rots_r[:, [0]] *= -1
+    assert np.array_equal(fixed["xyz"], xyz_r) and np.array_equal(fixed["scaling"], scales_r)
+    assert np.array_equal(fixed["rotation"], rots_r)
+    for k in ("features_dc", "features_rest", "opacity"):
+        assert np.array_equal(fixed[k], plain[k])
+    assert not np.array_equal(fixed["xyz"], plain["xyz"])

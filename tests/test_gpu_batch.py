@@ -317,3 +317,56 @@ def test_raw_abi_batch_call_matches_raw_single_calls():
     arr[1].image_height = H + 16
     assert lib.hgs_forward_batch(arr, B, P, 4, _p(m3), _p(shs), None, _p(op), _p(scl), _p(rot), None, _p(color), _p(depth),
                                  _p(alpha), _p(radii), _p(geom), _p(binb), cap, _p(img), 1, 0, None, 0, None, None, sp) == -1
+
+
+def _rccl_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from humangaussian_amd import view_parallel as vp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        P, M = 3000, 4
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = {"means3D": torch.randn(P, 3, generator=g), "means2D": torch.randn(P, 3, generator=g),
+                 "shs": torch.randn(P, M, 3, generator=g), "opacities": torch.randn(P, 1, generator=g),
+                 "scales": torch.randn(P, 3, generator=g), "rotations": torch.randn(P, 4, generator=g)}
+        radii = torch.randint(0, 50, (P,), generator=g, dtype=torch.int32)
+        total = vp.allgather_reduce(vp.pack_contribution({k: v.to(dev) for k, v in grads.items()}, radii.to(dev)))
+        q.put((rank, total.cpu()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL over xGMI); the CPU suite covers gloo")
+def test_view_parallel_allgather_on_rccl_two_gpus():
+    """The HIP pack / reduce kernels around a real RCCL all-gather: every rank ends with the same bits
+    = the rank-ordered sum (and max of the radii column)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert torch.equal(res[0], res[1])
+    # rank-ordered reference on the CPU
+    from humangaussian_amd import view_parallel as vp
+    packs = []
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        P, M = 3000, 4
+        grads = {"means3D": torch.randn(P, 3, generator=g), "means2D": torch.randn(P, 3, generator=g),
+                 "shs": torch.randn(P, M, 3, generator=g), "opacities": torch.randn(P, 1, generator=g),
+                 "scales": torch.randn(P, 3, generator=g), "rotations": torch.randn(P, 4, generator=g)}
+        radii = torch.randint(0, 50, (P,), generator=g, dtype=torch.int32)
+        packs.append(vp.pack_contribution(grads, radii))
+    assert torch.equal(res[0], vp.reduce_gathered(torch.stack(packs)))
