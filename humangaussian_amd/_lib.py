@@ -58,6 +58,12 @@ EXPORTS = {
     "hgs_backward_batch": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 8
                            + [c_void_p] * 6 + [c_void_p] * 3 + [POINTER(HgsStatus), c_int64, c_void_p]
                            + [c_void_p] * 8 + [c_void_p, c_void_p]),
+    "hgs_forward_batch_act": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 7
+                              + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
+                                                  c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hgs_backward_batch_act": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 8
+                               + [c_void_p] * 6 + [c_void_p] * 3 + [POINTER(HgsStatus), c_int64, c_void_p]
+                               + [c_void_p] * 8 + [c_void_p, c_int32, c_void_p]),
     "hgs_forward": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32] + [c_void_p] * 7
                     + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
                                         c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),

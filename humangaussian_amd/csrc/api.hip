@@ -129,8 +129,9 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   return L;
 }
 
-View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_tile_hint = 0) {
+View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_tile_hint = 0, int act = 0) {
   View v;
+  v.act = act;
   for (int b = 0; b < HGS_MAX_VIEWS; ++b) {
     const hgs_settings& sb = s[b < B ? b : 0];
     Cam& c = v.cam[b];
@@ -263,14 +264,15 @@ size_t hgs_bwd_scratch_bytes(int64_t R) {
   return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_ROW_FLOATS * sizeof(float), ALIGN);
 }
 
-int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
-                      const float* shs, const float* colors_precomp, const float* opacities,
-                      const float* scales, const float* rotations, const float* cov3D_precomp,
-                      float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
-                      void* geom, void* bin, int64_t entry_capacity, void* img,
-                      int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
-                      int32_t status_host_mapped, void* status_event, void* const* stage_events,
-                      void* stream_) {
+int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                          const float* shs, const float* colors_precomp, const float* opacities,
+                          const float* scales, const float* rotations, const float* cov3D_precomp,
+                          float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                          void* geom, void* bin, int64_t entry_capacity, void* img,
+                          int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
+                          int32_t status_host_mapped, void* status_event, void* const* stage_events,
+                          int32_t activation_flags, void* stream_) {
+  if (activation_flags & ~7) return HGS_EINVAL;
   if (!batch_ok(s, B) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
     return HGS_EINVAL;
@@ -285,7 +287,8 @@ int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, co
     if ((int64_t)B * P >= (1ll << 31) || P >= (1 << 28)) return HGS_EINVAL;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const View v = make_view(s, B, P, M, entry_capacity, max_tile_entries_hint > 0 ? max_tile_entries_hint : 0);
+  const View v = make_view(s, B, P, M, entry_capacity, max_tile_entries_hint > 0 ? max_tile_entries_hint : 0,
+                           activation_flags);
   const Layout L = make_layout(geom, bin, img, B, P, v.H, v.W, entry_capacity);
   hgs_status* status_dev =
       reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(B, P, v.H, v.W).status);
@@ -393,6 +396,20 @@ int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, co
   return HGS_OK;
 }
 
+int hgs_forward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                      const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, const float* rotations, const float* cov3D_precomp,
+                      float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                      void* geom, void* bin, int64_t entry_capacity, void* img,
+                      int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
+                      int32_t status_host_mapped, void* status_event, void* const* stage_events,
+                      void* stream_) {
+  return hgs_forward_batch_act(s, B, P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                               out_color, out_depth, out_alpha, radii, geom, bin, entry_capacity, img, store_bwd_state,
+                               max_tile_entries_hint, status_host, status_host_mapped, status_event, stage_events, 0,
+                               stream_);
+}
+
 int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3D,
                 const float* shs, const float* colors_precomp, const float* opacities,
                 const float* scales, const float* rotations, const float* cov3D_precomp,
@@ -407,18 +424,20 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                            status_event, stage_events, stream_);
 }
 
-int hgs_backward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
-                       const float* shs, const float* colors_precomp, const float* opacities,
-                       const float* scales, const float* rotations, const float* cov3D_precomp,
-                       const int32_t* radii, const float* out_color, const float* out_depth,
-                       const float* out_alpha, const float* dL_dout_color,
-                       const float* dL_dout_depth, const float* dL_dout_alpha, const void* geom,
-                       const void* bin, const void* img, const hgs_status* status,
-                       int64_t entry_capacity, void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
-                       float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
-                       float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
-                       void* stream_) {
-  (void)opacities; (void)radii;
+int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                           const float* shs, const float* colors_precomp, const float* opacities,
+                           const float* scales, const float* rotations, const float* cov3D_precomp,
+                           const int32_t* radii, const float* out_color, const float* out_depth,
+                           const float* out_alpha, const float* dL_dout_color,
+                           const float* dL_dout_depth, const float* dL_dout_alpha, const void* geom,
+                           const void* bin, const void* img, const hgs_status* status,
+                           int64_t entry_capacity, void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                           float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                           float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
+                           int32_t activation_flags, void* stream_) {
+  (void)radii;
+  if (activation_flags & ~7) return HGS_EINVAL;
+  if ((activation_flags & HGS_ACT_OPACITY_SIGMOID) && P > 0 && !opacities) return HGS_EINVAL;
   if (!batch_ok(s, B) || P < 0 || !geom || !img || entry_capacity < 0) return HGS_EINVAL;
   if (status && status->overflow) return HGS_EINVAL;
   if (status && (int64_t)status->reserved[0] != entry_capacity) return HGS_EINVAL;
@@ -432,7 +451,7 @@ int hgs_backward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, c
   if (maybe_entries && (!bin || !bwd_scratch)) return HGS_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int64_t cap = entry_capacity;
-  const View v = make_view(s, B, P, M, cap);
+  const View v = make_view(s, B, P, M, cap, 0, activation_flags);
   const Layout L = make_layout(const_cast<void*>(geom), const_cast<void*>(bin),
                                const_cast<void*>(img), B, P, v.H, v.W, cap);
   const hgs_status* status_dev = reinterpret_cast<const hgs_status*>(
@@ -455,7 +474,7 @@ int hgs_backward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, c
   HGS_STAGE(1);
 #define HGS_LAUNCH_PRE_BWD(K)                                                                         \
   hipLaunchKernelGGL(K, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, status_dev, rows, means3D, shs, \
-                     colors_precomp, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D,       \
+                     colors_precomp, opacities, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, \
                      dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,            \
                      dL_dcov3D_precomp)
   switch (shs ? v.D : 0) {
@@ -468,6 +487,24 @@ int hgs_backward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, c
   HGS_LAUNCH_CHECK();
   HGS_STAGE(2);
   return HGS_OK;
+}
+
+int hgs_backward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                       const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* scales, const float* rotations, const float* cov3D_precomp,
+                       const int32_t* radii, const float* out_color, const float* out_depth,
+                       const float* out_alpha, const float* dL_dout_color,
+                       const float* dL_dout_depth, const float* dL_dout_alpha, const void* geom,
+                       const void* bin, const void* img, const hgs_status* status,
+                       int64_t entry_capacity, void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                       float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                       float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
+                       void* stream_) {
+  return hgs_backward_batch_act(s, B, P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                radii, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha,
+                                geom, bin, img, status, entry_capacity, bwd_scratch, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                                dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D_precomp,
+                                stage_events, 0, stream_);
 }
 
 int hgs_backward(const hgs_settings* s, int32_t P, int32_t M, const float* means3D,

@@ -141,6 +141,7 @@ struct View {            // per-call constants, passed by value to every kernel
   int32_t max_tile_hint;             // >0: caller promises no tile list is longer (else overflow bit 2)
   int32_t seg_off;                   // 1: the caller's hint proves no list exceeds HGS_SEG_THRESH
   int32_t seg_recompute;             // 1: the hint proves lists have <= 12 segments: no segT pre-pass
+  int32_t act;                       // HGS_ACT_* bits: inputs are RAW parameters, activations fused into preprocess
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

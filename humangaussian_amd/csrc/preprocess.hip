@@ -34,14 +34,35 @@ struct RotScale {
   float sx, sy, sz;
 };
 
+// fused activations (HGS_ACT_*): what GaussianModel.get_opacity / get_scaling / get_rotation compute
+__device__ __forceinline__ float act_opacity(float raw, int act) {
+  return (act & HGS_ACT_OPACITY_SIGMOID) ? 1.0f / (1.0f + expf(-raw)) : raw;
+}
+__device__ __forceinline__ void act_scale(const float* __restrict__ scales, int i, int act, float& s0, float& s1, float& s2) {
+  s0 = scales[3 * i + 0]; s1 = scales[3 * i + 1]; s2 = scales[3 * i + 2];
+  if (act & HGS_ACT_SCALE_EXP) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
+}
+// returns the quaternion the kernels use and, for the backward, 1 / max(|q_raw|, 1e-12) (F.normalize)
+__device__ __forceinline__ float4 act_rotation(const float* __restrict__ rots, int i, int act, float& inv_norm) {
+  float4 q = reinterpret_cast<const float4*>(rots)[i];
+  inv_norm = 1.0f;
+  if (act & HGS_ACT_ROTATION_NORMALIZE) {
+    inv_norm = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    q.x *= inv_norm; q.y *= inv_norm; q.z *= inv_norm; q.w *= inv_norm;
+  }
+  return q;
+}
+
 __device__ __forceinline__ RotScale make_rotscale(const float* __restrict__ scales,
                                                   const float* __restrict__ rots, int i,
-                                                  float mod) {
+                                                  float mod, int act) {
   RotScale o;
-  o.sx = mod * scales[3 * i + 0];
-  o.sy = mod * scales[3 * i + 1];
-  o.sz = mod * scales[3 * i + 2];
-  const float4 q = reinterpret_cast<const float4*>(rots)[i];
+  float s0, s1, s2, inv_norm;
+  act_scale(scales, i, act, s0, s1, s2);
+  o.sx = mod * s0;
+  o.sy = mod * s1;
+  o.sz = mod * s2;
+  const float4 q = act_rotation(rots, i, act, inv_norm);
   const float r = q.x, x = q.y, y = q.z, z = q.w;
   o.R00 = 1.0f - 2.0f * (y * y + z * z);
   o.R01 = 2.0f * (x * y - r * z);
@@ -193,7 +214,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float* c = cov3D_precomp + 6 * (size_t)i;
     s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
   } else {
-    s = cov3d_from(make_rotscale(scales, rotations, i, v.scale_modifier));
+    s = cov3d_from(make_rotscale(scales, rotations, i, v.scale_modifier, v.act));
   }
   project_cov(cam, V, s, pj);
   if (pj.det == 0.0f) return 0;
@@ -213,7 +234,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
   if (area <= 0) return 0;
   rec.mx = mx; rec.my = my;
   rec.ca = pj.c * det_inv; rec.cb = -pj.b * det_inv; rec.cc = pj.a * det_inv;
-  rec.op = opacities[i];
+  rec.op = act_opacity(opacities[i], v.act);
   rec.depth = pj.tz;
   rec.rect_lo = (uint32_t)rminx | ((uint32_t)rminy << 16);
   rec.rect_hi = (uint32_t)rmaxx | ((uint32_t)rmaxy << 16);
@@ -360,6 +381,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const View& v, const Layout& L, const hgs_status* __restrict__ status,
     const float* __restrict__ grad_rows, const float* __restrict__ means3D,
     const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ opacities_raw,
     const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
@@ -375,13 +397,14 @@ __device__ __forceinline__ void preprocess_bwd_body(
   Cov3 s;
   RotScale rs;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  float q_inv_norm = 1.0f;
   if (cov3D_precomp) {
     const float* c = cov3D_precomp + 6 * (size_t)i;
     s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
   } else {
-    rs = make_rotscale(scales, rotations, i, v.scale_modifier);
+    rs = make_rotscale(scales, rotations, i, v.scale_modifier, v.act);
     s = cov3d_from(rs);
-    q = reinterpret_cast<const float4*>(rotations)[i];
+    q = act_rotation(rotations, i, v.act, q_inv_norm);
   }
   const bool want_sh = dL_dshs != nullptr && shs != nullptr;
   float sh48[48];
@@ -628,11 +651,34 @@ __device__ __forceinline__ void preprocess_bwd_body(
   if (dL_dcolors) {
     dL_dcolors[3 * i + 0] = a_col[0]; dL_dcolors[3 * i + 1] = a_col[1]; dL_dcolors[3 * i + 2] = a_col[2];
   }
-  if (dL_dopac) dL_dopac[i] = a_op;
+  // fused activations: chain rule on the view-summed gradients (sigmoid' = y (1 - y) with y as the
+  // forward stored it in geom.op is not needed: recompute from the raw input, like autograd does)
+  if (dL_dopac) {
+    float g = a_op;
+    if (v.act & HGS_ACT_OPACITY_SIGMOID) {
+      const float y = act_opacity(opacities_raw[i], v.act);
+      g = g * ((1.0f - y) * y);
+    }
+    dL_dopac[i] = g;
+  }
   if (dL_dscales) {
+    if (v.act & HGS_ACT_SCALE_EXP) {       // d exp(x) = exp(x) = the activated scale (= rs.s / scale_modifier's input)
+      float s0, s1, s2;
+      act_scale(scales, i, v.act, s0, s1, s2);
+      a_sc[0] *= s0; a_sc[1] *= s1; a_sc[2] *= s2;
+    }
     dL_dscales[3 * i + 0] = a_sc[0]; dL_dscales[3 * i + 1] = a_sc[1]; dL_dscales[3 * i + 2] = a_sc[2];
   }
-  if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(a_rot[0], a_rot[1], a_rot[2], a_rot[3]);
+  if (dL_drots) {
+    if (v.act & HGS_ACT_ROTATION_NORMALIZE) {   // d normalize: (g - q_hat (q_hat . g)) / |q|
+      const float dot = q.x * a_rot[0] + q.y * a_rot[1] + q.z * a_rot[2] + q.w * a_rot[3];
+      a_rot[0] = (a_rot[0] - q.x * dot) * q_inv_norm;
+      a_rot[1] = (a_rot[1] - q.y * dot) * q_inv_norm;
+      a_rot[2] = (a_rot[2] - q.z * dot) * q_inv_norm;
+      a_rot[3] = (a_rot[3] - q.w * dot) * q_inv_norm;
+    }
+    reinterpret_cast<float4*>(dL_drots)[i] = make_float4(a_rot[0], a_rot[1], a_rot[2], a_rot[3]);
+  }
   if (dL_dcov3D) {
     float* o = dL_dcov3D + 6 * (size_t)i;
 #pragma unroll
@@ -646,12 +692,13 @@ __device__ __forceinline__ void preprocess_bwd_body(
   extern "C" __global__ void __launch_bounds__(HGS_BLOCK) hgs_k_preprocess_bwd_d##DEG(             \
       View v, Layout L, const hgs_status* __restrict__ status, const float* __restrict__ grad_rows, \
       const float* __restrict__ means3D, const float* __restrict__ shs,                             \
-      const float* __restrict__ colors_precomp, const float* __restrict__ scales,                   \
+      const float* __restrict__ colors_precomp, const float* __restrict__ opacities_raw,            \
+      const float* __restrict__ scales,                                                             \
       const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,                 \
       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, \
       float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,  \
       float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {                                \
-    preprocess_bwd_body<DEG>(v, L, status, grad_rows, means3D, shs, colors_precomp, scales,         \
+    preprocess_bwd_body<DEG>(v, L, status, grad_rows, means3D, shs, colors_precomp, opacities_raw, scales, \
                              rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, dL_dshs,           \
                              dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D);                \
   }

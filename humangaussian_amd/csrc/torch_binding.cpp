@@ -166,22 +166,23 @@ struct BwdPlan : torch::CustomClassHolder {
   char *geom = nullptr, *bin = nullptr, *img = nullptr, *rows = nullptr;
   int64_t cap = 0;
   hgs_status status{};
-  int32_t B = 1, P = 0, M = 0;
+  int32_t B = 1, P = 0, M = 0, act = 0;
   bool batched = false;
   bool has_sh = false, has_cp = false, has_sr = false, has_cv = false;
   std::vector<int64_t> opac_sizes;
 };
 
 struct Rasterize : public torch::autograd::Function<Rasterize> {
-  // 21 arguments after ctx (backward returns one slot per argument).  `tanfov` is a CPU double
-  // tensor [2][B] (x row, y row); `batch` = 0 for the single-view API, else the number of views.
+  // 22 arguments after ctx (backward returns one slot per argument).  `tanfov` is a CPU double
+  // tensor [2][B] (x row, y row); `batch` = 0 for the single-view API, else the number of views;
+  // `act` = HGS_ACT_* bits (raw parameters in, activations fused into the per-Gaussian kernels).
   static variable_list forward(AutogradContext* ctx, const Tensor& means3D, const Tensor& means2D,
                                const Tensor& sh, const Tensor& colors_precomp, const Tensor& opacities,
                                const Tensor& scales, const Tensor& rotations, const Tensor& cov3D,
                                const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
                                const Tensor& campos, const Tensor& tanfov, int64_t H, int64_t W,
                                double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
-                               bool want_grad, int64_t batch) {
+                               bool want_grad, int64_t batch, int64_t act) {
     (void)means2D;
     const c10::Device dev = means3D.device();
     if (!dev.is_cuda())
@@ -255,11 +256,12 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     for (; attempt < 4; ++attempt) {
       const int slot = st.ring_pos;
       st.ring_pos = (st.ring_pos + 1) % RING;
-      const int rc = hgs_forward_batch(plan->settings.s.data(), (int32_t)B, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_),
-                                       fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth),
-                                       fptr_mut(alpha), P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom, plan->bin,
-                                       cap, plan->img, want_grad ? 1 : 0, hint, &st.ring[slot], /*mapped=*/1,
-                                       st.status_event, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(), stream);
+      const int rc = hgs_forward_batch_act(plan->settings.s.data(), (int32_t)B, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_),
+                                           fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth),
+                                           fptr_mut(alpha), P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom,
+                                           plan->bin, cap, plan->img, want_grad ? 1 : 0, hint, &st.ring[slot], /*mapped=*/1,
+                                           st.status_event, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(),
+                                           (int32_t)act, stream);
       check_rc(rc, "hgs_forward_batch");
       // `debug=True` is upstream's switch for surfacing device errors at the call that caused
       // them (std::runtime_error): synchronise and report
@@ -304,6 +306,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       plan->P = (int32_t)P;
       plan->M = M;
       plan->batched = batched;
+      plan->act = (int32_t)act;
       plan->has_sh = has_sh; plan->has_cp = has_cp; plan->has_sr = has_sc; plan->has_cv = has_cv;
       plan->opac_sizes = opacities.sizes().vec();
       ctx->saved_data["plan"] = c10::IValue::make_capsule(plan);
@@ -350,15 +353,15 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     if (plan->has_sr) { d_sc = at::empty({P, 3}, fopt); d_ro = at::empty({P, 4}, fopt); }
     if (plan->has_cv) d_cv = at::empty({P, 6}, fopt);
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-    const int rc = hgs_backward_batch(
+    const int rc = hgs_backward_batch_act(
         plan->settings.s.data(), plan->B, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_), fptr(ro_),
         fptr(cv_), plan->P > 0 ? radii.data_ptr<int32_t>() : nullptr, fptr(color), fptr(depth), fptr(alpha), fptr(gc),
         fptr(gd), fptr(ga), plan->geom, plan->bin, plan->img, &plan->status, plan->cap, plan->rows, fptr_mut(d_means3D),
         fptr_mut(d_means2D), fptr_mut(d_sh), fptr_mut(d_cp), fptr_mut(d_opac), fptr_mut(d_sc), fptr_mut(d_ro),
-        fptr_mut(d_cv), g_stage_bwd.empty() ? nullptr : g_stage_bwd.data(), stream);
+        fptr_mut(d_cv), g_stage_bwd.empty() ? nullptr : g_stage_bwd.data(), plan->act, stream);
     check_rc(rc, "hgs_backward_batch");
     if (plan->settings.s[0].debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer backward (debug=True)");
-    variable_list out(21);
+    variable_list out(22);
     out[0] = d_means3D; out[1] = d_means2D; out[2] = d_sh; out[3] = d_cp;
     out[4] = d_opac; out[5] = d_sc; out[6] = d_ro; out[7] = d_cv;
     return out;
@@ -390,7 +393,7 @@ std::vector<Tensor> rasterize(const Tensor& means3D, const Tensor& means2D, cons
                               bool want_grad) {
   return Rasterize::apply(means3D, means2D, opt(sh), opt(colors_precomp), opacities, opt(scales), opt(rotations),
                           opt(cov3D), bg, viewmatrix, projmatrix, campos, tanfov_tensor({tanfovx}, {tanfovy}), H, W,
-                          scale_modifier, sh_degree, prefiltered, debug, want_grad, (int64_t)0);
+                          scale_modifier, sh_degree, prefiltered, debug, want_grad, (int64_t)0, (int64_t)0);
 }
 
 // B views in one launch set: bg (3) or (B,3), viewmatrix / projmatrix (B,4,4), campos (B,3), means2D (B,P,3);
@@ -402,13 +405,13 @@ std::vector<Tensor> rasterize_batch(const Tensor& means3D, const Tensor& means2D
                                     const Tensor& projmatrix, const Tensor& campos, int64_t H, int64_t W,
                                     const std::vector<double>& tanfovx, const std::vector<double>& tanfovy,
                                     double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
-                                    bool want_grad) {
+                                    bool want_grad, int64_t activation_flags) {
   const int64_t B = (int64_t)tanfovx.size();
   if (means2D.defined() && means2D.numel() > 0 && means2D.numel() != B * means3D.size(0) * 3)
     throw std::runtime_error("means2D must have dimensions (views, num_points, 3) for a batched call");
   return Rasterize::apply(means3D, means2D, opt(sh), opt(colors_precomp), opacities, opt(scales), opt(rotations),
                           opt(cov3D), bg, viewmatrix, projmatrix, campos, tanfov_tensor(tanfovx, tanfovy), H, W,
-                          scale_modifier, sh_degree, prefiltered, debug, want_grad, B);
+                          scale_modifier, sh_degree, prefiltered, debug, want_grad, B, activation_flags);
 }
 
 Tensor mark_visible(const Tensor& positions, const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,

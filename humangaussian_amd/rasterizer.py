@@ -86,8 +86,11 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     return color, radii, depth, alpha
 
 
+ACT_OPACITY_SIGMOID, ACT_SCALE_EXP, ACT_ROTATION_NORMALIZE = 1, 2, 4      # HGS_ACT_* of include/hgs_rast.h
+
+
 def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                              cov3Ds_precomp, raster_settings_list):
+                              cov3Ds_precomp, raster_settings_list, activation_flags: int = 0):
     """B views of the same Gaussians in ONE launch set (include/hgs_rast.h: hgs_forward_batch /
     hgs_backward_batch) - what the reference does with a Python loop over
     `render()` at threestudio/systems/GaussianDreamer.py:244-266.
@@ -96,6 +99,10 @@ def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, s
                           sh_degree and scale_modifier (cameras, fov and bg may differ)
     means2D               (B, P, 3) zeros whose .grad receives the per-view screen-space gradient
                           (may be None under no_grad)
+    activation_flags      ACT_* bits: `opacities` / `scales` / `rotations` are the model's RAW parameters
+                          (`_opacity` logits, `_scaling` log-scales, un-normalised `_rotation`) and
+                          sigmoid / exp / normalize (scene/gaussian_model.py:95-115) run inside the
+                          per-Gaussian kernels, forward and backward; gradients are w.r.t. the raw tensors
     Returns color (B,3,H,W), radii (B,P) int32, depth (B,1,H,W), alpha (B,1,H,W); every view is
     bit-identical to a separate single-view call, parameter gradients are the sum over the views."""
     rsl = list(raster_settings_list)
@@ -121,7 +128,7 @@ def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, s
         means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, bg, vm, pm, cp,
         int(r0.image_height), int(r0.image_width), [float(rs.tanfovx) for rs in rsl],
         [float(rs.tanfovy) for rs in rsl], float(r0.scale_modifier), int(r0.sh_degree),
-        bool(r0.prefiltered), any(bool(rs.debug) for rs in rsl), want_grad)
+        bool(r0.prefiltered), any(bool(rs.debug) for rs in rsl), want_grad, int(activation_flags))
 
 
 class _RasterizeGaussians:

@@ -151,6 +151,40 @@ int hgs_backward_batch(const hgs_settings* views, int32_t B, int32_t P, int32_t 
                        float* dL_drotations, float* dL_dcov3D_precomp,
                        void* const* stage_events, void* stream);
 
+/* ---- fused activations -----------------------------------------------------
+ * The reference feeds the rasterizer `get_opacity` = sigmoid(_opacity), `get_scaling` = exp(_scaling),
+ * `get_rotation` = normalize(_rotation) (gaussiansplatting/scene/gaussian_model.py:95-115): three
+ * elementwise kernels forward and three backward per render call.  With the *_act entry points the
+ * caller hands over the RAW parameters and the activation runs inside the per-Gaussian kernels
+ * (forward: as the value is loaded; backward: chain rule applied to the summed gradient, so
+ * dL_dopacities / dL_dscales / dL_drotations are gradients w.r.t. the raw parameters).
+ * activation_flags: any combination of the bits below; 0 = identical to the plain entry points. */
+#define HGS_ACT_OPACITY_SIGMOID 1    /* opacities are logits                                  */
+#define HGS_ACT_SCALE_EXP 2          /* scales are log-scales                                 */
+#define HGS_ACT_ROTATION_NORMALIZE 4 /* rotations are un-normalised quaternions (w,x,y,z)      */
+int hgs_forward_batch_act(const hgs_settings* views, int32_t B, int32_t P, int32_t M,
+                          const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* opacities, const float* scales, const float* rotations,
+                          const float* cov3D_precomp,
+                          float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                          void* geom, void* bin, int64_t entry_capacity, void* img,
+                          int32_t store_bwd_state, int32_t max_tile_entries_hint,
+                          hgs_status* status_host, int32_t status_host_mapped, void* status_event,
+                          void* const* stage_events, int32_t activation_flags, void* stream);
+int hgs_backward_batch_act(const hgs_settings* views, int32_t B, int32_t P, int32_t M,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp, const int32_t* radii,
+                           const float* out_color, const float* out_depth, const float* out_alpha,
+                           const float* dL_dout_color, const float* dL_dout_depth,
+                           const float* dL_dout_alpha,
+                           const void* geom, const void* bin, const void* img,
+                           const hgs_status* status, int64_t entry_capacity, void* bwd_scratch,
+                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                           float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                           float* dL_drotations, float* dL_dcov3D_precomp,
+                           void* const* stage_events, int32_t activation_flags, void* stream);
+
 /* ---- backward: replaces _C.rasterize_gaussians_backward ----------------------------
  * `status` is a HOST copy of what hgs_forward reported (read after the stream has passed
  * the forward), or NULL: then nothing about the forward's result is needed on the host -

@@ -370,3 +370,28 @@ def test_view_parallel_allgather_on_rccl_two_gpus():
         radii = torch.randint(0, 50, (P,), generator=g, dtype=torch.int32)
         packs.append(vp.pack_contribution(grads, radii))
     assert torch.equal(res[0], vp.reduce_gathered(torch.stack(packs)))
+
+
+def test_fused_activations_match_the_unfused_path_forward_and_backward():
+    """render_views(fuse_activations=True): sigmoid / exp / normalize of GaussianModel.get_* run inside the
+    per-Gaussian kernels; outputs and the gradients w.r.t. the RAW parameters agree with the torch-activation
+    path to rounding."""
+    from test_gpu_api_contract import FakeCamera, FakeGaussianModel, Pipe
+    B, P, H, W = 3, 1500, 64, 72
+    sc = make_scene(P=P, sh_degree=1, seed=61, H=H, W=W, spread=0.3)
+    cams = [FakeCamera(c) for c in _cams(B, H, W, seed=13)]
+    bg = sc["bg"].to(DEV)
+    g = torch.Generator().manual_seed(4)
+    wc, wd, wa = (torch.randn(s, generator=g).to(DEV) for s in ((B, 3, H, W), (B, 1, H, W), (B, 1, H, W)))
+    res = []
+    for fuse in (False, True):
+        pc = FakeGaussianModel(sc, 1)
+        out = render_views(cams, pc, Pipe(), bg, fuse_activations=fuse)
+        ((out["render"] * wc).sum() + (out["depth_3dgs"] * wd).sum() + (out["alpha_3dgs"] * wa).sum()).backward()
+        res.append((out, [p.grad.clone() for p in pc.params()], out["viewspace_points"].grad.clone()))
+    (o0, g0, v0), (o1, g1, v1) = res
+    assert torch.equal(o0["radii"], o1["radii"])
+    for k in ("render", "depth_3dgs", "alpha_3dgs"):
+        assert float((o0[k] - o1[k]).abs().max()) <= 2e-6 * max(1.0, float(o0[k].abs().max())), k
+    for a, b in zip(g0 + [v0], g1 + [v1]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-12)
