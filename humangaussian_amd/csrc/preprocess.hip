@@ -688,8 +688,13 @@ __device__ __forceinline__ void preprocess_bwd_body(
 
 }  // namespace
 
+#ifdef HGS_PRE_BWD_WAVES_PER_EU
+#define HGS_PRE_BWD_OCC __attribute__((amdgpu_waves_per_eu(HGS_PRE_BWD_WAVES_PER_EU, HGS_PRE_BWD_WAVES_PER_EU)))
+#else
+#define HGS_PRE_BWD_OCC
+#endif
 #define HGS_PRE_BWD_KERNEL(DEG)                                                                     \
-  extern "C" __global__ void __launch_bounds__(HGS_BLOCK) hgs_k_preprocess_bwd_d##DEG(             \
+  extern "C" __global__ void __launch_bounds__(HGS_BLOCK) HGS_PRE_BWD_OCC hgs_k_preprocess_bwd_d##DEG( \
       View v, Layout L, const hgs_status* __restrict__ status, const float* __restrict__ grad_rows, \
       const float* __restrict__ means3D, const float* __restrict__ shs,                             \
       const float* __restrict__ colors_precomp, const float* __restrict__ opacities_raw,            \

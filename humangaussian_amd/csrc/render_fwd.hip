@@ -35,7 +35,8 @@
 #include "hgs_common.h"
 
 #ifndef HGS_FWD_UNROLL
-#define HGS_FWD_UNROLL 4      // compacted records per unrolled group (pad records >= this)
+#define HGS_FWD_UNROLL 2      // compacted records per unrolled group (pad records >= this).  2: 64 VGPRs = 8 waves/SIMD;
+                              // 4: 88 VGPRs = 5 waves/SIMD.  Same single-view time, 14 % faster with 8 views in flight
 #endif
 
 namespace {

@@ -4,7 +4,7 @@ wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibra
 sit at the L2's fabric side, so Infinity-Cache hits are included: an upper bound on DRAM traffic."""
 import collections, csv, json, sys
 
-STAGE = [("hgs_k_preprocess_fwd", "preprocess_fwd"), ("hgs_k_colscan", "scan"), ("hgs_k_scan", "scan"),
+STAGE = [("hgs_k_preprocess_fwd", "preprocess_fwd"), ("hgs_k_tiles", "tiles"),
          ("hgs_k_fill", "fill"), ("hgs_k_sort", "sort"), ("hgs_k_fwd_segT", "render_fwd"),
          ("hgs_k_render_fwd", "render_fwd"), ("hgs_k_fwd_combine", "render_fwd"),
          ("hgs_k_render_bwd", "render_bwd"), ("hgs_k_preprocess_bwd", "preprocess_bwd")]
