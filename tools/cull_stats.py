@@ -10,7 +10,7 @@ from humangaussian_amd import synth
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 deg = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 cloud = synth.init_cloud(P, deg, "mid", seed=0)
-cam = bench.camera_for_rank(0)
+cam = synth.orbit_camera(10.0, 30.0, 1.75, 55.0, 1024, 1024)
 st = oracle.OracleSettings(1024, 1024, math.tan(cam.FoVx * .5), math.tan(cam.FoVy * .5), torch.zeros(3), 1.0,
                            cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center, False, False)
 with torch.no_grad():
