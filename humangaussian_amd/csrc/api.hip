@@ -23,6 +23,9 @@ extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, con
 
 namespace {
 
+#ifndef HGS_SORT_256_MIN_VIEWS
+#define HGS_SORT_256_MIN_VIEWS 3   // calls with at least this many views sort with 256-thread workgroups (binning.hip)
+#endif
 #ifndef HGS_SEG_RECOMPUTE_MAX
 #define HGS_SEG_RECOMPUTE_MAX 12   // longest list (in segments) for which segments recompute their predecessors' products
 #endif
@@ -361,7 +364,10 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
       hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
       HGS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(hgs_k_sort_lds, dim3(class_grid(1)), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
+    if (v.B >= HGS_SORT_256_MIN_VIEWS)
+      hipLaunchKernelGGL(hgs_k_sort_lds_256, dim3(class_grid(1)), dim3(256), 0, stream, v, L, status_dev);
+    else
+      hipLaunchKernelGGL(hgs_k_sort_lds, dim3(class_grid(1)), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
   } else {
     HGS_STAGE(3);
@@ -372,7 +378,8 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
   // remaining tiles, then the combine of the segment partials.  Grids are capacity bounds;
   // surplus workgroups exit on the device-side totals.
   const bool use_seg = !v.seg_off && entry_capacity > HGS_SEG_THRESH;
-  const unsigned seg_bound = use_seg ? 2u * (unsigned)(entry_capacity / HGS_SEG) + 2u : 0u;
+  // segments of multi-segment lists: sum ceil(n / SEG) over lists longer than THRESH <= C / SEG + C / THRESH
+  const unsigned seg_bound = use_seg ? (unsigned)(entry_capacity / HGS_SEG + entry_capacity / HGS_SEG_THRESH) + 2u : 0u;
   if (use_seg && !v.seg_recompute) {
     hipLaunchKernelGGL(hgs_k_fwd_segT, dim3(seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.recs, L.segT);
@@ -388,7 +395,9 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
                        out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
   if (use_seg) {
-    hipLaunchKernelGGL(hgs_k_fwd_combine, dim3(v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L,
+    // tiles with more than HGS_SEG_THRESH entries occupy at most the first capacity / THRESH positions
+    const int64_t cg = entry_capacity / HGS_SEG_THRESH + 1;
+    hipLaunchKernelGGL(hgs_k_fwd_combine, dim3((unsigned)(cg < v.TT ? cg : v.TT)), dim3(HGS_FWD_THREADS), 0, stream, v, L,
                        status_dev, L.segP, out_color, out_depth, out_alpha);
     HGS_LAUNCH_CHECK();
   }

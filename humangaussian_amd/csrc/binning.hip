@@ -627,15 +627,16 @@ __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, in
 
 }  // namespace
 
-// All tiles with 1..4096 entries in ONE launch (512 threads; 2, 4 or 8 keys per thread by
-// list length): each sort is latency-bound on its own stage chain, so the few long lists
-// overlap with the many short ones instead of running in a second kernel after them.
-#ifndef HGS_SORT_NT
-#define HGS_SORT_NT 512
-#endif
-extern "C" __global__ void __launch_bounds__(HGS_SORT_NT)
-hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
-  __shared__ unsigned long long keys[4096];
+// All tiles with 1..4096 entries in ONE launch: each sort is latency-bound on its own stage chain,
+// so the few long lists overlap with the many short ones instead of running in a second kernel
+// after them.  Two workgroup shapes: 512 threads (2, 4 or 8 keys per thread by list length) gives
+// the heaviest tile the shortest chain - what a single view waits for (34 vs 37.5 us); 256 threads
+// (4, 8, 16 keys) keeps twice as many tiles resident per CU - what counts with several views in
+// flight (8 views: 120 vs 158 us).  The host picks by the number of views of the call.
+namespace {
+template <int NT>
+__device__ __forceinline__ void sort_lds_body(const View& v, const Layout& L, const hgs_status* __restrict__ status,
+                                              unsigned long long* keys) {
   if (status->overflow) return;
   const uint32_t b = blockIdx.x;
   if (b >= status->active_tiles) return;
@@ -643,12 +644,28 @@ hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_n[t];
   if (n == 0 || n > 4096u) return;
-  constexpr int E0 = 1024 / HGS_SORT_NT;
-  // (4 keys per thread for every list <= 2048, i.e. half the waves for lists <= 1024, was measured:
-  // single view 34 -> 39 us, 8 views 158 -> 150 us; not kept)
-  if (n <= 1024u) sort_one_tile<E0, HGS_SORT_NT>(v, L, t, start, n, keys);
-  else if (n <= 2048u) sort_one_tile<2 * E0, HGS_SORT_NT>(v, L, t, start, n, keys);
-  else sort_one_tile<4 * E0, HGS_SORT_NT>(v, L, t, start, n, keys);
+  constexpr int E0 = 1024 / NT;
+  // (4 keys per thread for every list <= 2048 at 512 threads, i.e. half the waves for lists <= 1024,
+  // was measured: single view 34 -> 39 us, 8 views 158 -> 150 us; not kept)
+  if (n <= 1024u) sort_one_tile<E0, NT>(v, L, t, start, n, keys);
+  else if (n <= 2048u) sort_one_tile<2 * E0, NT>(v, L, t, start, n, keys);
+  else sort_one_tile<4 * E0, NT>(v, L, t, start, n, keys);
+}
+}  // namespace
+
+#ifndef HGS_SORT_NT
+#define HGS_SORT_NT 512
+#endif
+extern "C" __global__ void __launch_bounds__(HGS_SORT_NT)
+hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
+  __shared__ unsigned long long keys[4096];
+  sort_lds_body<HGS_SORT_NT>(v, L, status, keys);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+hgs_k_sort_lds_256(View v, Layout L, const hgs_status* __restrict__ status) {
+  __shared__ unsigned long long keys[4096];
+  sort_lds_body<256>(v, L, status, keys);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)

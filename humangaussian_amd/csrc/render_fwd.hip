@@ -333,13 +333,14 @@ hgs_k_render_fwd_nostore(View v, Layout L, uint32_t seg_bound, const hgs_status*
 }
 
 // -------------------------------------------------------------------------- combine
-// One workgroup per tile; only tiles with more than one segment do anything.  Thread = pf.
+// One workgroup per tile_order position that can hold a tile with more than one segment (the
+// launch covers the first capacity / HGS_SEG_THRESH positions); the others do nothing.  Thread = pf.
 extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
 hgs_k_fwd_combine(View v, Layout L, const hgs_status* __restrict__ status,
                   float* __restrict__ segP, float* __restrict__ out_color,
                   float* __restrict__ out_depth, float* __restrict__ out_alpha) {
-  if (status->overflow) return;
-  const int g = blockIdx.x;
+  if (status->overflow || blockIdx.x >= status->active_tiles) return;
+  const int g = (int)L.tile_order[blockIdx.x];      // heavy first: the multi-segment tiles lead the order
   const uint32_t n = L.tile_n[g];
   const uint32_t nseg = hgs_nseg(n);
   if (nseg <= 1) return;
