@@ -81,7 +81,7 @@ size_t hgs_img_bytes_batch(int32_t B, int32_t image_height, int32_t image_width)
 
 /* Optional per-stage timing (measurement only; pass NULL in production): `stage_events`
  * is a HOST array of hipEvent_t handles; entry k (if non-NULL) is recorded on `stream`
- * after stage k.  Forward: 0 start, 1 preprocess, 2 scan, 3 fill, 4 sort, 5 blend.
+ * after stage k.  Forward: 0 start, 1 preprocess, 2 tile tables, 3 fill (+ status), 4 sort, 5 blend.
  * Backward: 0 start, 1 blend backward, 2 preprocess backward. */
 #define HGS_FWD_STAGES 6
 #define HGS_BWD_STAGES 3
@@ -99,7 +99,7 @@ size_t hgs_img_bytes_batch(int32_t B, int32_t image_height, int32_t image_width)
  * status_host_mapped != 0: `status_host` is pinned host memory that the device can address
  * with the same pointer (hipHostMalloc / torch pin_memory on ROCm); the scan kernel then
  * stores the status into it directly (system-scope fence) and no copy is enqueued.
- * Otherwise the status copy to `status_host` is enqueued right after the scan stage (before fill /
+ * Otherwise the status copy to `status_host` is enqueued right after the fill stage (before
  * sort / blend); `status_event` (a hipEvent_t, may be NULL) is recorded right behind it, so a
  * host can wait for just the status - hipEventSynchronize(status_event) - while the rest of
  * the forward is still running, and knows about an overflow before it hands out outputs. */
