@@ -34,7 +34,8 @@ P_POINTS = 100_000
 RES = 1024
 SH_DEGREE = 0
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
-INIT_STEPS = 30                # un-timed first-use steps before the W warm-up steps (reported as init_steps)
+INIT_STEPS = 100               # un-timed first-use steps before the W warm-up steps (reported as init_steps): the
+                               # estimates settle and the GPU leaves its idle clocks (some boxes need > 20 ms for that)
 
 FWD_STAGES = ["preprocess_fwd", "tiles", "fill", "sort", "render_fwd"]
 BWD_STAGES = ["render_bwd", "preprocess_bwd"]

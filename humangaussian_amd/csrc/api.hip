@@ -96,7 +96,7 @@ BinCarve carve_bin(int64_t cap) {
   c.seg_item = take((nms + 2) * 8);
   // one backward work item per bucket: <= C/64 + (tiles with a partial bucket) <= C/64 + min(C, tiles);
   // sized by C alone so that the carve does not depend on the image
-  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 8);
+  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 16);
   c.total = off;
   return c;
 }
@@ -126,7 +126,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
   L.segT = bp ? reinterpret_cast<float*>(bp + b.segT) : nullptr;
   L.segP = bp ? reinterpret_cast<float*>(bp + b.segP) : nullptr;
-  L.wg_tile = bp ? reinterpret_cast<uint2*>(bp + b.wg_tile) : nullptr;
+  L.wg_tile = bp ? reinterpret_cast<uint4*>(bp + b.wg_tile) : nullptr;
   L.seg_item = bp ? reinterpret_cast<uint2*>(bp + b.seg_item) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;
@@ -486,11 +486,16 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
                      colors_precomp, opacities, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, \
                      dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,            \
                      dL_dcov3D_precomp)
-  switch (shs ? v.D : 0) {
+  // one view: the instantiation without the loop over views (94 instead of 176 VGPRs at SH degree 0)
+  switch ((shs ? v.D : 0) + (v.B == 1 ? 4 : 0)) {
     case 0: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d0); break;
     case 1: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d1); break;
     case 2: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d2); break;
-    default: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d3); break;
+    case 3: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d3); break;
+    case 4: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s0); break;
+    case 5: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s1); break;
+    case 6: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s2); break;
+    default: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s3); break;
   }
 #undef HGS_LAUNCH_PRE_BWD
   HGS_LAUNCH_CHECK();

@@ -113,7 +113,8 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* chunk_base;       // [B*nblk] first entry id of the chunk (bump-allocated)
   Counters* ctr;
   uint2* seg_item;            // [<= 2C/HGS_SEG + 4] (tile, segment) of every segment of the long lists
-  uint2* wg_tile;             // [<= C/64 + B*T] (tile, bucket) of every backward work item (written by the forward)
+  uint4* wg_tile;             // [<= C/64 + B*T] (tile, bucket, list start, list length) of every backward work item
+                              // (written by the forward: the backward wave finds its records with ONE load)
   unsigned long long* keys;
   SortRec* recs;
   float* bstate;

@@ -376,7 +376,7 @@ hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
 // gradient block accumulates in registers with constant indices.
 namespace {
 
-template <int DEG>
+template <int DEG, bool SINGLE>
 __device__ __forceinline__ void preprocess_bwd_body(
     const View& v, const Layout& L, const hgs_status* __restrict__ status,
     const float* __restrict__ grad_rows, const float* __restrict__ means3D,
@@ -392,31 +392,38 @@ __device__ __forceinline__ void preprocess_bwd_body(
   if (i >= v.P) return;
   const bool ok = status->overflow == 0;
 
-  // ---- view-independent inputs, loaded once
-  const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+  // ---- view-independent inputs.  One view: loaded once.  Several views: RE-loaded at the top of every
+  // view iteration behind a compiler barrier - they come from L1/L2, and keeping them (and what the
+  // compiler derives from them) live across the loop next to the running sums cost 176-256 VGPRs
+  // (1-2 waves/SIMD) instead of ~100-130.
+  float x, y, z;
   Cov3 s;
   RotScale rs;
   float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
   float q_inv_norm = 1.0f;
-  if (cov3D_precomp) {
-    const float* c = cov3D_precomp + 6 * (size_t)i;
-    s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
-  } else {
-    rs = make_rotscale(scales, rotations, i, v.scale_modifier, v.act);
-    s = cov3d_from(rs);
-    q = act_rotation(rotations, i, v.act, q_inv_norm);
-  }
   const bool want_sh = dL_dshs != nullptr && shs != nullptr;
   float sh48[48];
-  if (DEG > 0 && want_sh) {
-    if (sh_block_vectorisable(v.M)) {
-      load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
+  auto load_inputs = [&]() {
+    x = means3D[3 * i + 0]; y = means3D[3 * i + 1]; z = means3D[3 * i + 2];
+    if (cov3D_precomp) {
+      const float* c = cov3D_precomp + 6 * (size_t)i;
+      s.c0 = c[0]; s.c1 = c[1]; s.c2 = c[2]; s.c3 = c[3]; s.c4 = c[4]; s.c5 = c[5];
     } else {
-      const float* shp = shs + (size_t)i * v.M * 3;
-#pragma unroll
-      for (int k = 3; k < 48; ++k) sh48[k] = (k < 3 * NC) ? shp[k] : 0.f;   // degree >= 1 terms only
+      rs = make_rotscale(scales, rotations, i, v.scale_modifier, v.act);
+      s = cov3d_from(rs);
+      q = act_rotation(rotations, i, v.act, q_inv_norm);
     }
-  }
+    if (DEG > 0 && want_sh) {
+      if (sh_block_vectorisable(v.M)) {
+        load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
+      } else {
+        const float* shp = shs + (size_t)i * v.M * 3;
+#pragma unroll
+        for (int k = 3; k < 48; ++k) sh48[k] = (k < 3 * NC) ? shp[k] : 0.f;   // degree >= 1 terms only
+      }
+    }
+  };
+  if (SINGLE) load_inputs();
 
   // ---- sums over the views
   float a_mean[3] = {0.f, 0.f, 0.f}, a_sc[3] = {0.f, 0.f, 0.f}, a_rot[4] = {0.f, 0.f, 0.f, 0.f};
@@ -425,7 +432,12 @@ __device__ __forceinline__ void preprocess_bwd_body(
 #pragma unroll
   for (int k = 0; k < 3 * NC; ++k) a_sh[k] = 0.f;
 
-  for (int b = 0; b < v.B; ++b) {
+  const int nviews = SINGLE ? 1 : v.B;      // SINGLE: one view, known at compile time (no loop-carried sums)
+  for (int b = 0; b < nviews; ++b) {
+    if (!SINGLE) {
+      asm volatile("" ::: "memory");          // nothing loaded below may be carried over from the last view
+      load_inputs();
+    }
     const Cam cam = v.cam[b];
     const float* __restrict__ V = cam.viewmatrix;
     const float* __restrict__ PM = cam.projmatrix;
@@ -670,6 +682,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     dL_dscales[3 * i + 0] = a_sc[0]; dL_dscales[3 * i + 1] = a_sc[1]; dL_dscales[3 * i + 2] = a_sc[2];
   }
   if (dL_drots) {
+    if (!SINGLE && !cov3D_precomp) q = act_rotation(rotations, i, v.act, q_inv_norm);
     if (v.act & HGS_ACT_ROTATION_NORMALIZE) {   // d normalize: (g - q_hat (q_hat . g)) / |q|
       const float dot = q.x * a_rot[0] + q.y * a_rot[1] + q.z * a_rot[2] + q.w * a_rot[3];
       a_rot[0] = (a_rot[0] - q.x * dot) * q_inv_norm;
@@ -693,8 +706,8 @@ __device__ __forceinline__ void preprocess_bwd_body(
 #else
 #define HGS_PRE_BWD_OCC
 #endif
-#define HGS_PRE_BWD_KERNEL(DEG)                                                                     \
-  extern "C" __global__ void __launch_bounds__(HGS_BLOCK) HGS_PRE_BWD_OCC hgs_k_preprocess_bwd_d##DEG( \
+#define HGS_PRE_BWD_KERNEL(DEG, NAME, SINGLE)                                                       \
+  extern "C" __global__ void __launch_bounds__(HGS_BLOCK) HGS_PRE_BWD_OCC NAME(                     \
       View v, Layout L, const hgs_status* __restrict__ status, const float* __restrict__ grad_rows, \
       const float* __restrict__ means3D, const float* __restrict__ shs,                             \
       const float* __restrict__ colors_precomp, const float* __restrict__ opacities_raw,            \
@@ -703,14 +716,18 @@ __device__ __forceinline__ void preprocess_bwd_body(
       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, \
       float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,  \
       float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {                                \
-    preprocess_bwd_body<DEG>(v, L, status, grad_rows, means3D, shs, colors_precomp, opacities_raw, scales, \
+    preprocess_bwd_body<DEG, SINGLE>(v, L, status, grad_rows, means3D, shs, colors_precomp, opacities_raw, scales, \
                              rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, dL_dshs,           \
                              dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D);                \
   }
-HGS_PRE_BWD_KERNEL(0)
-HGS_PRE_BWD_KERNEL(1)
-HGS_PRE_BWD_KERNEL(2)
-HGS_PRE_BWD_KERNEL(3)
+HGS_PRE_BWD_KERNEL(0, hgs_k_preprocess_bwd_d0, false)
+HGS_PRE_BWD_KERNEL(1, hgs_k_preprocess_bwd_d1, false)
+HGS_PRE_BWD_KERNEL(2, hgs_k_preprocess_bwd_d2, false)
+HGS_PRE_BWD_KERNEL(3, hgs_k_preprocess_bwd_d3, false)
+HGS_PRE_BWD_KERNEL(0, hgs_k_preprocess_bwd_s0, true)      // single-view instantiations
+HGS_PRE_BWD_KERNEL(1, hgs_k_preprocess_bwd_s1, true)
+HGS_PRE_BWD_KERNEL(2, hgs_k_preprocess_bwd_s2, true)
+HGS_PRE_BWD_KERNEL(3, hgs_k_preprocess_bwd_s3, true)
 
 // ------------------------------------------------------------------------- mark visible
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)

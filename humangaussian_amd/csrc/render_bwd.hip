@@ -76,7 +76,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   // buffer (768 floats), which is filled only after the basis has been read back
   float* __restrict__ basis = (2 * HGS_BWD_BATCH >= 11) ? stage : reinterpret_cast<float*>(s_rec);
 
-  // ---- which (tile, bucket)?  The forward left (tile, bucket) of every work item in wg_tile, heavy
+  // ---- which (tile, bucket)?  The forward left (tile, bucket, list start, length) of every work item in wg_tile, heavy
   // tiles first (a binary search over a prefix array here cost 12 dependent loads).
   const uint32_t g = blockIdx.x;
 #ifdef HGS_BWD_TIMING
@@ -92,11 +92,11 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #define HGS_TSTART()
 #endif
   if (status->overflow || g >= status->bwd_groups) return;   // surplus workgroup
-  const uint2 item = L.wg_tile[g];
+  const uint4 item = L.wg_tile[g];                          // one load: everything needed to find the records
   const int gt = (int)item.x;                               // global tile = view * T + tile
   const uint32_t b = item.y;
-  const uint32_t start = L.tile_start[gt];
-  const uint32_t n = L.tile_n[gt];
+  const uint32_t start = item.z;
+  const uint32_t n = item.w;
   const uint32_t maxc = L.tile_maxcontrib[gt];
   const int bview = gt / v.T, t = gt % v.T;
   {   // this view's planes

@@ -249,7 +249,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
     // backward work item -> (global tile, bucket) map, one item per 64-entry bucket: spares the
     // backward a dependent binary search at the start of every wave
     const uint32_t w0 = L.tile_wgstart[g], nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
-    for (uint32_t bb = tid; bb < nb; bb += HGS_FWD_THREADS) L.wg_tile[w0 + bb] = make_uint2((uint32_t)g, bb);
+    for (uint32_t bb = tid; bb < nb; bb += HGS_FWD_THREADS) L.wg_tile[w0 + bb] = make_uint4((uint32_t)g, bb, start, n);
   }
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
 

@@ -97,7 +97,7 @@ size_t hgs_img_bytes_batch(int32_t B, int32_t image_height, int32_t image_width)
  * detected on the device and reported as overflow bit 1 (value 2) - call again with 0.
  * P == 0 writes background / zeros and reports num_rendered = 0.
  * status_host_mapped != 0: `status_host` is pinned host memory that the device can address
- * with the same pointer (hipHostMalloc / torch pin_memory on ROCm); the scan kernel then
+ * with the same pointer (hipHostMalloc / torch pin_memory on ROCm); the fill launch then
  * stores the status into it directly (system-scope fence) and no copy is enqueued.
  * Otherwise the status copy to `status_host` is enqueued right after the fill stage (before
  * sort / blend); `status_event` (a hipEvent_t, may be NULL) is recorded right behind it, so a

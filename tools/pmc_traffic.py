@@ -20,7 +20,7 @@ def load(path, counter):
         for pre, st in STAGE:
             if k.startswith(pre) or k.startswith("void " + pre):
                 tot[st] += float(r["Counter_Value"])
-                if pre == "hgs_k_preprocess_bwd":
+                if pre == "hgs_k_preprocess_bwd":      # one per step (any instantiation)
                     steps += 1
                 break
     return tot, max(steps, 1)
