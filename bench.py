@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--variant", default="mid", choices=["mid", "init"])
     ap.add_argument("--views", type=int, default=1,
                     help="views per rank per step rendered by ONE batched call (extra measurement when > 1)")
+    ap.add_argument("--collective", default="auto", choices=["auto", "allgather", "scatter"],
+                    help="N > 1: how the per-rank gradient packs are reduced (view_parallel.allgather_reduce); auto times "
+                         "both outside the timed region and uses the faster one")
     ap.add_argument("--forward-only", action="store_true",
                     help="extra measurement (animation path, configs[4]): no-grad forward only")
     args = ap.parse_args()
@@ -160,7 +163,7 @@ def main():
                 grads = {k: L[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")}
                 grads["means2D"] = means2D.grad if self.views == 1 else means2D.grad.sum(0)
                 rad = radii if self.views == 1 else radii.max(dim=0).values
-                return vp.allgather_reduce(vp.pack_contribution(grads, rad))
+                return vp.allgather_reduce(vp.pack_contribution(grads, rad), mode=collective_mode[0])
             return means2D.grad
 
         def timed(self, steps, warmup, init_steps=INIT_STEPS):
@@ -204,7 +207,45 @@ def main():
             return {k: v / nprof * 1e3 for k, v in acc.items()}
 
     P, sh_degree = args.points, args.sh_degree
+    collective_mode = [args.collective if args.collective != "auto" else "allgather"]
     main_wl = Workload(P, sh_degree, args.variant, args.views, args.forward_only, first_view=rank * args.views)
+
+    # ---------------- N > 1: what the collective of a step costs, per mode (OUTSIDE the timed region);
+    # --collective auto then runs the timed steps with the faster mode (every rank takes the same decision)
+    collective = None
+    if world > 1:
+        L = main_wl.leaves
+        grads = {k: torch.zeros_like(L[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        grads["means2D"] = torch.zeros_like(L["means3D"])
+        rad = torch.ones(P, dtype=torch.int32, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        nrep = 20
+        res = {}
+        for mode in vp.COLLECTIVE_MODES:
+            acc = [0.0, 0.0]
+            for it in range(nrep + 5):
+                fence()
+                ev[0].record()
+                pack = vp.pack_contribution(grads, rad)
+                ev[1].record()
+                vp.allgather_reduce(pack, mode=mode)
+                ev[2].record()
+                torch.cuda.synchronize()
+                if it >= 5:
+                    acc[0] += ev[0].elapsed_time(ev[1])
+                    acc[1] += ev[1].elapsed_time(ev[2])
+            tt = torch.tensor(acc, dtype=torch.float64, device=dev) / nrep * 1e3
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            res[mode] = {"pack_us": float(tt[0]), "collective_and_reduce_us": float(tt[1])}
+        if args.collective == "auto":
+            collective_mode[0] = min(vp.COLLECTIVE_MODES, key=lambda m: res[m]["collective_and_reduce_us"])
+        collective = {"mode_used": collective_mode[0], "requested": args.collective, "timings": res,
+                      "bytes_per_rank_pack": int(pack.numel() * 4),
+                      "note": "allgather = ONE all_gather_into_tensor of the per-rank gradient packs + rank-ordered local "
+                              "reduction; scatter = all_to_all of row shards + the same local reduction + one all-gather of "
+                              "the reduced shards (same bits, (world-1)/world * 2 packs per rank on the links instead of "
+                              "world-1); timed outside the step loop, max over ranks"}
+
     elapsed = main_wl.timed(args.steps, args.warmup)
     M = main_wl.M
 
@@ -222,35 +263,7 @@ def main():
                  "event_wait_us": round((st_now.wait_ns - w0) / nhost * 1e-3, 1),
                  "forward_retries_total": int(st_now.retries), "forward_calls_total": int(st_now.calls)}
 
-    # ---------------- N > 1: what the one collective of a step costs (outside the timed region)
-    collective = None
-    if world > 1:
-        L = main_wl.leaves
-        grads = {k: torch.zeros_like(L[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
-        grads["means2D"] = torch.zeros_like(L["means3D"])
-        rad = torch.ones(P, dtype=torch.int32, device=dev)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        acc = [0.0, 0.0, 0.0]
-        nrep = 20
-        for it in range(nrep + 3):
-            fence()
-            ev[0].record()
-            pack = vp.pack_contribution(grads, rad)
-            ev[1].record()
-            gathered = vp.allgather(pack)
-            ev[2].record()
-            vp.reduce_gathered(gathered)
-            ev[3].record()
-            torch.cuda.synchronize()
-            if it >= 3:
-                for i in range(3):
-                    acc[i] += ev[i].elapsed_time(ev[i + 1])
-        tt = torch.tensor(acc, dtype=torch.float64, device=dev) / nrep * 1e3
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        collective = {"pack_us": float(tt[0]), "allgather_us": float(tt[1]), "reduce_us": float(tt[2]),
-                      "bytes_per_rank": int(pack.numel() * 4), "note": "one all_gather_into_tensor of the per-rank "
-                      "gradient pack per step, then a rank-ordered local reduction (max over ranks of each phase)"}
-
+    # ---------------- host/GPU balance etc. follow below
     # ---------------- per-kernel timing (outside the timed region; library-recorded events)
     stage_us = main_wl.stage_times()
     R = int(_rast._state(dev).max_R)
@@ -348,7 +361,7 @@ def main():
                                    + ("fwd only" if args.forward_only else "fwd+bwd"),
                        "views_per_step": world * args.views, "num_rendered_R": int(R),
                        "host_mode": "sync (one host wait per forward for the device-side status, as upstream)",
-                       "parallelism": f"view-parallel x{world}" + (", 1 all-gather/step" if world > 1 else "")},
+                       "parallelism": f"view-parallel x{world}" + (f", collective {collective_mode[0]}" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": dom_bytes, "avg_us": stage_us[dom],

@@ -334,7 +334,10 @@ def _rccl_worker(rank, world, port, q):
                  "shs": torch.randn(P, M, 3, generator=g), "opacities": torch.randn(P, 1, generator=g),
                  "scales": torch.randn(P, 3, generator=g), "rotations": torch.randn(P, 4, generator=g)}
         radii = torch.randint(0, 50, (P,), generator=g, dtype=torch.int32)
-        total = vp.allgather_reduce(vp.pack_contribution({k: v.to(dev) for k, v in grads.items()}, radii.to(dev)))
+        pack = vp.pack_contribution({k: v.to(dev) for k, v in grads.items()}, radii.to(dev))
+        total = vp.allgather_reduce(pack, mode="allgather")
+        total2 = vp.allgather_reduce(pack, mode="scatter")
+        assert torch.equal(total, total2)              # both collectives give the same bits
         q.put((rank, total.cpu()))
     finally:
         dist.destroy_process_group()

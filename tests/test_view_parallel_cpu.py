@@ -104,3 +104,48 @@ def test_two_ranks_reproduce_the_serial_accumulation():
         assert torch.equal(res[0][1][k], res[1][1][k])
     for (v0, c0), (v1, c1) in zip(res[0][3], res[1][3]):
         assert v0 == v1 and torch.equal(c0, c1)
+
+
+def _collective_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(7 + rank)
+    P, F = 1001, 18                                    # P not a multiple of the world size
+    pack = torch.randn(P, F, generator=g)
+    pack[:, -1] = torch.randint(0, 40, (P,), generator=g).float()
+    a = vp.allgather_reduce(pack, mode="allgather")
+    b = vp.allgather_reduce(pack, mode="scatter")
+    q.put((rank, a.clone(), b.clone()))
+    dist.barrier()
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scatter_collective_equals_allgather_bitwise(world):
+    """mode "scatter" (all-to-all of shards + local rank-ordered reduce + all-gather of the reduced
+    shards) returns the bits of the single all-gather + local reduce, on every rank."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_collective_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    ref = res[0][1]
+    for rank, a, b in res:
+        assert torch.equal(a, ref) and torch.equal(b, ref), rank
+    # and it is the rank-ordered sum / max
+    packs = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(7 + r)
+        pk = torch.randn(1001, 18, generator=g)
+        pk[:, -1] = torch.randint(0, 40, (1001,), generator=g).float()
+        packs.append(pk)
+    assert torch.equal(ref, vp.reduce_gathered(torch.stack(packs)))
