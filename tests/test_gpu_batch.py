@@ -398,3 +398,76 @@ def test_fused_activations_match_the_unfused_path_forward_and_backward():
         assert float((o0[k] - o1[k]).abs().max()) <= 2e-6 * max(1.0, float(o0[k].abs().max())), k
     for a, b in zip(g0 + [v0], g1 + [v1]):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-12)
+
+
+def test_batch_capacity_overflow_retries_transparently_and_matches_single_calls():
+    """Huge splats: R of the batch exceeds the first capacity guess (4 P B entries) - the device reports
+    the overflow, the binding re-runs with the exact size, results are those of single calls."""
+    dev = torch.device(DEV)
+    B, P, H, W = 2, 3000, 208, 200                      # a shape no other test uses: fresh estimate
+    sc = make_scene(P=P, sh_degree=0, seed=91, H=H, W=W, spread=0.3, scale=0.35)
+    g = torch.Generator().manual_seed(6)
+    sc["opacities"] = 0.002 + 0.004 * torch.rand(P, 1, generator=g)      # nothing terminates early
+    cams = _cams(B, H, W, seed=17)
+    rsl = [_settings(c, sc["bg"], 0) for c in cams]
+    ins = {k: sc[k].to(dev) for k in NAMES}
+    before = R._state(dev).retries
+    with torch.no_grad():
+        c, r, d, a = rasterize_gaussians_batch(ins["means3D"], None, ins["shs"], None, ins["opacities"], ins["scales"],
+                                               ins["rotations"], None, rsl)
+    st = R._state(dev)
+    assert st.retries > before and st.max_R > 4 * P * B and st.capacity >= st.max_R
+    with torch.no_grad():
+        for b in range(B):
+            cs, rs_, ds, as_ = GaussianRasterizer(rsl[b])(means3D=ins["means3D"], means2D=torch.zeros_like(ins["means3D"]),
+                                                          shs=ins["shs"], opacities=ins["opacities"], scales=ins["scales"],
+                                                          rotations=ins["rotations"])
+            assert torch.equal(c[b], cs) and torch.equal(r[b], rs_) and torch.equal(d[b], ds) and torch.equal(a[b], as_)
+    # second call: the estimate has learnt, no retry
+    mid = R._state(dev).retries
+    with torch.no_grad():
+        c2 = rasterize_gaussians_batch(ins["means3D"], None, ins["shs"], None, ins["opacities"], ins["scales"],
+                                       ins["rotations"], None, rsl)[0]
+    assert R._state(dev).retries == mid and torch.equal(c2, c)
+
+
+def test_batch_of_sixteen_views_and_global_atomic_bin_path():
+    """The largest batch (HGS_MAX_VIEWS) and, separately, a batched call on an image with more than 16384
+    tiles per view (the global-atomic binning path) agree with single calls."""
+    dev = torch.device(DEV)
+    sc = make_scene(P=700, sh_degree=1, seed=93, H=48, W=48, spread=0.3)
+    ins = {k: sc[k].to(dev) for k in NAMES}
+    cams = _cams(16, 48, 48, seed=19)
+    rsl = [_settings(c, sc["bg"], 1) for c in cams]
+    with torch.no_grad():
+        c = rasterize_gaussians_batch(ins["means3D"], None, ins["shs"], None, ins["opacities"], ins["scales"],
+                                      ins["rotations"], None, rsl)[0]
+        for b in (0, 7, 15):
+            cs = GaussianRasterizer(rsl[b])(means3D=ins["means3D"], means2D=torch.zeros_like(ins["means3D"]), shs=ins["shs"],
+                                            opacities=ins["opacities"], scales=ins["scales"], rotations=ins["rotations"])[0]
+            assert torch.equal(c[b], cs), b
+    # T = 130 * 130 = 16900 tiles per view > 16384: hgs_k_preprocess_fwd_ga / hgs_k_fill_ga
+    H = W = 2080
+    sc2 = make_scene(P=1500, sh_degree=0, seed=95, H=H, W=W, spread=0.4, scale=0.02)
+    ins2 = {k: sc2[k].to(dev).requires_grad_(True) for k in NAMES}
+    cams2 = _cams(2, H, W, seed=23)
+    rsl2 = [_settings(c, sc2["bg"], 0) for c in cams2]
+    m2 = torch.zeros(2, 1500, 3, device=dev, requires_grad=True)
+    c, r, d, a = rasterize_gaussians_batch(ins2["means3D"], m2, ins2["shs"], None, ins2["opacities"], ins2["scales"],
+                                           ins2["rotations"], None, rsl2)
+    w = torch.linspace(0.5, 1.5, W, device=dev)
+    (c * w).sum().backward()
+    got = {k: ins2[k].grad.clone() for k in NAMES}
+    acc = None
+    for b in range(2):
+        ins_b = {k: sc2[k].to(dev).requires_grad_(True) for k in NAMES}
+        mb = torch.zeros(1500, 3, device=dev, requires_grad=True)
+        cs, rs_, _, _ = GaussianRasterizer(rsl2[b])(means3D=ins_b["means3D"], means2D=mb, shs=ins_b["shs"],
+                                                    opacities=ins_b["opacities"], scales=ins_b["scales"], rotations=ins_b["rotations"])
+        assert torch.equal(c[b], cs) and torch.equal(r[b], rs_)
+        (cs * w).sum().backward()
+        assert torch.equal(m2.grad[b], mb.grad)
+        gb = {k: ins_b[k].grad for k in NAMES}
+        acc = gb if acc is None else {k: acc[k] + gb[k] for k in NAMES}
+    for k in NAMES:
+        assert torch.equal(got[k], acc[k]), k
