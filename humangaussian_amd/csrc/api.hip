@@ -31,8 +31,14 @@ namespace {
 #endif
 constexpr size_t ALIGN = 256;
 constexpr size_t HGS_LDS_BINS_MAX = 16384;   // T*4 bytes of LDS <= 64 KB
-constexpr int HGS_MAX_BIN_WGS_PER_VIEW = 256;
-constexpr int HGS_BIN_WGS_TOTAL = 1024;      // binning workgroups of a batch (all views)
+#ifndef HGS_BIN_WGS_PER_VIEW_MAX
+#define HGS_BIN_WGS_PER_VIEW_MAX 256
+#endif
+#ifndef HGS_BIN_WGS_TOTAL_MAX
+#define HGS_BIN_WGS_TOTAL_MAX 1024
+#endif
+constexpr int HGS_MAX_BIN_WGS_PER_VIEW = HGS_BIN_WGS_PER_VIEW_MAX;
+constexpr int HGS_BIN_WGS_TOTAL = HGS_BIN_WGS_TOTAL_MAX;      // binning workgroups of a batch (all views)
 
 struct GeomCarve {
   size_t geom, tile_n, tile_start, tile_bstart, tile_wgstart, tile_msegstart, tile_maxcontrib, tile_order,
