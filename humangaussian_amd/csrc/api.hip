@@ -24,7 +24,8 @@ extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, con
 namespace {
 
 #ifndef HGS_SORT_256_MIN_VIEWS
-#define HGS_SORT_256_MIN_VIEWS 3   // calls with at least this many views sort with 256-thread workgroups (binning.hip)
+#define HGS_SORT_256_MIN_VIEWS 3   // calls with at least this many views use the throughput-shaped kernel variants:
+                                   // 256-thread sort workgroups (binning.hip), blend unroll 2 (render_fwd.hip)
 #endif
 #ifndef HGS_SEG_RECOMPUTE_MAX
 #define HGS_SEG_RECOMPUTE_MAX 12   // longest list (in segments) for which segments recompute their predecessors' products
@@ -391,14 +392,18 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
                        status_dev, L.recs, L.segT);
     HGS_LAUNCH_CHECK();
   }
-  if (store_bwd_state)
-    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.TT + seg_bound), dim3(HGS_FWD_THREADS), 0, stream,
-                       v, L, (uint32_t)seg_bound, status_dev, L.recs, L.bstate, L.segT, L.segP, out_color,
-                       out_depth, out_alpha);
-  else
-    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.TT + seg_bound), dim3(HGS_FWD_THREADS), 0,
-                       stream, v, L, (uint32_t)seg_bound, status_dev, L.recs, L.bstate, L.segT, L.segP,
-                       out_color, out_depth, out_alpha);
+  // two instantiations of the blend: unroll 4 (shortest per-tile chain) for calls of few views, unroll 2
+  // (8 waves/SIMD) when several views keep the chip full (render_fwd.hip); same bits either way
+  const bool many = v.B >= HGS_SORT_256_MIN_VIEWS;
+#define HGS_LAUNCH_FWD(K)                                                                                    \
+  hipLaunchKernelGGL(K, dim3(v.TT + seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L, (uint32_t)seg_bound, \
+                     status_dev, L.recs, L.bstate, L.segT, L.segP, out_color, out_depth, out_alpha)
+  if (store_bwd_state) {
+    if (many) HGS_LAUNCH_FWD(hgs_k_render_fwd_store_many); else HGS_LAUNCH_FWD(hgs_k_render_fwd_store);
+  } else {
+    if (many) HGS_LAUNCH_FWD(hgs_k_render_fwd_nostore_many); else HGS_LAUNCH_FWD(hgs_k_render_fwd_nostore);
+  }
+#undef HGS_LAUNCH_FWD
   HGS_LAUNCH_CHECK();
   if (use_seg) {
     // tiles with more than HGS_SEG_THRESH entries occupy at most the first capacity / THRESH positions

@@ -34,9 +34,16 @@
 // state when storing, 32 B/pixel/segment for long lists.
 #include "hgs_common.h"
 
-#ifndef HGS_FWD_UNROLL
-#define HGS_FWD_UNROLL 2      // compacted records per unrolled group (pad records >= this).  2: 64 VGPRs = 8 waves/SIMD;
-                              // 4: 88 VGPRs = 5 waves/SIMD.  Same single-view time, 14 % faster with 8 views in flight
+// Compacted records per unrolled group of the blend loop (pad records >= this), a template parameter:
+//   4: 88 VGPRs = 5 waves/SIMD - the shortest chain per tile: what a single view waits for (62 vs 66 us);
+//   2: 64 VGPRs = 8 waves/SIMD - the best throughput: what counts with several views in flight
+//      (8 views: 263 vs 306 us).  The host picks by the number of views of the call; the results are
+//      bit-identical (the blend is sequential in list order either way).
+#ifndef HGS_FWD_UNROLL_FEW
+#define HGS_FWD_UNROLL_FEW 4
+#endif
+#ifndef HGS_FWD_UNROLL_MANY
+#define HGS_FWD_UNROLL_MANY 2
 #endif
 
 namespace {
@@ -79,7 +86,7 @@ __device__ __forceinline__ void tprod_one(float& P, float pxf, float pyf, const 
 // Wave-level walk over list entries [q_begin, q_end) of one tile: loads, compaction, and a
 // callback per group of 4 compacted records.  BODY(ra, rb, rc) gets float4[4] arrays;
 // PRE(j0) runs at every bucket start (bucket-state stores); ALIVE() lets the wave stop early.
-template <typename Pre, typename Alive, typename Body>
+template <int U, typename Pre, typename Alive, typename Body>
 __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, uint32_t q_begin,
                                              uint32_t q_end, uint32_t wbit, float4* __restrict__ srec,
                                              int lane, Pre pre, Alive alive, Body body) {
@@ -109,7 +116,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
       srec[3 * pos + 1] = c1;
       srec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float(j0 + lane + 1));
     }
-    if (lane < 2 * HGS_FWD_UNROLL) {                 // pad records behind the last real one
+    if (lane < 2 * U) {                 // pad records behind the last real one
       srec[3 * (cnt + lane) + 0] = zero4;
       srec[3 * (cnt + lane) + 1] = zero4;            // opacity 0 => alpha 0 => skipped
       srec[3 * (cnt + lane) + 2] = zero4;
@@ -119,29 +126,29 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
 
 #ifdef HGS_FWD_LDS_PREFETCH
     // register double buffer: the LDS reads of group g+1 are in flight while group g blends
-    float4 ra[HGS_FWD_UNROLL], rb[HGS_FWD_UNROLL], rc[HGS_FWD_UNROLL];
+    float4 ra[U], rb[U], rc[U];
 #pragma unroll
-    for (int u = 0; u < HGS_FWD_UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
       ra[u] = srec[3 * u + 0]; rb[u] = srec[3 * u + 1]; rc[u] = srec[3 * u + 2];
     }
-    for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_FWD_UNROLL) {
-      float4 na[HGS_FWD_UNROLL], nb[HGS_FWD_UNROLL], nc[HGS_FWD_UNROLL];
+    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
+      float4 na[U], nb[U], nc[U];
 #pragma unroll
-      for (int u = 0; u < HGS_FWD_UNROLL; ++u) {
-        const uint32_t k = k0 + HGS_FWD_UNROLL + u;          // <= cnt + 2U - 1: inside the pads
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = k0 + U + u;          // <= cnt + 2U - 1: inside the pads
         na[u] = srec[3 * k + 0]; nb[u] = srec[3 * k + 1]; nc[u] = srec[3 * k + 2];
       }
       __builtin_amdgcn_sched_barrier(0);
       body(ra, rb, rc);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < HGS_FWD_UNROLL; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
+      for (int u = 0; u < U; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
     }
 #else
-    for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_FWD_UNROLL) {
-      float4 ra[HGS_FWD_UNROLL], rb[HGS_FWD_UNROLL], rc[HGS_FWD_UNROLL];
+    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
+      float4 ra[U], rb[U], rc[U];
 #pragma unroll
-      for (int u = 0; u < HGS_FWD_UNROLL; ++u) {
+      for (int u = 0; u < U; ++u) {
         ra[u] = srec[3 * (k0 + u) + 0]; rb[u] = srec[3 * (k0 + u) + 1]; rc[u] = srec[3 * (k0 + u) + 2];
       }
       body(ra, rb, rc);
@@ -154,14 +161,15 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
 }  // namespace
 
 // product of (1 - alpha) over segment i of a tile's list for this thread's pixel (no stop rule)
+template <int U>
 __device__ __forceinline__ float segment_tprod(const float4* __restrict__ recs, uint32_t i, int w,
                                                float4* __restrict__ srec, int lane, float pxf, float pyf) {
   float P = 1.0f;
-  walk_segment(recs, i * HGS_SEG, (i + 1) * HGS_SEG, 1u << (28 + w), srec, lane,
+  walk_segment<U>(recs, i * HGS_SEG, (i + 1) * HGS_SEG, 1u << (28 + w), srec, lane,
                [](uint32_t) {}, [] { return true; },
-               [&](const float4 (&ra)[HGS_FWD_UNROLL], const float4 (&rb)[HGS_FWD_UNROLL], const float4 (&)[HGS_FWD_UNROLL]) {
+               [&](const float4 (&ra)[U], const float4 (&rb)[U], const float4 (&)[U]) {
 #pragma unroll
-                 for (int u = 0; u < HGS_FWD_UNROLL; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
+                 for (int u = 0; u < U; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
                });
   return P;
 }
@@ -170,7 +178,8 @@ __device__ __forceinline__ float segment_tprod(const float4* __restrict__ recs, 
 extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
 hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
                const SortRec* __restrict__ recs_all, float* __restrict__ segT) {
-  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * HGS_FWD_UNROLL)];
+  constexpr int U = HGS_FWD_UNROLL_FEW;
+  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * U)];
   const uint32_t ms = blockIdx.x;
   if (status->overflow || ms >= status->reserved[2]) return;
   const uint2 item = L.seg_item[ms];                // (global tile, segment): one load, no search
@@ -188,12 +197,12 @@ hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
   hgs_fwd_thread_pixel(tid, lx, ly);
   const float pxf = (float)((t % v.grid_x) * HGS_TILE + lx), pyf = (float)((t / v.grid_x) * HGS_TILE + ly);
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
-  const float P = segment_tprod(recs, k, w, s_rec[w], lane, pxf, pyf);
+  const float P = segment_tprod<U>(recs, k, w, s_rec[w], lane, pxf, pyf);
   segT[(size_t)ms * HGS_TILE_PIX + tid] = P;
 }
 
 // ---------------------------------------------------------------------------- blend
-template <bool STORE>
+template <bool STORE, int U>
 __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, uint32_t seg_bound,
                                                 const hgs_status* __restrict__ status,
                                                 const SortRec* __restrict__ recs_all,
@@ -203,7 +212,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
                                                 float* __restrict__ out_color,
                                                 float* __restrict__ out_depth,
                                                 float* __restrict__ out_alpha) {
-  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * HGS_FWD_UNROLL)];
+  __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * U)];
   const bool overflow = status->overflow != 0;
   int g;                                            // global tile = view * T + tile
   uint32_t k = 0;
@@ -260,14 +269,14 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
     // lists of at most a few segments: the segment recomputes its predecessors' transmittance
     // products itself (same arithmetic as hgs_k_fwd_segT, so the same bits) and the pre-pass
     // kernel - 15 us alone on the GPU for ~60 long tiles - is not launched at all
-    for (uint32_t i = 0; i < k; ++i) s.T *= segment_tprod(recs, i, w, s_rec[w], lane, pxf, pyf);
+    for (uint32_t i = 0; i < k; ++i) s.T *= segment_tprod<U>(recs, i, w, s_rec[w], lane, pxf, pyf);
   } else {
     for (uint32_t i = 0; i < k; ++i) s.T *= segT[(size_t)(ms0 + i) * HGS_TILE_PIX + tid];
   }
   // T only decreases: "terminated before this segment" <=> entry transmittance < 1e-4
   s.done = !inside || (s.T < HGS_T_EPS);
 
-  walk_segment(
+  walk_segment<U>(
       recs, nseg > 1 ? k * HGS_SEG : 0u, nseg > 1 ? min(n, (k + 1) * HGS_SEG) : n, 1u << (28 + w), s_rec[w], lane,
       [&](uint32_t j0) {
         if (STORE && j0 > 0) {
@@ -281,9 +290,9 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
         }
       },
       [&] { return __ballot(!s.done) != 0ull; },      // stop when every pixel is finished
-      [&](const float4 (&ra)[HGS_FWD_UNROLL], const float4 (&rb)[HGS_FWD_UNROLL], const float4 (&rc)[HGS_FWD_UNROLL]) {
+      [&](const float4 (&ra)[U], const float4 (&rb)[U], const float4 (&rc)[U]) {
 #pragma unroll
-        for (int u = 0; u < HGS_FWD_UNROLL; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
+        for (int u = 0; u < U; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
       });
 
   if (nseg == 1) {
@@ -314,23 +323,18 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   }
 }
 
-extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
-hgs_k_render_fwd_store(View v, Layout L, uint32_t seg_bound, const hgs_status* __restrict__ status,
-                       const SortRec* __restrict__ recs, float* __restrict__ bstate,
-                       const float* __restrict__ segT, float* __restrict__ segP,
-                       float* __restrict__ out_color, float* __restrict__ out_depth,
-                       float* __restrict__ out_alpha) {
-  render_fwd_body<true>(v, L, seg_bound, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
-}
-
-extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS)
-hgs_k_render_fwd_nostore(View v, Layout L, uint32_t seg_bound, const hgs_status* __restrict__ status,
-                         const SortRec* __restrict__ recs, float* __restrict__ bstate,
-                         const float* __restrict__ segT, float* __restrict__ segP,
-                         float* __restrict__ out_color, float* __restrict__ out_depth,
-                         float* __restrict__ out_alpha) {
-  render_fwd_body<false>(v, L, seg_bound, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha);
-}
+#define HGS_RENDER_FWD_KERNEL(NAME, STORE, U)                                                              \
+  extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS) NAME(                                       \
+      View v, Layout L, uint32_t seg_bound, const hgs_status* __restrict__ status,                           \
+      const SortRec* __restrict__ recs, float* __restrict__ bstate, const float* __restrict__ segT,          \
+      float* __restrict__ segP, float* __restrict__ out_color, float* __restrict__ out_depth,                \
+      float* __restrict__ out_alpha) {                                                                       \
+    render_fwd_body<STORE, U>(v, L, seg_bound, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha); \
+  }
+HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_store, true, HGS_FWD_UNROLL_FEW)            // calls of < 3 views
+HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_nostore, false, HGS_FWD_UNROLL_FEW)
+HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_store_many, true, HGS_FWD_UNROLL_MANY)      // >= 3 views in flight
+HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_nostore_many, false, HGS_FWD_UNROLL_MANY)
 
 // -------------------------------------------------------------------------- combine
 // One workgroup per tile_order position that can hold a tile with more than one segment (the
