@@ -93,6 +93,8 @@ struct Counters {
   uint32_t ticket;               // hgs_k_tiles workgroups that have finished
   uint32_t max_n;                // longest tile list
   uint32_t pad;
+  uint32_t bwd_front;            // backward work items placed so far from the front (expensive buckets) ...
+  uint32_t bwd_back;             // ... and from the back (cheap ones) of wg_tile
   uint32_t cls_hist[HGS_NCLS];   // tiles per class
   uint32_t cls_cur[HGS_NCLS];    // tile_order cursor per class (starts at the class base, heavy first)
 };

@@ -34,12 +34,16 @@
 #include "hgs_common.h"
 
 #ifndef HGS_BWD_PREFETCH
-#define HGS_BWD_PREFETCH 1               // fetch the next quadrant's pixel inputs during the current one
+#define HGS_BWD_PREFETCH 0               // 1: fetch the next quadrant's pixel inputs during the current one (22 more VGPRs;
+                                         // measured neutral, and it pushes the full-batch path over 128 registers)
 #endif
 #ifndef HGS_BWD_BATCH
 #define HGS_BWD_BATCH 8                  // records per MFMA batch (8 records x {k, wgt} = 16 columns).
 #endif                                   // 4 (half-empty MFMAs, 7.8 KB LDS, 5 waves/SIMD) was measured:
                                          // 96 -> 127 us - the fp32 MFMA time is not hidden behind VALU work
+#ifndef HGS_BWD_FULL_BATCH_PATH
+#define HGS_BWD_FULL_BATCH_PATH 1        // branch-free evaluation of full batches (see the loop)
+#endif
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 #define HGS_PART_FLOATS 10               // sums per (entry, quadrant)
 
@@ -324,35 +328,59 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     hgs_f32x4 pa0 = {0.f, 0.f, 0.f, 0.f}, pa1 = {0.f, 0.f, 0.f, 0.f};
     uint32_t pk0 = 0, pn = 0;
     HGS_TSTART();
+    // one record of the batch: everything that depends on (pixel, record); T and F are the only
+    // values carried from record to record
+    auto eval_record = [&](uint32_t idx, float& kq, float& wgt) {
+      const float4 r0 = s_rec[3 * idx + 0];    // mx my qa qb
+      const float4 r1 = s_rec[3 * idx + 1];    // qc op r g
+      const float4 r2 = s_rec[3 * idx + 2];    // b depth entry slot
+      const uint32_t slot = __float_as_uint(r2.w);
+      // same dx/dy expressions as the forward so skip decisions agree
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      float G, alpha, m2, m3;
+      const bool keep = hgs_eval_alpha(dx, dy, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
+      // `&`, not `&&`: a short-circuit here makes the compiler sink the slot read into a divergent
+      // branch, which cuts the eight records of a batch into eight basic blocks (no overlap of one
+      // record's LDS / exp / rcp latencies with its neighbours' arithmetic)
+      const bool act = keep & (q0 + slot < nc);
+      const float am = act ? r1.y * G : 0.0f;    // un-clamped alpha (= op*G), 0 when inactive
+      const float a = fminf(HGS_ALPHA_MAX, am);
+      wgt = a * T;
+      const float S = __builtin_fmaf(r1.z, g0, __builtin_fmaf(r1.w, g1, __builtin_fmaf(r2.x, g2,
+                      __builtin_fmaf(r2.y, gd, ga))));
+      F = __builtin_fmaf(wgt, S, F);
+      const float om = 1.0f - a;
+      // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
+      const float dLda = __builtin_fmaf(T, S, -((fp - F) * __builtin_amdgcn_rcpf(om)));
+      T *= om;
+      kq = am * dLda;                            // k = dL/dG * G
+    };
     for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_BWD_BATCH) {
       const uint32_t nrec = min((uint32_t)HGS_BWD_BATCH, cnt - k0);
+#if HGS_BWD_FULL_BATCH_PATH
+      if (nrec == HGS_BWD_BATCH) {
+        // FULL batch (three of four at config 2): no per-record branch, ONE basic block for the eight
+        // records, so the scheduler overlaps the LDS reads and the exp / rcp latencies of one record
+        // with the arithmetic of its neighbours.  (With a wave-uniform `u < nrec` test per record
+        // every record was its own block: read, wait, compute - 14 cycles per instruction per wave.)
+        float kqv[HGS_BWD_BATCH], wgv[HGS_BWD_BATCH];
 #pragma unroll
-      for (int u = 0; u < HGS_BWD_BATCH; ++u) {
-        float kq = 0.0f, wgt = 0.0f;
-        if ((uint32_t)u < nrec) {                    // wave-uniform
-          const float4 r0 = s_rec[3 * (k0 + u) + 0];    // mx my qa qb
-          const float4 r1 = s_rec[3 * (k0 + u) + 1];    // qc op r g
-          const float4 r2 = s_rec[3 * (k0 + u) + 2];    // b depth entry slot
-          const uint32_t slot = __float_as_uint(r2.w);
-          // same dx/dy expressions as the forward so skip decisions agree
-          const float dx = r0.x - pxf, dy = r0.y - pyf;
-          float G, alpha, m2, m3;
-          const bool keep = hgs_eval_alpha(dx, dy, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
-          const bool act = keep && (q0 + slot < nc);
-          const float am = act ? r1.y * G : 0.0f;    // un-clamped alpha (= op*G), 0 when inactive
-          const float a = fminf(HGS_ALPHA_MAX, am);
-          wgt = a * T;
-          const float S = __builtin_fmaf(r1.z, g0, __builtin_fmaf(r1.w, g1, __builtin_fmaf(r2.x, g2,
-                          __builtin_fmaf(r2.y, gd, ga))));
-          F = __builtin_fmaf(wgt, S, F);
-          const float om = 1.0f - a;
-          // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
-          const float dLda = __builtin_fmaf(T, S, -((fp - F) * __builtin_amdgcn_rcpf(om)));
-          T *= om;
-          kq = am * dLda;                            // k = dL/dG * G
+        for (int u = 0; u < HGS_BWD_BATCH; ++u) eval_record(k0 + u, kqv[u], wgv[u]);
+#pragma unroll
+        for (int u = 0; u < HGS_BWD_BATCH; ++u) {
+          stage[u * HGS_STAGE_STRIDE + lane] = kqv[u];
+          stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgv[u];
         }
-        stage[u * HGS_STAGE_STRIDE + lane] = kq;
-        stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgt;
+      } else
+#endif
+      {
+#pragma unroll
+        for (int u = 0; u < HGS_BWD_BATCH; ++u) {
+          float kq = 0.0f, wgt = 0.0f;
+          if ((uint32_t)u < nrec) eval_record(k0 + u, kq, wgt);      // wave-uniform
+          stage[u * HGS_STAGE_STRIDE + lane] = kq;
+          stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgt;
+        }
       }
       HGS_TACC(0);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -39,6 +39,10 @@
 //   2: 64 VGPRs = 8 waves/SIMD - the best throughput: what counts with several views in flight
 //      (8 views: 263 vs 306 us).  The host picks by the number of views of the call; the results are
 //      bit-identical (the blend is sequential in list order either way).
+#ifndef HGS_BWD_HEAVY_COST
+#define HGS_BWD_HEAVY_COST 80    // kept (entry, quadrant) pairs from which a backward work item counts as expensive
+#endif                           // (mean 97 at config 2).  render_bwd, single view: plain bump order (0) 89.6 us,
+                                 // threshold 64 / 80 / 96 / 112 / 144: 77.6 / 76.6 / 78.7 / 80.9 / 85.3 us
 #ifndef HGS_FWD_UNROLL_FEW
 #define HGS_FWD_UNROLL_FEW 4
 #endif
@@ -98,7 +102,6 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
   }
   for (uint32_t j0 = q_begin; j0 < q_end; j0 += HGS_BUCKET) {
     if (!alive()) break;
-    pre(j0);
     // issue the next bucket's loads now; they land while this bucket is processed
     const uint32_t qn = j0 + HGS_BUCKET + lane;
     float4 n0 = zero4, n1 = zero4, n2 = zero4;
@@ -110,6 +113,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
     const uint32_t cnt = (uint32_t)__popcll(ball);
     const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+    pre(j0, cnt);                                    // bucket start: state stores, cost bookkeeping
     __builtin_amdgcn_wave_barrier();                 // previous bucket's reads are done
     if (hit) {
       srec[3 * pos + 0] = c0;
@@ -166,7 +170,7 @@ __device__ __forceinline__ float segment_tprod(const float4* __restrict__ recs, 
                                                float4* __restrict__ srec, int lane, float pxf, float pyf) {
   float P = 1.0f;
   walk_segment<U>(recs, i * HGS_SEG, (i + 1) * HGS_SEG, 1u << (28 + w), srec, lane,
-               [](uint32_t) {}, [] { return true; },
+               [](uint32_t, uint32_t) {}, [] { return true; },
                [&](const float4 (&ra)[U], const float4 (&rb)[U], const float4 (&)[U]) {
 #pragma unroll
                  for (int u = 0; u < U; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
@@ -213,7 +217,11 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
                                                 float* __restrict__ out_depth,
                                                 float* __restrict__ out_alpha) {
   __shared__ float4 s_rec[4][3 * (HGS_BUCKET + 2 * U)];
+  constexpr int MAXB = (HGS_SEG_THRESH > HGS_SEG ? HGS_SEG_THRESH : HGS_SEG) / HGS_BUCKET;   // buckets one workgroup blends
+  __shared__ uint32_t s_cost[MAXB];                 // (entry, quadrant) pairs its waves kept, per bucket
+  __shared__ uint32_t s_done;                       // waves of this workgroup that have finished blending
   const bool overflow = status->overflow != 0;
+  const uint32_t total_items = status->bwd_groups;  // all backward work items of the call (not in the counters' cache line)
   int g;                                            // global tile = view * T + tile
   uint32_t k = 0;
   // Work items, in dispatch order: first the segments of the long lists (the heaviest tiles: their
@@ -254,11 +262,10 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   if (!LONG && nseg > 1) return;
   const uint32_t bstart = overflow ? 0u : L.tile_bstart[g];
   const uint32_t ms0 = (nseg > 1) ? L.tile_msegstart[g] : 0u;
-  if (STORE && !overflow && k == 0) {
-    // backward work item -> (global tile, bucket) map, one item per 64-entry bucket: spares the
-    // backward a dependent binary search at the start of every wave
-    const uint32_t w0 = L.tile_wgstart[g], nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
-    for (uint32_t bb = tid; bb < nb; bb += HGS_FWD_THREADS) L.wg_tile[w0 + bb] = make_uint4((uint32_t)g, bb, start, n);
+  if (STORE) {
+    if (tid < MAXB) s_cost[tid] = 0;
+    if (tid == MAXB) s_done = 0;
+    __syncthreads();
   }
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
 
@@ -276,9 +283,11 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   // T only decreases: "terminated before this segment" <=> entry transmittance < 1e-4
   s.done = !inside || (s.T < HGS_T_EPS);
 
+  const uint32_t seg_begin = nseg > 1 ? k * HGS_SEG : 0u, seg_end = nseg > 1 ? min(n, (k + 1) * HGS_SEG) : n;
   walk_segment<U>(
-      recs, nseg > 1 ? k * HGS_SEG : 0u, nseg > 1 ? min(n, (k + 1) * HGS_SEG) : n, 1u << (28 + w), s_rec[w], lane,
-      [&](uint32_t j0) {
+      recs, seg_begin, seg_end, 1u << (28 + w), s_rec[w], lane,
+      [&](uint32_t j0, uint32_t cnt) {
+        if (STORE && lane == 0 && cnt) atomicAdd(&s_cost[(j0 - seg_begin) / HGS_BUCKET], cnt);
         if (STORE && j0 > 0) {
           float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
           bs[0 * 256 + tid] = s.T;
@@ -320,6 +329,37 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
     // tile-wide max of n_contrib: buckets at or beyond it are skipped by the backward
     const uint32_t mx = hgs_wave_max_u32(s.last);
     if ((tid & 63) == 0 && mx > 0) atomicMax(&L.tile_maxcontrib[g], mx);
+    // Backward work items (one per 64-entry bucket this workgroup blended): (global tile, bucket, list
+    // start, list length), so that a backward wave finds its records with ONE load.  An item's
+    // duration follows the (entry, quadrant) pairs it must evaluate (device timestamps: 38k cycles
+    // at the 10th percentile, 121k at the 90th, 161k max), and the kernel ends with its last
+    // item: EXPENSIVE items are placed from the front of the table (dispatched first), cheap ones
+    // from the back, with two bump cursors - a two-class longest-first schedule.  (Buckets no
+    // wave reached - every pixel had terminated - cost 0 and still get their zero rows.)
+    // The LAST of the four waves to get here places the items (no workgroup barrier: the waves are
+    // independent and retire on their own; LDS atomics order the cost updates before the count).
+    uint32_t arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&s_done, 1u);
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    const uint32_t b0 = seg_begin / HGS_BUCKET, nbl = (seg_end - seg_begin + HGS_BUCKET - 1) / HGS_BUCKET;
+    if (arrived == HGS_FWD_THREADS / 64 - 1) {       // nbl <= MAXB <= 64: one wave, two atomics per workgroup at most
+      const bool mine = (uint32_t)lane < nbl;
+      const bool heavy = mine && (s_cost[mine ? lane : 0] >= HGS_BWD_HEAVY_COST);
+      const unsigned long long bh = __ballot(heavy), bl = __ballot(mine && !heavy);
+      uint32_t fbase = 0, bbase = 0;
+      if (lane == 0) {
+        if (bh) fbase = atomicAdd(&L.ctr->bwd_front, (uint32_t)__popcll(bh));
+        if (bl) bbase = atomicAdd(&L.ctr->bwd_back, (uint32_t)__popcll(bl));
+      }
+      fbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)fbase);
+      bbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)bbase);
+      if (mine) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t pos = heavy ? fbase + (uint32_t)__popcll(bh & below)
+                                   : total_items - 1u - (bbase + (uint32_t)__popcll(bl & below));
+        L.wg_tile[pos] = make_uint4((uint32_t)g, b0 + (uint32_t)lane, start, n);
+      }
+    }
   }
 }
 
