@@ -284,10 +284,11 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   s.done = !inside || (s.T < HGS_T_EPS);
 
   const uint32_t seg_begin = nseg > 1 ? k * HGS_SEG : 0u, seg_end = nseg > 1 ? min(n, (k + 1) * HGS_SEG) : n;
+  uint32_t wcost = 0;                               // this wave's kept records per bucket (lane = bucket)
   walk_segment<U>(
       recs, seg_begin, seg_end, 1u << (28 + w), s_rec[w], lane,
       [&](uint32_t j0, uint32_t cnt) {
-        if (STORE && lane == 0 && cnt) atomicAdd(&s_cost[(j0 - seg_begin) / HGS_BUCKET], cnt);
+        if (STORE) wcost = ((uint32_t)lane == (j0 - seg_begin) / HGS_BUCKET) ? cnt : wcost;   // lane i keeps bucket i's count
         if (STORE && j0 > 0) {
           float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
           bs[0 * 256 + tid] = s.T;
@@ -338,6 +339,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
     // wave reached - every pixel had terminated - cost 0 and still get their zero rows.)
     // The LAST of the four waves to get here places the items (no workgroup barrier: the waves are
     // independent and retire on their own; LDS atomics order the cost updates before the count).
+    if (lane < MAXB && wcost) atomicAdd(&s_cost[lane], wcost);      // one LDS atomic per wave, not one per bucket
     uint32_t arrived = 0;
     if (lane == 0) arrived = atomicAdd(&s_done, 1u);
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
@@ -346,13 +348,12 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
       const bool mine = (uint32_t)lane < nbl;
       const bool heavy = mine && (s_cost[mine ? lane : 0] >= HGS_BWD_HEAVY_COST);
       const unsigned long long bh = __ballot(heavy), bl = __ballot(mine && !heavy);
-      uint32_t fbase = 0, bbase = 0;
-      if (lane == 0) {
-        if (bh) fbase = atomicAdd(&L.ctr->bwd_front, (uint32_t)__popcll(bh));
-        if (bl) bbase = atomicAdd(&L.ctr->bwd_back, (uint32_t)__popcll(bl));
-      }
-      fbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)fbase);
-      bbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)bbase);
+      // the two bump allocations travel together (lanes 0 and 1): one round trip at the end of the chain
+      uint32_t base = 0;
+      if (lane == 0 && bh) base = atomicAdd(&L.ctr->bwd_front, (uint32_t)__popcll(bh));
+      if (lane == 1 && bl) base = atomicAdd(&L.ctr->bwd_back, (uint32_t)__popcll(bl));
+      const uint32_t fbase = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+      const uint32_t bbase = (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
       if (mine) {
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t pos = heavy ? fbase + (uint32_t)__popcll(bh & below)
