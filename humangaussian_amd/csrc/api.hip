@@ -9,6 +9,9 @@
 
 // The forward kernels and the per-Gaussian backward are included here (one translation
 // unit, SLP vectorisation on: the forward blend is latency-bound and profits from v_pk_*).
+#ifdef HGS_TIMELINE
+__device__ unsigned long long hgs_tl[HGS_TL_KERNELS][HGS_TL_SLOTS][4];
+#endif
 #include "preprocess.hip"
 #include "binning.hip"
 #include "render_fwd.hip"
@@ -103,7 +106,7 @@ BinCarve carve_bin(int64_t cap) {
   c.seg_item = take((nms + 2) * 8);
   // one backward work item per bucket: <= C/64 + (tiles with a partial bucket) <= C/64 + min(C, tiles);
   // sized by C alone so that the carve does not depend on the image
-  c.wg_tile = take((C + C / HGS_BUCKET + 2) * 16);
+  c.wg_tile = take(2 * (C + C / HGS_BUCKET + 2) * 16);       // two tables (hgs_bwd_item_slot)
   c.total = off;
   return c;
 }
@@ -216,6 +219,19 @@ bool batch_ok(const hgs_settings* s, int B) {
 }
 
 }  // namespace
+
+#ifdef HGS_TIMELINE
+// debug builds only: copy one kernel's timeline table to the host (synchronous) and clear it
+extern "C" int hgs_debug_timeline_read(int kernel_id, void* host_dst) {
+  if (kernel_id < 0 || kernel_id >= HGS_TL_KERNELS) return -1;
+  const size_t bytes = sizeof(unsigned long long) * HGS_TL_SLOTS * 4, off = bytes * (size_t)kernel_id;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(hgs_tl), bytes, off, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(hgs_tl)) != hipSuccess) return -4;
+  return hipMemset(static_cast<char*>(p) + off, 0, bytes) == hipSuccess ? 0 : -5;
+}
+#endif
 
 extern "C" {
 

@@ -273,10 +273,14 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
   }
   // GU records per thread in flight: the 64 B geom gathers are dependent random reads (~1-2 us
   // each); issued one at a time they dominated the sort kernel of the heaviest tile
-  constexpr int GU = 4;
+#ifndef HGS_GATHER_GU
+#define HGS_GATHER_GU 4
+#endif
+  constexpr int GU = HGS_GATHER_GU;
   for (uint32_t kb = threadIdx.x; kb < n; kb += (uint32_t)nt * GU) {
     uint32_t idxv[GU];
-    uint4 q0[GU], q1[GU], q2[GU], q3[GU];
+    uint4 q0[GU], q1[GU], q2[GU];
+    uint32_t q3[GU];
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       const uint32_t k = kb + (uint32_t)u * nt;
@@ -287,7 +291,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
       const uint32_t k = kb + (uint32_t)u * nt;
       if (k < n) {
         const uint4* gp = reinterpret_cast<const uint4*>(&geom[idxv[u]]);
-        q0[u] = gp[0]; q1[u] = gp[1]; q2[u] = gp[2]; q3[u] = gp[3];
+        q0[u] = gp[0]; q1[u] = gp[1]; q2[u] = gp[2]; q3[u] = gp[3].x;        // g3: only the entry-id offset
       }
     }
 #pragma unroll
@@ -295,10 +299,10 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
       const uint32_t k = kb + (uint32_t)u * nt;
       if (k >= n) continue;
       const uint32_t idx = idxv[u];
-      const uint4 g0 = q0[u], g1 = q1[u], g2 = q2[u], g3 = q3[u];
-      // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | g3: offset radius ..
+      const uint4 g0 = q0[u], g1 = q1[u], g2 = q2[u];
+      // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | q3: offset
       const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
-      const uint32_t entry = cbase[idx >> 8] + g3.x + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+      const uint32_t entry = cbase[idx >> 8] + q3[u] + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
       const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
       const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
       const float op = __uint_as_float(g1.y);
@@ -596,31 +600,30 @@ __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, in
   if (threadIdx.x >= live) return;
   u64 k[E];
   const uint32_t base = threadIdx.x * E;
-#ifdef HGS_SORT_TIMING
-  unsigned long long tmk[4];
-  tmk[0] = __builtin_readcyclecounter();
+#ifdef HGS_TIMELINE
+  const unsigned long long tp0 = wall_clock64();
 #endif
 #pragma unroll
   for (int e = 0; e < E; ++e) k[e] = (base + e < n) ? L.keys[start + base + e] : ~0ull;
-#ifdef HGS_SORT_TIMING
+#ifdef HGS_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)");
-  tmk[1] = __builtin_readcyclecounter();
+  const unsigned long long tp1 = wall_clock64();
 #endif
   hybrid_sort<E, NT>(k, keys, npad);
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < E; ++e) keys[base + e] = k[e];
   __syncthreads();
-#ifdef HGS_SORT_TIMING
-  tmk[2] = __builtin_readcyclecounter();
+#ifdef HGS_TIMELINE
+  const unsigned long long tp2 = wall_clock64();
 #endif
   gather_records(v, L, t, start, n, keys, (int)live);
-#ifdef HGS_SORT_TIMING
-  __syncthreads();
-  tmk[3] = __builtin_readcyclecounter();
-  if (threadIdx.x == 0) {
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(L.segT) + (size_t)blockIdx.x * 8;
-    o[0] = tmk[0]; o[1] = tmk[1]; o[2] = tmk[2]; o[3] = tmk[3]; o[4] = n; o[5] = E;
+#ifdef HGS_TIMELINE
+  if (threadIdx.x == 0 && blockIdx.x < HGS_TL_SLOTS) {     // phases of this tile's sort (wave 0): kernel id 5
+    hgs_tl[5][blockIdx.x][0] = tp1 - tp0;
+    hgs_tl[5][blockIdx.x][1] = tp2 - tp1;
+    hgs_tl[5][blockIdx.x][2] = wall_clock64() - tp2;
+    hgs_tl[5][blockIdx.x][3] = ((unsigned long long)E << 32) | n;
   }
 #endif
 }
@@ -656,10 +659,17 @@ __device__ __forceinline__ void sort_lds_body(const View& v, const Layout& L, co
 #ifndef HGS_SORT_NT
 #define HGS_SORT_NT 512
 #endif
-extern "C" __global__ void __launch_bounds__(HGS_SORT_NT)
+#ifdef HGS_SORT_WAVES_PER_EU
+#define HGS_SORT_OCC __attribute__((amdgpu_waves_per_eu(HGS_SORT_WAVES_PER_EU, HGS_SORT_WAVES_PER_EU)))
+#else
+#define HGS_SORT_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(HGS_SORT_NT) HGS_SORT_OCC
 hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[4096];
+  HGS_TL_BEGIN();
   sort_lds_body<HGS_SORT_NT>(v, L, status, keys);
+  HGS_TL_END(3, blockIdx.x < status->active_tiles ? L.tile_n[L.tile_order[blockIdx.x]] : 0u);
 }
 
 extern "C" __global__ void __launch_bounds__(256)

@@ -93,11 +93,21 @@ struct Counters {
   uint32_t ticket;               // hgs_k_tiles workgroups that have finished
   uint32_t max_n;                // longest tile list
   uint32_t pad;
-  uint32_t bwd_front;            // backward work items placed so far from the front (expensive buckets) ...
-  uint32_t bwd_back;             // ... and from the back (cheap ones) of wg_tile
+  uint32_t bwd_cur[4];           // backward work items placed so far, per cost class (0 = most expensive): classes 0 / 1
+                                 // fill the first item table from its front / back, classes 2 / 3 the second one
   uint32_t cls_hist[HGS_NCLS];   // tiles per class
   uint32_t cls_cur[HGS_NCLS];    // tile_order cursor per class (starts at the class base, heavy first)
 };
+
+// Backward work items are dispatched in table order, and the kernel ends with its last item: the
+// forward sorts them into four cost classes (kept (entry, quadrant) pairs of the bucket) so that
+// expensive buckets start first and the cheapest ones fill the tail.  Classes 0 and 1 share one
+// table (front / back), classes 2 and 3 a second one: no class needs to know another's size while
+// the forward is still placing items.  Position r of class c among `total` items:
+__host__ __device__ __forceinline__ size_t hgs_bwd_item_slot(uint32_t cls, uint32_t r, uint32_t total, uint32_t capacity) {
+  const size_t table = (cls >> 1) ? (size_t)capacity + capacity / HGS_BUCKET + 2 : 0;
+  return table + ((cls & 1u) ? (size_t)(total - 1u - r) : (size_t)r);
+}
 
 struct Layout {          // pointers carved out of the caller's buffers
   GeomRec* geom;
@@ -115,7 +125,8 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* chunk_base;       // [B*nblk] first entry id of the chunk (bump-allocated)
   Counters* ctr;
   uint2* seg_item;            // [<= 2C/HGS_SEG + 4] (tile, segment) of every segment of the long lists
-  uint4* wg_tile;             // [<= C/64 + B*T] (tile, bucket, list start, list length) of every backward work item
+  uint4* wg_tile;             // two tables of [C + C/64 + 2]: (tile, bucket, list start, list length) of every backward
+                              // work item, by cost class (hgs_bwd_item_slot)
                               // (written by the forward: the backward wave finds its records with ONE load)
   unsigned long long* keys;
   SortRec* recs;
@@ -237,3 +248,29 @@ __device__ __forceinline__ uint32_t hgs_block_excl_scan(uint32_t v, uint32_t* wt
   total = tot;
   return base + incl - v;
 }
+
+// ---- device timeline (debug builds only: -DHGS_TIMELINE, tools/timeline.py) --------------------------
+// Every wave of an instrumented kernel leaves (start, end, hardware id, tag) in a static device
+// table (defined in api.hip: the kernels of that translation unit); wall_clock64 ticks at 100 MHz.
+// Not compiled into the product library.
+#ifdef HGS_TIMELINE
+#define HGS_TL_KERNELS 6
+#define HGS_TL_SLOTS (1 << 17)
+#define HGS_TL_BEGIN() const unsigned long long tl_t0__ = wall_clock64()
+#define HGS_TL_END(KID, TAG)                                                                        \
+  do {                                                                                              \
+    const unsigned long long tl_t1__ = wall_clock64();                                              \
+    const uint32_t tl_slot__ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                 \
+    if ((threadIdx.x & 63) == 0 && tl_slot__ < HGS_TL_SLOTS) {                                      \
+      const uint32_t hw__ = __builtin_amdgcn_s_getreg((31 << 11) | 4);                              \
+      const uint32_t xcc__ = __builtin_amdgcn_s_getreg((31 << 11) | 20);                            \
+      hgs_tl[KID][tl_slot__][0] = tl_t0__;                                                          \
+      hgs_tl[KID][tl_slot__][1] = tl_t1__;                                                          \
+      hgs_tl[KID][tl_slot__][2] = ((unsigned long long)xcc__ << 32) | hw__;                         \
+      hgs_tl[KID][tl_slot__][3] = (unsigned long long)(TAG);                                        \
+    }                                                                                               \
+  } while (0)
+#else
+#define HGS_TL_BEGIN() do {} while (0)
+#define HGS_TL_END(KID, TAG) do {} while (0)
+#endif

@@ -44,6 +44,9 @@
 #ifndef HGS_BWD_FULL_BATCH_PATH
 #define HGS_BWD_FULL_BATCH_PATH 1        // branch-free evaluation of full batches (see the loop)
 #endif
+#ifndef HGS_BWD_SCALAR_RECS
+#define HGS_BWD_SCALAR_RECS 0            // 1: the evaluation reads its records through the SCALAR path (s_load from the
+#endif                                   // sorted list, addresses from the quadrant's ballot) instead of three LDS reads
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 #define HGS_PART_FLOATS 10               // sums per (entry, quadrant)
 
@@ -85,6 +88,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   const uint32_t g = blockIdx.x;
 #ifdef HGS_BWD_TIMING
   unsigned long long tm[8];
+  const unsigned long long wall0 = wall_clock64();      // 100 MHz, the same clock on every XCD (the cycle counter is per XCD)
   tm[0] = __builtin_readcyclecounter();
 #define HGS_TM(i) tm[i] = __builtin_readcyclecounter()
   unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
@@ -95,8 +99,15 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #define HGS_TACC(i)
 #define HGS_TSTART()
 #endif
-  if (status->overflow || g >= status->bwd_groups) return;   // surplus workgroup
-  const uint4 item = L.wg_tile[g];                          // one load: everything needed to find the records
+  const uint32_t total_items = status->bwd_groups;
+  if (status->overflow || g >= total_items) return;          // surplus workgroup
+  // dispatch position -> (cost class, rank): classes in order 0 (most expensive) .. 3, sizes from the forward's cursors
+  uint32_t cls = 0, r = g;
+  {
+    const uint32_t n0 = L.ctr->bwd_cur[0], n1 = L.ctr->bwd_cur[1], n2 = L.ctr->bwd_cur[2];
+    if (r >= n0) { r -= n0; cls = 1; if (r >= n1) { r -= n1; cls = 2; if (r >= n2) { r -= n2; cls = 3; } } }
+  }
+  const uint4 item = L.wg_tile[hgs_bwd_item_slot(cls, r, total_items, v.entry_capacity)];   // one load: everything needed to find the records
   const int gt = (int)item.x;                               // global tile = view * T + tile
   const uint32_t b = item.y;
   const uint32_t start = item.z;
@@ -330,11 +341,25 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     HGS_TSTART();
     // one record of the batch: everything that depends on (pixel, record); T and F are the only
     // values carried from record to record
+#if HGS_BWD_SCALAR_RECS
+    // the quadrant's kept records, in list order = the set bits of its ballot: wave-uniform addresses,
+    // so the compiler fetches the record with s_load_dwordx4 into SGPRs (no LDS pipe, no VGPRs)
+    unsigned long long mrem = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ball >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ball);
+    const float4* __restrict__ brecs4 = reinterpret_cast<const float4*>(brecs);
+    auto eval_record = [&](uint32_t /*idx*/, float& kq, float& wgt) {
+      const uint32_t slot = (uint32_t)__builtin_ctzll(mrem);
+      mrem &= mrem - 1ull;
+      const float4 r0 = brecs4[3 * slot + 0];    // mx my qa qb
+      const float4 r1 = brecs4[3 * slot + 1];    // qc op r g
+      const float2 r2 = *reinterpret_cast<const float2*>(&brecs4[3 * slot + 2]);    // b depth
+#else
     auto eval_record = [&](uint32_t idx, float& kq, float& wgt) {
       const float4 r0 = s_rec[3 * idx + 0];    // mx my qa qb
       const float4 r1 = s_rec[3 * idx + 1];    // qc op r g
       const float4 r2 = s_rec[3 * idx + 2];    // b depth entry slot
       const uint32_t slot = __float_as_uint(r2.w);
+#endif
       // same dx/dy expressions as the forward so skip decisions agree
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       float G, alpha, m2, m3;
@@ -437,8 +462,9 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #ifdef HGS_BWD_TIMING
   HGS_TM(6);
   if (threadIdx.x == 0) {
-    unsigned long long* o = L.keys + (size_t)g * 8;
+    unsigned long long* o = L.keys + (size_t)g * 10;
     o[0] = tm[0]; o[1] = tm[1]; o[2] = tacc[0]; o[3] = tacc[1]; o[4] = tm[4]; o[5] = tacc[2]; o[6] = tm[6]; o[7] = tacc[3];
+    o[8] = wall0; o[9] = wall_clock64();
   }
 #endif
 }

@@ -39,10 +39,29 @@
 //   2: 64 VGPRs = 8 waves/SIMD - the best throughput: what counts with several views in flight
 //      (8 views: 263 vs 306 us).  The host picks by the number of views of the call; the results are
 //      bit-identical (the blend is sequential in list order either way).
-#ifndef HGS_BWD_HEAVY_COST
-#define HGS_BWD_HEAVY_COST 80    // kept (entry, quadrant) pairs from which a backward work item counts as expensive
-#endif                           // (mean 97 at config 2).  render_bwd, single view: plain bump order (0) 89.6 us,
-                                 // threshold 64 / 80 / 96 / 112 / 144: 77.6 / 76.6 / 78.7 / 80.9 / 85.3 us
+// Cost classes of the backward work items (kept (entry, quadrant) pairs of the bucket, mean 97 at config 2):
+// class 0 >= COST_0 > class 1 >= COST_1 > class 2 >= COST_2 > class 3.  render_bwd, single view: plain bump order
+// 89.6 us; two classes split at 64 / 80 / 96 / 112 / 144: 77.6 / 76.6 / 78.7 / 80.9 / 85.3 us.
+#ifndef HGS_BWD_COST_0
+#define HGS_BWD_COST_0 128
+#endif
+#ifndef HGS_BWD_COST_1
+#define HGS_BWD_COST_1 80
+#endif
+#ifndef HGS_BWD_COST_2
+#define HGS_BWD_COST_2 40
+#endif
+#ifndef HGS_FWD_PRIO
+#define HGS_FWD_PRIO 0
+#endif
+#ifndef HGS_FWD_PRIO_3
+#define HGS_FWD_PRIO_3 768
+#define HGS_FWD_PRIO_2 512
+#define HGS_FWD_PRIO_1 256
+#endif
+#ifndef HGS_FWD_SCALAR_RECS
+#define HGS_FWD_SCALAR_RECS 0
+#endif
 #ifndef HGS_FWD_UNROLL_FEW
 #define HGS_FWD_UNROLL_FEW 4
 #endif
@@ -90,6 +109,50 @@ __device__ __forceinline__ void tprod_one(float& P, float pxf, float pyf, const 
 // Wave-level walk over list entries [q_begin, q_end) of one tile: loads, compaction, and a
 // callback per group of 4 compacted records.  BODY(ra, rb, rc) gets float4[4] arrays;
 // PRE(j0) runs at every bucket start (bucket-state stores); ALIVE() lets the wave stop early.
+#if HGS_FWD_SCALAR_RECS
+// Scalar-path variant: the lanes only fetch their record's cull-mask word; the kept records (the set
+// bits of the ballot, in list order) are then read with wave-uniform addresses, which the compiler
+// turns into s_load_dwordx8 / x2 into SGPRs - the blend loop uses no LDS and no record VGPRs.
+template <int U, typename Pre, typename Alive, typename Body>
+__device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, uint32_t q_begin,
+                                             uint32_t q_end, uint32_t wbit, float4* __restrict__ /*srec*/,
+                                             int lane, Pre pre, Alive alive, Body body) {
+  const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(recs);
+  uint32_t cw = 0;
+  {
+    const uint32_t q = q_begin + lane;
+    if (q < q_end) cw = words[12 * q + 11];
+  }
+  for (uint32_t j0 = q_begin; j0 < q_end; j0 += HGS_BUCKET) {
+    if (!alive()) break;
+    const uint32_t qn = j0 + HGS_BUCKET + lane;
+    uint32_t nw = 0;
+    if (qn < q_end) nw = words[12 * qn + 11];          // next bucket's mask words, in flight during this bucket
+    const unsigned long long ball = __ballot((cw & wbit) != 0u);     // lanes beyond q_end hold 0
+    const uint32_t cnt = (uint32_t)__popcll(ball);
+    pre(j0, cnt);
+    unsigned long long mrem = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ball >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ball);
+    const float4* __restrict__ brec = recs + 3 * (size_t)j0;
+    while (mrem) {
+      float4 ra[U], rb[U], rc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool valid = mrem != 0ull;
+        const uint32_t kk = valid ? (uint32_t)__builtin_ctzll(mrem) : 0u;
+        mrem = valid ? (mrem & (mrem - 1ull)) : 0ull;
+        ra[u] = brec[3 * kk + 0];
+        rb[u] = brec[3 * kk + 1];
+        const float2 t = *reinterpret_cast<const float2*>(&brec[3 * kk + 2]);
+        if (!valid) rb[u].y = 0.0f;                       // pad: opacity 0 => alpha 0 => skipped
+        rc[u] = make_float4(t.x, t.y, 0.0f, __uint_as_float(j0 + kk + 1u));
+      }
+      body(ra, rb, rc);
+    }
+    cw = nw;
+  }
+}
+#else
 template <int U, typename Pre, typename Alive, typename Body>
 __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, uint32_t q_begin,
                                              uint32_t q_end, uint32_t wbit, float4* __restrict__ srec,
@@ -162,6 +225,8 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
   }
 }
 
+#endif
+
 }  // namespace
 
 // product of (1 - alpha) over segment i of a tile's list for this thread's pixel (no stop rule)
@@ -206,7 +271,7 @@ hgs_k_fwd_segT(View v, Layout L, const hgs_status* __restrict__ status,
 }
 
 // ---------------------------------------------------------------------------- blend
-template <bool STORE, int U>
+template <bool STORE, int U, bool FINE_CLASSES>
 __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, uint32_t seg_bound,
                                                 const hgs_status* __restrict__ status,
                                                 const SortRec* __restrict__ recs_all,
@@ -268,6 +333,17 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
     __syncthreads();
   }
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
+#if HGS_FWD_PRIO
+  {
+    // Issue priority by the length of the chain this wave has to walk (wave-uniform): the kernel ends
+    // with its longest chains, and those should not share their SIMD's issue slots equally with
+    // the thousands of short ones.
+    const uint32_t work = nseg > 1 ? (k + 1) * HGS_SEG : n;
+    if (work >= HGS_FWD_PRIO_3) __builtin_amdgcn_s_setprio(3);
+    else if (work >= HGS_FWD_PRIO_2) __builtin_amdgcn_s_setprio(2);
+    else if (work >= HGS_FWD_PRIO_1) __builtin_amdgcn_s_setprio(1);
+  }
+#endif
 
   PixState s;
   s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
@@ -288,7 +364,10 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
   walk_segment<U>(
       recs, seg_begin, seg_end, 1u << (28 + w), s_rec[w], lane,
       [&](uint32_t j0, uint32_t cnt) {
-        if (STORE) wcost = ((uint32_t)lane == (j0 - seg_begin) / HGS_BUCKET) ? cnt : wcost;   // lane i keeps bucket i's count
+        // kept pairs per bucket: few views - lane i of a per-wave register keeps bucket i's count (one LDS atomic per
+        // wave at the end); many views - one LDS add per bucket (the register would cost the eighth wave per SIMD)
+        if (STORE && FINE_CLASSES) wcost = ((uint32_t)lane == (j0 - seg_begin) / HGS_BUCKET) ? cnt : wcost;
+        if (STORE && !FINE_CLASSES && lane == 0 && cnt) atomicAdd(&s_cost[(j0 - seg_begin) / HGS_BUCKET], cnt);
         if (STORE && j0 > 0) {
           float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
           bs[0 * 256 + tid] = s.T;
@@ -339,27 +418,36 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
     // wave reached - every pixel had terminated - cost 0 and still get their zero rows.)
     // The LAST of the four waves to get here places the items (no workgroup barrier: the waves are
     // independent and retire on their own; LDS atomics order the cost updates before the count).
-    if (lane < MAXB && wcost) atomicAdd(&s_cost[lane], wcost);      // one LDS atomic per wave, not one per bucket
+    if (FINE_CLASSES && lane < MAXB && wcost) atomicAdd(&s_cost[lane], wcost);      // one LDS atomic per wave, not one per bucket
     uint32_t arrived = 0;
     if (lane == 0) arrived = atomicAdd(&s_done, 1u);
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
     const uint32_t b0 = seg_begin / HGS_BUCKET, nbl = (seg_end - seg_begin + HGS_BUCKET - 1) / HGS_BUCKET;
-    if (arrived == HGS_FWD_THREADS / 64 - 1) {       // nbl <= MAXB <= 64: one wave, two atomics per workgroup at most
+    if (arrived == HGS_FWD_THREADS / 64 - 1) {       // nbl <= MAXB <= 64: one wave, at most four atomics per workgroup
       const bool mine = (uint32_t)lane < nbl;
-      const bool heavy = mine && (s_cost[mine ? lane : 0] >= HGS_BWD_HEAVY_COST);
-      const unsigned long long bh = __ballot(heavy), bl = __ballot(mine && !heavy);
-      // the two bump allocations travel together (lanes 0 and 1): one round trip at the end of the chain
+      const uint32_t cost = s_cost[mine ? lane : 0];
+      // four classes for calls of few views (the tail of the backward is what a single view waits for); two when
+      // many views are in flight: every class is one more device-scope atomic on the same line per workgroup, and
+      // 33k workgroups queueing on it cost the 8-view forward 65 us
+      const uint32_t cls = FINE_CLASSES ? (cost >= HGS_BWD_COST_0 ? 0u : cost >= HGS_BWD_COST_1 ? 1u : cost >= HGS_BWD_COST_2 ? 2u : 3u)
+                                        : (cost >= HGS_BWD_COST_1 ? 1u : 2u);
+      unsigned long long bc[4];
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) bc[c] = __ballot(mine && cls == c);
+      // the bump allocations travel together (lanes 0..3): one round trip at the end of the chain
       uint32_t base = 0;
-      if (lane == 0 && bh) base = atomicAdd(&L.ctr->bwd_front, (uint32_t)__popcll(bh));
-      if (lane == 1 && bl) base = atomicAdd(&L.ctr->bwd_back, (uint32_t)__popcll(bl));
-      const uint32_t fbase = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
-      const uint32_t bbase = (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
-      if (mine) {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const uint32_t pos = heavy ? fbase + (uint32_t)__popcll(bh & below)
-                                   : total_items - 1u - (bbase + (uint32_t)__popcll(bl & below));
-        L.wg_tile[pos] = make_uint4((uint32_t)g, b0 + (uint32_t)lane, start, n);
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c)
+        if ((uint32_t)lane == c && bc[c]) base = atomicAdd(&L.ctr->bwd_cur[c], (uint32_t)__popcll(bc[c]));
+      const unsigned long long below = (1ull << lane) - 1ull;
+      uint32_t r = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) {
+        const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)c);
+        r = (cls == c) ? cb + (uint32_t)__popcll(bc[c] & below) : r;
       }
+      if (mine)
+        L.wg_tile[hgs_bwd_item_slot(cls, r, total_items, v.entry_capacity)] = make_uint4((uint32_t)g, b0 + (uint32_t)lane, start, n);
     }
   }
 }
@@ -370,7 +458,11 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
       const SortRec* __restrict__ recs, float* __restrict__ bstate, const float* __restrict__ segT,          \
       float* __restrict__ segP, float* __restrict__ out_color, float* __restrict__ out_depth,                \
       float* __restrict__ out_alpha) {                                                                       \
-    render_fwd_body<STORE, U>(v, L, seg_bound, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha); \
+    HGS_TL_BEGIN();                                                                                          \
+    render_fwd_body<STORE, U, (U == HGS_FWD_UNROLL_FEW)>(v, L, seg_bound, status, recs, bstate, segT, segP, out_color, out_depth, out_alpha); \
+    HGS_TL_END(4, blockIdx.x < seg_bound                                                                     \
+                      ? (blockIdx.x < status->reserved[2] ? (1ull << 32) | L.seg_item[blockIdx.x].y : 0ull) \
+                      : (blockIdx.x - seg_bound < (uint32_t)v.TT ? L.tile_n[L.tile_order[blockIdx.x - seg_bound]] : 0u)); \
   }
 HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_store, true, HGS_FWD_UNROLL_FEW)            // calls of < 3 views
 HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_nostore, false, HGS_FWD_UNROLL_FEW)
