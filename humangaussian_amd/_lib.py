@@ -104,7 +104,7 @@ def needs_build() -> bool:
 
 # translation units: (source, extra flags)
 UNITS = [("api.hip", []),
-         ("render_bwd.hip", ["-fno-slp-vectorize"])]
+         ("render_bwd.hip", [])]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -30,6 +30,9 @@ namespace {
 #define HGS_SORT_256_MIN_VIEWS 3   // calls with at least this many views use the throughput-shaped kernel variants:
                                    // 256-thread sort workgroups (binning.hip), blend unroll 2 (render_fwd.hip)
 #endif
+#ifndef HGS_PRE_BWD_VPAR_MIN_VIEWS
+#define HGS_PRE_BWD_VPAR_MIN_VIEWS 2   // calls with at least this many views run the per-Gaussian backward with one thread per
+#endif                                 // (Gaussian, view); fewer: one thread per Gaussian
 #ifndef HGS_SEG_RECOMPUTE_MAX
 #define HGS_SEG_RECOMPUTE_MAX 12   // longest list (in segments) for which segments recompute their predecessors' products
 #endif
@@ -508,21 +511,33 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(1);
-#define HGS_LAUNCH_PRE_BWD(K)                                                                         \
-  hipLaunchKernelGGL(K, dim3(v.nblk), dim3(HGS_BLOCK), 0, stream, v, L, status_dev, rows, means3D, shs, \
+#define HGS_LAUNCH_PRE_BWD(K, GRID, THREADS, LDS)                                                     \
+  hipLaunchKernelGGL(K, dim3(GRID), dim3(THREADS), LDS, stream, v, L, status_dev, rows, means3D, shs, \
                      colors_precomp, opacities, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, \
                      dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,            \
                      dL_dcov3D_precomp)
-  // one view: the instantiation without the loop over views (94 instead of 176 VGPRs at SH degree 0)
-  switch ((shs ? v.D : 0) + (v.B == 1 ? 4 : 0)) {
-    case 0: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d0); break;
-    case 1: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d1); break;
-    case 2: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d2); break;
-    case 3: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d3); break;
-    case 4: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s0); break;
-    case 5: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s1); break;
-    case 6: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s2); break;
-    default: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s3); break;
+  // One view: the instantiation without the loop over views (94 instead of 176 VGPRs at SH degree 0).  Several
+  // views: one thread per (Gaussian, view) - a workgroup of B waves per 64 Gaussians, summed in view order
+  // through LDS (preprocess.hip, mode 2); SH degree >= 2 with more than 8 views: the loop (registers, LDS).
+  const int deg = shs ? v.D : 0;
+  const int nc = (deg + 1) * (deg + 1);
+  const unsigned thr_p = 64u * (unsigned)v.B, grid_p = (unsigned)((v.P + 63) / 64);
+  const size_t lds_p = (size_t)(20 + 3 * nc) * thr_p * sizeof(float);
+  const bool vpar_ok = v.B >= HGS_PRE_BWD_VPAR_MIN_VIEWS && v.B <= (deg >= 2 ? 8 : 16);
+  const int mode = v.B == 1 ? 1 : (vpar_ok ? 2 : 0);
+  switch (deg + 4 * mode) {
+    case 0: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d0, v.nblk, HGS_BLOCK, 0); break;
+    case 1: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d1, v.nblk, HGS_BLOCK, 0); break;
+    case 2: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d2, v.nblk, HGS_BLOCK, 0); break;
+    case 3: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d3, v.nblk, HGS_BLOCK, 0); break;
+    case 4: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s0, v.nblk, HGS_BLOCK, 0); break;
+    case 5: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s1, v.nblk, HGS_BLOCK, 0); break;
+    case 6: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s2, v.nblk, HGS_BLOCK, 0); break;
+    case 7: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s3, v.nblk, HGS_BLOCK, 0); break;
+    case 8: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_p0, grid_p, thr_p, lds_p); break;
+    case 9: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_p1, grid_p, thr_p, lds_p); break;
+    case 10: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_p2, grid_p, thr_p, lds_p); break;
+    default: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_p3, grid_p, thr_p, lds_p); break;
   }
 #undef HGS_LAUNCH_PRE_BWD
   HGS_LAUNCH_CHECK();

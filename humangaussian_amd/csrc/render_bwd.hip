@@ -29,8 +29,9 @@
 // beside it (2 x 32 cycles per record); HBM traffic per entry: 4 x 48 B record reads
 // (L2-served), 24 B/pixel/bucket state in, 48 B row out.
 //
-// This file is its own translation unit (built with -fno-slp-vectorize: the kernel is
-// throughput-bound, where v_pk_* packing only adds register moves).
+// This file is its own translation unit (it compiles in parallel with api.hip; same flags.  SLP vectorisation
+// off was worth 1-2 % while every record of a batch was its own basic block; with the branch-free
+// full-batch evaluation the v_pk_* pairs across neighbouring records win: 8 views 441 -> 435 us).
 #include "hgs_common.h"
 
 #ifndef HGS_BWD_PREFETCH
@@ -350,9 +351,17 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     auto eval_record = [&](uint32_t /*idx*/, float& kq, float& wgt) {
       const uint32_t slot = (uint32_t)__builtin_ctzll(mrem);
       mrem &= mrem - 1ull;
+#if HGS_BWD_SCALAR_RECS == 2
+      // ... or straight from the registers that hold the bucket (lane = slot): v_readlane into SGPRs
+      auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (int)slot)); };
+      const float4 r0 = make_float4(rl(c0.x), rl(c0.y), rl(c0.z), rl(c0.w));    // mx my qa qb
+      const float4 r1 = make_float4(rl(c1.x), rl(c1.y), rl(c1.z), rl(c1.w));    // qc op r g
+      const float2 r2 = make_float2(rl(c2.x), rl(c2.y));                        // b depth
+#else
       const float4 r0 = brecs4[3 * slot + 0];    // mx my qa qb
       const float4 r1 = brecs4[3 * slot + 1];    // qc op r g
       const float2 r2 = *reinterpret_cast<const float2*>(&brecs4[3 * slot + 2]);    // b depth
+#endif
 #else
     auto eval_record = [&](uint32_t idx, float& kq, float& wgt) {
       const float4 r0 = s_rec[3 * idx + 0];    // mx my qa qb

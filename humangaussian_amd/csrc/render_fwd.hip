@@ -487,17 +487,32 @@ hgs_k_fwd_combine(View v, Layout L, const hgs_status* __restrict__ status,
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, Wt = 0.f, Tf = 1.0f;
   uint32_t last = 0;
   bool stopped = false;
-  for (uint32_t k = 0; k < nseg; ++k) {
-    float* sp = segP + (size_t)(ms0 + k) * HGS_SEG_PLANES * HGS_TILE_PIX;
-    const float p0 = sp[0 * 256 + tid], p1 = sp[1 * 256 + tid], p2 = sp[2 * 256 + tid];
-    const float p3 = sp[3 * 256 + tid], p4 = sp[4 * 256 + tid], te = sp[5 * 256 + tid];
-    const uint32_t pl = __float_as_uint(sp[6 * 256 + tid]);
-    // exclusive prefix = what the backward adds to the segment-relative bucket states
-    sp[0 * 256 + tid] = C0; sp[1 * 256 + tid] = C1; sp[2 * 256 + tid] = C2;
-    sp[3 * 256 + tid] = D;  sp[4 * 256 + tid] = Wt;
-    C0 += p0; C1 += p1; C2 += p2; D += p3; Wt += p4;     // later segments add exact zeros once stopped
-    if (!stopped) { Tf = fabsf(te); stopped = te < 0.0f; }
-    last = max(last, pl);
+  // The partials of FOUR segments are fetched together before any base is written back (same buffer: the
+  // compiler may not move loads above the stores itself): one load latency per four segments instead of one
+  // per segment - this kernel is nothing but that dependent chain.
+  constexpr uint32_t CG = 4;
+  for (uint32_t k0 = 0; k0 < nseg; k0 += CG) {
+    float* sp0 = segP + (size_t)(ms0 + k0) * HGS_SEG_PLANES * HGS_TILE_PIX;
+    float pv[CG][HGS_SEG_PLANES];
+#pragma unroll
+    for (uint32_t u = 0; u < CG; ++u) {
+      const float* sp = sp0 + (size_t)min(u, nseg - 1u - k0) * HGS_SEG_PLANES * HGS_TILE_PIX;   // clamp: in range
+#pragma unroll
+      for (int pl = 0; pl < HGS_SEG_PLANES; ++pl) pv[u][pl] = sp[pl * 256 + tid];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < CG; ++u) {
+      if (k0 + u < nseg) {
+        float* sp = sp0 + (size_t)u * HGS_SEG_PLANES * HGS_TILE_PIX;
+        // exclusive prefix = what the backward adds to the segment-relative bucket states
+        sp[0 * 256 + tid] = C0; sp[1 * 256 + tid] = C1; sp[2 * 256 + tid] = C2;
+        sp[3 * 256 + tid] = D;  sp[4 * 256 + tid] = Wt;
+        C0 += pv[u][0]; C1 += pv[u][1]; C2 += pv[u][2]; D += pv[u][3]; Wt += pv[u][4];   // later segments add exact zeros once stopped
+        const float te = pv[u][5];
+        if (!stopped) { Tf = fabsf(te); stopped = te < 0.0f; }
+        last = max(last, __float_as_uint(pv[u][6]));
+      }
+    }
   }
   int lx, ly;
   hgs_fwd_thread_pixel(tid, lx, ly);

@@ -5,7 +5,7 @@ set -e
 N=$1; F=$2; R=/root/repo; D=$R/variants/$N; mkdir -p $D
 C=$R/humangaussian_amd/csrc
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC $F -c $C/api.hip -o $D/api.o &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fno-slp-vectorize $F -c $C/render_bwd.hip -o $D/bwd.o &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC $F -c $C/render_bwd.hip -o $D/bwd.o &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC $D/api.o $D/bwd.o -o $D/libhgs_rast.so
 rm -f $D/*.o
