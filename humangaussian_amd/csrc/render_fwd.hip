@@ -62,6 +62,9 @@
 #ifndef HGS_FWD_SCALAR_RECS
 #define HGS_FWD_SCALAR_RECS 0
 #endif
+#ifndef HGS_FWD_SCALAR_POS
+#define HGS_FWD_SCALAR_POS 0
+#endif
 #ifndef HGS_FWD_UNROLL_FEW
 #define HGS_FWD_UNROLL_FEW 4
 #endif
@@ -210,6 +213,23 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
+    }
+#elif HGS_FWD_SCALAR_POS
+    // the list position of a compacted record = the next set bit of the ballot: SALU work instead of a
+    // fourth LDS read per record (the third one shrinks to b, depth)
+    unsigned long long mrem = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ball >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ball);
+    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
+      float4 ra[U], rb[U], rc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t kk = mrem ? (uint32_t)__builtin_ctzll(mrem) : 0u;      // pads: any position, they never blend
+        mrem = mrem ? (mrem & (mrem - 1ull)) : 0ull;
+        ra[u] = srec[3 * (k0 + u) + 0]; rb[u] = srec[3 * (k0 + u) + 1];
+        const float2 t = *reinterpret_cast<const float2*>(&srec[3 * (k0 + u) + 2]);
+        rc[u] = make_float4(t.x, t.y, 0.0f, __uint_as_float(j0 + kk + 1u));
+      }
+      body(ra, rb, rc);
     }
 #else
     for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
