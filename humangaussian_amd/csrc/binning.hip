@@ -273,10 +273,9 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
   }
   // GU records per thread in flight: the 64 B geom gathers are dependent random reads (~1-2 us
   // each); issued one at a time they dominated the sort kernel of the heaviest tile
-#ifndef HGS_GATHER_GU
-#define HGS_GATHER_GU 4
-#endif
-  constexpr int GU = HGS_GATHER_GU;
+  // (1 / 2 in flight: 72 / 85 VGPRs and three / two workgroups per CU instead of two - every tile then starts at
+  // t = 0, but the crowded phase is throughput-bound: 36.2 / 33.2 vs 34.5 us)
+  constexpr int GU = 4;
   for (uint32_t kb = threadIdx.x; kb < n; kb += (uint32_t)nt * GU) {
     uint32_t idxv[GU];
     uint4 q0[GU], q1[GU], q2[GU];
@@ -659,12 +658,7 @@ __device__ __forceinline__ void sort_lds_body(const View& v, const Layout& L, co
 #ifndef HGS_SORT_NT
 #define HGS_SORT_NT 512
 #endif
-#ifdef HGS_SORT_WAVES_PER_EU
-#define HGS_SORT_OCC __attribute__((amdgpu_waves_per_eu(HGS_SORT_WAVES_PER_EU, HGS_SORT_WAVES_PER_EU)))
-#else
-#define HGS_SORT_OCC
-#endif
-extern "C" __global__ void __launch_bounds__(HGS_SORT_NT) HGS_SORT_OCC
+extern "C" __global__ void __launch_bounds__(HGS_SORT_NT)
 hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[4096];
   HGS_TL_BEGIN();

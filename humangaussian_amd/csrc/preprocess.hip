@@ -472,14 +472,11 @@ __device__ __forceinline__ void preprocess_bwd_body(
 #ifndef HGS_ROWS_UNROLL_MANY
 #define HGS_ROWS_UNROLL_MANY 4
 #endif
-#ifndef HGS_ROWS_UNROLL_VPAR
-#define HGS_ROWS_UNROLL_VPAR 1
-#endif
       // Several views: the rows of RU tiles are fetched together (independent loads: one latency round per group
       // instead of one per row - a Gaussian touches 3.3 tiles on average), then added in tile order; 8 views:
       // 95.8 -> 81.8 us.  One view: row by row (grouping measured 15.7 -> 16.3 us: one wave per SIMD has nothing to
       // overlap the wider loads with).
-      constexpr int RU = VPAR ? HGS_ROWS_UNROLL_VPAR : (SINGLE ? 1 : HGS_ROWS_UNROLL_MANY);
+      constexpr int RU = SINGLE ? 1 : HGS_ROWS_UNROLL_MANY;      // (view-parallel form: 1 / 4 / 8 measured, 68.9 / 67.7 / 72.9 us)
       for (int k0 = 0; k0 < tt; k0 += RU) {
         float4 r0[RU], r1[RU], r2[RU];
 #pragma unroll
@@ -792,13 +789,8 @@ __device__ __forceinline__ void preprocess_bwd_body(
 
 }  // namespace
 
-#ifdef HGS_PRE_BWD_WAVES_PER_EU
-#define HGS_PRE_BWD_OCC __attribute__((amdgpu_waves_per_eu(HGS_PRE_BWD_WAVES_PER_EU, HGS_PRE_BWD_WAVES_PER_EU)))
-#else
-#define HGS_PRE_BWD_OCC
-#endif
 #define HGS_PRE_BWD_KERNEL(DEG, NAME, MODE, THREADS)                                                     \
-  extern "C" __global__ void __launch_bounds__(THREADS) HGS_PRE_BWD_OCC NAME(                       \
+  extern "C" __global__ void __launch_bounds__(THREADS) NAME(                                       \
       View v, Layout L, const hgs_status* __restrict__ status, const float* __restrict__ grad_rows, \
       const float* __restrict__ means3D, const float* __restrict__ shs,                             \
       const float* __restrict__ colors_precomp, const float* __restrict__ opacities_raw,            \

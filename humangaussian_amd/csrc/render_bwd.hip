@@ -34,34 +34,16 @@
 // full-batch evaluation the v_pk_* pairs across neighbouring records win: 8 views 441 -> 435 us).
 #include "hgs_common.h"
 
-#ifndef HGS_BWD_PREFETCH
-#define HGS_BWD_PREFETCH 0               // 1: fetch the next quadrant's pixel inputs during the current one (22 more VGPRs;
-                                         // measured neutral, and it pushes the full-batch path over 128 registers)
-#endif
 #ifndef HGS_BWD_BATCH
 #define HGS_BWD_BATCH 8                  // records per MFMA batch (8 records x {k, wgt} = 16 columns).
 #endif                                   // 4 (half-empty MFMAs, 7.8 KB LDS, 5 waves/SIMD) was measured:
                                          // 96 -> 127 us - the fp32 MFMA time is not hidden behind VALU work
-#ifndef HGS_BWD_FULL_BATCH_PATH
-#define HGS_BWD_FULL_BATCH_PATH 1        // branch-free evaluation of full batches (see the loop)
-#endif
-#ifndef HGS_BWD_SCALAR_RECS
-#define HGS_BWD_SCALAR_RECS 0            // 1: the evaluation reads its records through the SCALAR path (s_load from the
-#endif                                   // sorted list, addresses from the quadrant's ballot) instead of three LDS reads
-#ifndef HGS_BWD_SCALAR_SLOT
-#define HGS_BWD_SCALAR_SLOT 1            // the record's slot comes from the quadrant's ballot (SALU) instead of a fourth LDS read
-#endif                                   // per record: render_bwd 73.2 -> 72.2 us, 8 views 433.7 -> 428.6 us
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 #define HGS_PART_FLOATS 10               // sums per (entry, quadrant)
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
 
-#ifdef HGS_BWD_WAVES_PER_EU
-#define HGS_BWD_OCC __attribute__((amdgpu_waves_per_eu(HGS_BWD_WAVES_PER_EU, HGS_BWD_WAVES_PER_EU)))
-#else
-#define HGS_BWD_OCC
-#endif
-extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_WAVES) HGS_BWD_OCC
+extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_WAVES)
 hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const SortRec* __restrict__ recs_all,
                  const float* __restrict__ bstate, const float* __restrict__ segP,
@@ -213,9 +195,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   }
   int jnext = 0;
   while (jnext < QW && cntq[jnext] == 0) ++jnext;
-#if HGS_BWD_PREFETCH
-  PixRaw nxt = fetch(w_begin + min(jnext, QW - 1));
-#endif
 
 #pragma unroll 1
   for (int j = jnext; j < QW; j = jnext) {
@@ -227,17 +206,10 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
     const int px = tile_x0 + ((w & 1) << 3) + (lane & 7), py = tile_y0 + ((w >> 1) << 3) + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
-#if HGS_BWD_PREFETCH
-    const PixRaw cur = nxt;
-#else
-    const PixRaw cur = fetch(w);
-#endif
+    const PixRaw cur = fetch(w);       // (fetching one quadrant ahead: 22 more VGPRs, measured neutral)
     const uint32_t nc = ncq[j];
     jnext = j + 1;
     while (jnext < QW && cntq[jnext] == 0) ++jnext;
-#if HGS_BWD_PREFETCH
-    if (jnext < QW) nxt = fetch(w_begin + jnext);    // in flight during this quadrant's loop
-#endif
     const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2, gd = cur.gd, ga = cur.ga;
     const float fp = cur.o0 * g0 + cur.o1 * g1 + cur.o2 * g2 + cur.od * gd + cur.oa * ga;
     // running state at the bucket start.  A pixel with n_contrib <= q0 finished before this
@@ -345,29 +317,10 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     HGS_TSTART();
     // one record of the batch: everything that depends on (pixel, record); T and F are the only
     // values carried from record to record
-#if HGS_BWD_SCALAR_RECS
-    // the quadrant's kept records, in list order = the set bits of its ballot: wave-uniform addresses,
-    // so the compiler fetches the record with s_load_dwordx4 into SGPRs (no LDS pipe, no VGPRs)
-    unsigned long long mrem = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ball >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ball);
-    const float4* __restrict__ brecs4 = reinterpret_cast<const float4*>(brecs);
-    auto eval_record = [&](uint32_t /*idx*/, float& kq, float& wgt) {
-      const uint32_t slot = (uint32_t)__builtin_ctzll(mrem);
-      mrem &= mrem - 1ull;
-#if HGS_BWD_SCALAR_RECS == 2
-      // ... or straight from the registers that hold the bucket (lane = slot): v_readlane into SGPRs
-      auto rl = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (int)slot)); };
-      const float4 r0 = make_float4(rl(c0.x), rl(c0.y), rl(c0.z), rl(c0.w));    // mx my qa qb
-      const float4 r1 = make_float4(rl(c1.x), rl(c1.y), rl(c1.z), rl(c1.w));    // qc op r g
-      const float2 r2 = make_float2(rl(c2.x), rl(c2.y));                        // b depth
-#else
-      const float4 r0 = brecs4[3 * slot + 0];    // mx my qa qb
-      const float4 r1 = brecs4[3 * slot + 1];    // qc op r g
-      const float2 r2 = *reinterpret_cast<const float2*>(&brecs4[3 * slot + 2]);    // b depth
-#endif
-#elif HGS_BWD_SCALAR_SLOT
     // the record's slot in the bucket = the position of the next set bit of the quadrant's ballot: SALU
-    // work, so the third LDS read shrinks from 16 to 8 bytes per lane (b, depth)
+    // work instead of a fourth LDS read per record (73.2 -> 72.2 us, 8 views 433.7 -> 428.6: the LDS pipe is
+    // the co-limit of this kernel).  Reading the whole record through the scalar cache (s_load from the
+    // sorted list) or with v_readlane from the bucket's registers was measured too: 77 -> 89 us both.
     unsigned long long mrem = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ball >> 32)) << 32) |
                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ball);
     auto eval_record = [&](uint32_t idx, float& kq, float& wgt) {
@@ -376,13 +329,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float4 r0 = s_rec[3 * idx + 0];    // mx my qa qb
       const float4 r1 = s_rec[3 * idx + 1];    // qc op r g
       const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[3 * idx + 2]);    // b depth
-#else
-    auto eval_record = [&](uint32_t idx, float& kq, float& wgt) {
-      const float4 r0 = s_rec[3 * idx + 0];    // mx my qa qb
-      const float4 r1 = s_rec[3 * idx + 1];    // qc op r g
-      const float4 r2 = s_rec[3 * idx + 2];    // b depth entry slot
-      const uint32_t slot = __float_as_uint(r2.w);
-#endif
       // same dx/dy expressions as the forward so skip decisions agree
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       float G, alpha, m2, m3;
@@ -405,7 +351,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     };
     for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_BWD_BATCH) {
       const uint32_t nrec = min((uint32_t)HGS_BWD_BATCH, cnt - k0);
-#if HGS_BWD_FULL_BATCH_PATH
       if (nrec == HGS_BWD_BATCH) {
         // FULL batch (three of four at config 2): no per-record branch, ONE basic block for the eight
         // records, so the scheduler overlaps the LDS reads and the exp / rcp latencies of one record
@@ -419,9 +364,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           stage[u * HGS_STAGE_STRIDE + lane] = kqv[u];
           stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgv[u];
         }
-      } else
-#endif
-      {
+      } else {
 #pragma unroll
         for (int u = 0; u < HGS_BWD_BATCH; ++u) {
           float kq = 0.0f, wgt = 0.0f;

@@ -51,20 +51,6 @@
 #ifndef HGS_BWD_COST_2
 #define HGS_BWD_COST_2 40
 #endif
-#ifndef HGS_FWD_PRIO
-#define HGS_FWD_PRIO 0
-#endif
-#ifndef HGS_FWD_PRIO_3
-#define HGS_FWD_PRIO_3 768
-#define HGS_FWD_PRIO_2 512
-#define HGS_FWD_PRIO_1 256
-#endif
-#ifndef HGS_FWD_SCALAR_RECS
-#define HGS_FWD_SCALAR_RECS 0
-#endif
-#ifndef HGS_FWD_SCALAR_POS
-#define HGS_FWD_SCALAR_POS 0
-#endif
 #ifndef HGS_FWD_UNROLL_FEW
 #define HGS_FWD_UNROLL_FEW 4
 #endif
@@ -112,50 +98,6 @@ __device__ __forceinline__ void tprod_one(float& P, float pxf, float pyf, const 
 // Wave-level walk over list entries [q_begin, q_end) of one tile: loads, compaction, and a
 // callback per group of 4 compacted records.  BODY(ra, rb, rc) gets float4[4] arrays;
 // PRE(j0) runs at every bucket start (bucket-state stores); ALIVE() lets the wave stop early.
-#if HGS_FWD_SCALAR_RECS
-// Scalar-path variant: the lanes only fetch their record's cull-mask word; the kept records (the set
-// bits of the ballot, in list order) are then read with wave-uniform addresses, which the compiler
-// turns into s_load_dwordx8 / x2 into SGPRs - the blend loop uses no LDS and no record VGPRs.
-template <int U, typename Pre, typename Alive, typename Body>
-__device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, uint32_t q_begin,
-                                             uint32_t q_end, uint32_t wbit, float4* __restrict__ /*srec*/,
-                                             int lane, Pre pre, Alive alive, Body body) {
-  const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(recs);
-  uint32_t cw = 0;
-  {
-    const uint32_t q = q_begin + lane;
-    if (q < q_end) cw = words[12 * q + 11];
-  }
-  for (uint32_t j0 = q_begin; j0 < q_end; j0 += HGS_BUCKET) {
-    if (!alive()) break;
-    const uint32_t qn = j0 + HGS_BUCKET + lane;
-    uint32_t nw = 0;
-    if (qn < q_end) nw = words[12 * qn + 11];          // next bucket's mask words, in flight during this bucket
-    const unsigned long long ball = __ballot((cw & wbit) != 0u);     // lanes beyond q_end hold 0
-    const uint32_t cnt = (uint32_t)__popcll(ball);
-    pre(j0, cnt);
-    unsigned long long mrem = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ball >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ball);
-    const float4* __restrict__ brec = recs + 3 * (size_t)j0;
-    while (mrem) {
-      float4 ra[U], rb[U], rc[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool valid = mrem != 0ull;
-        const uint32_t kk = valid ? (uint32_t)__builtin_ctzll(mrem) : 0u;
-        mrem = valid ? (mrem & (mrem - 1ull)) : 0ull;
-        ra[u] = brec[3 * kk + 0];
-        rb[u] = brec[3 * kk + 1];
-        const float2 t = *reinterpret_cast<const float2*>(&brec[3 * kk + 2]);
-        if (!valid) rb[u].y = 0.0f;                       // pad: opacity 0 => alpha 0 => skipped
-        rc[u] = make_float4(t.x, t.y, 0.0f, __uint_as_float(j0 + kk + 1u));
-      }
-      body(ra, rb, rc);
-    }
-    cw = nw;
-  }
-}
-#else
 template <int U, typename Pre, typename Alive, typename Body>
 __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, uint32_t q_begin,
                                              uint32_t q_end, uint32_t wbit, float4* __restrict__ srec,
@@ -194,44 +136,6 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-#ifdef HGS_FWD_LDS_PREFETCH
-    // register double buffer: the LDS reads of group g+1 are in flight while group g blends
-    float4 ra[U], rb[U], rc[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      ra[u] = srec[3 * u + 0]; rb[u] = srec[3 * u + 1]; rc[u] = srec[3 * u + 2];
-    }
-    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
-      float4 na[U], nb[U], nc[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t k = k0 + U + u;          // <= cnt + 2U - 1: inside the pads
-        na[u] = srec[3 * k + 0]; nb[u] = srec[3 * k + 1]; nc[u] = srec[3 * k + 2];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      body(ra, rb, rc);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
-    }
-#elif HGS_FWD_SCALAR_POS
-    // the list position of a compacted record = the next set bit of the ballot: SALU work instead of a
-    // fourth LDS read per record (the third one shrinks to b, depth)
-    unsigned long long mrem = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ball >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ball);
-    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
-      float4 ra[U], rb[U], rc[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t kk = mrem ? (uint32_t)__builtin_ctzll(mrem) : 0u;      // pads: any position, they never blend
-        mrem = mrem ? (mrem & (mrem - 1ull)) : 0ull;
-        ra[u] = srec[3 * (k0 + u) + 0]; rb[u] = srec[3 * (k0 + u) + 1];
-        const float2 t = *reinterpret_cast<const float2*>(&srec[3 * (k0 + u) + 2]);
-        rc[u] = make_float4(t.x, t.y, 0.0f, __uint_as_float(j0 + kk + 1u));
-      }
-      body(ra, rb, rc);
-    }
-#else
     for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
       float4 ra[U], rb[U], rc[U];
 #pragma unroll
@@ -240,12 +144,10 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ recs, ui
       }
       body(ra, rb, rc);
     }
-#endif
     c0 = n0; c1 = n1; c2 = n2;
   }
 }
 
-#endif
 
 }  // namespace
 
@@ -353,17 +255,6 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
     __syncthreads();
   }
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all + start);
-#if HGS_FWD_PRIO
-  {
-    // Issue priority by the length of the chain this wave has to walk (wave-uniform): the kernel ends
-    // with its longest chains, and those should not share their SIMD's issue slots equally with
-    // the thousands of short ones.
-    const uint32_t work = nseg > 1 ? (k + 1) * HGS_SEG : n;
-    if (work >= HGS_FWD_PRIO_3) __builtin_amdgcn_s_setprio(3);
-    else if (work >= HGS_FWD_PRIO_2) __builtin_amdgcn_s_setprio(2);
-    else if (work >= HGS_FWD_PRIO_1) __builtin_amdgcn_s_setprio(1);
-  }
-#endif
 
   PixState s;
   s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
