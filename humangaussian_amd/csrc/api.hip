@@ -518,12 +518,13 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
                      dL_dcov3D_precomp)
   // One view: the instantiation without the loop over views (94 instead of 176 VGPRs at SH degree 0).  Several
   // views: one thread per (Gaussian, view) - a workgroup of B waves per 64 Gaussians, summed in view order
-  // through LDS (preprocess.hip, mode 2); SH degree >= 2 with more than 8 views: the loop (registers, LDS).
+  // through LDS (preprocess.hip, mode 2); combinations whose exchange buffer would not fit: the loop.
   const int deg = shs ? v.D : 0;
   const int nc = (deg + 1) * (deg + 1);
   const unsigned thr_p = 64u * (unsigned)v.B, grid_p = (unsigned)((v.P + 63) / 64);
   const size_t lds_p = (size_t)(20 + 3 * nc) * thr_p * sizeof(float);
-  const bool vpar_ok = v.B >= HGS_PRE_BWD_VPAR_MIN_VIEWS && v.B <= (deg >= 2 ? 8 : 16);
+  // (the exchange buffer is kept within 64 KB of dynamic LDS: 11 views at SH degree 0, 8 at degree 1, 5 / 3 at degrees 2 / 3)
+  const bool vpar_ok = v.B >= HGS_PRE_BWD_VPAR_MIN_VIEWS && v.B <= (deg >= 2 ? 8 : 16) && lds_p <= 65536;
   const int mode = v.B == 1 ? 1 : (vpar_ok ? 2 : 0);
   switch (deg + 4 * mode) {
     case 0: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d0, v.nblk, HGS_BLOCK, 0); break;
