@@ -51,12 +51,18 @@
 #ifndef HGS_BWD_COST_2
 #define HGS_BWD_COST_2 40
 #endif
+#ifndef HGS_FWD_PAIRS
+#define HGS_FWD_PAIRS 1          // calls of few views walk the lists with the PAIRED record stage (below): same bits
+#endif                           // (tools/cmp_variant.py), 4.3 fewer VALU and 1.3 fewer LDS instructions per record,
+                                 // render_fwd 70 -> 67 us; the many-view instantiation keeps the plain stage (its 64
+                                 // registers / 8 waves per SIMD would become 68 / 7; not measured yet)
 #ifndef HGS_FWD_UNROLL_FEW
 #define HGS_FWD_UNROLL_FEW 4
 #endif
 #ifndef HGS_FWD_UNROLL_MANY
 #define HGS_FWD_UNROLL_MANY 2
 #endif
+__host__ __device__ constexpr bool hgs_fwd_pairs(int unroll) { return HGS_FWD_PAIRS && unroll == HGS_FWD_UNROLL_FEW; }
 
 namespace {
 
@@ -95,6 +101,121 @@ __device__ __forceinline__ void tprod_one(float& P, float pxf, float pyf, const 
   P *= keep ? (1.0f - alpha) : 1.0f;
 }
 
+// ---- PAIRED record stage (calls of few views, HGS_FWD_PAIRS).  The ISA of the loops below spends 4.3 of its
+// 24 VALU instructions per record on v_mov_b32: the compiler packs the alpha arithmetic of two
+// neighbouring records into v_pk_* instructions and has to shuffle (mx_u, mx_u+1) ... into register
+// pairs first.  Here the compaction writes two records INTERLEAVED (24 dwords per pair)
+//   mx0 mx1 my0 my1 | qa0 qa1 qb0 qb1 | qc0 qc1 op0 op1 | r0 g0 b0 d0 | r1 g1 b1 d1 | pos0 pos1 - -
+// so that every ds_read_b128 already returns operand pairs: the per-record alpha evaluation runs packed
+// across the two records, the colour / depth accumulation packed across channels, and the T chain stays
+// scalar.  Same operations per element as blend_one / tprod_one (same bits).
+typedef float hgs_f2 __attribute__((ext_vector_type(2)));
+struct RecPair { float4 A, B, C, D0, D1; float2 E; };
+
+__device__ __forceinline__ RecPair load_pair(const float* __restrict__ blk) {
+  RecPair r;
+  r.A = *reinterpret_cast<const float4*>(blk + 0);
+  r.B = *reinterpret_cast<const float4*>(blk + 4);
+  r.C = *reinterpret_cast<const float4*>(blk + 8);
+  r.D0 = *reinterpret_cast<const float4*>(blk + 12);
+  r.D1 = *reinterpret_cast<const float4*>(blk + 16);
+  r.E = *reinterpret_cast<const float2*>(blk + 20);
+  return r;
+}
+
+// alpha of the two records at the lane's pixel: hgs_eval_alpha on both halves of the pair
+__device__ __forceinline__ void pair_alpha(const RecPair& r, float pxf, float pyf, float (&alpha)[2], bool (&keep)[2]) {
+  const hgs_f2 dx = hgs_f2{r.A.x, r.A.y} - hgs_f2{pxf, pxf};
+  const hgs_f2 dy = hgs_f2{r.A.z, r.A.w} - hgs_f2{pyf, pyf};
+  const hgs_f2 m2 = __builtin_elementwise_fma(hgs_f2{r.B.x, r.B.y}, dx, hgs_f2{r.B.z, r.B.w} * dy);
+  const hgs_f2 m3 = hgs_f2{r.C.x, r.C.y} * dy;
+  const hgs_f2 p2 = __builtin_elementwise_fma(dx, m2, m3 * dy);
+  const hgs_f2 G = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+  const hgs_f2 og = hgs_f2{r.C.z, r.C.w} * G;
+  alpha[0] = fminf(HGS_ALPHA_MAX, og.x);
+  alpha[1] = fminf(HGS_ALPHA_MAX, og.y);
+  keep[0] = (p2.x <= 0.0f) && (alpha[0] >= HGS_ALPHA_MIN);
+  keep[1] = (p2.y <= 0.0f) && (alpha[1] >= HGS_ALPHA_MIN);
+}
+
+__device__ __forceinline__ void blend_pair(PixState& s, float pxf, float pyf, const RecPair& r) {
+  float alpha[2];
+  bool keep[2];
+  pair_alpha(r, pxf, pyf, alpha, keep);
+  hgs_f2 c01 = {s.C0, s.C1}, c2d = {s.C2, s.D};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 col = h ? r.D1 : r.D0;
+    const bool live = keep[h] && !s.done;
+    const float test_T = s.T * (1.0f - alpha[h]);
+    const bool stop = live && (test_T < HGS_T_EPS);
+    const bool upd = live && !stop;
+    s.done = s.done || stop;
+    const float wgt = upd ? alpha[h] * s.T : 0.0f;
+    c01 = __builtin_elementwise_fma(hgs_f2{col.x, col.y}, hgs_f2{wgt, wgt}, c01);
+    c2d = __builtin_elementwise_fma(hgs_f2{col.z, col.w}, hgs_f2{wgt, wgt}, c2d);
+    s.Wt += wgt;
+    s.T = upd ? test_T : s.T;
+    s.last = upd ? __float_as_uint(h ? r.E.y : r.E.x) : s.last;
+  }
+  s.C0 = c01.x; s.C1 = c01.y; s.C2 = c2d.x; s.D = c2d.y;
+}
+
+__device__ __forceinline__ void tprod_pair(float& P, float pxf, float pyf, const RecPair& r) {
+  float alpha[2];
+  bool keep[2];
+  pair_alpha(r, pxf, pyf, alpha, keep);
+  P *= keep[0] ? (1.0f - alpha[0]) : 1.0f;
+  P *= keep[1] ? (1.0f - alpha[1]) : 1.0f;
+}
+
+// Same walk as walk_segment below; BODY gets U / 2 record pairs.
+template <int U, typename Pre, typename Alive, typename Body>
+__device__ __forceinline__ void walk_segment_pairs(const float4* __restrict__ recs, uint32_t q_begin,
+                                             uint32_t q_end, uint32_t wbit, float4* __restrict__ srec,
+                                             int lane, Pre pre, Alive alive, Body body) {
+  static_assert(U % 2 == 0, "pairs");
+  float* __restrict__ sf = reinterpret_cast<float*>(srec);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 c0 = zero4, c1 = zero4, c2 = zero4;
+  {
+    const uint32_t q = q_begin + lane;
+    if (q < q_end) { c0 = recs[3 * q + 0]; c1 = recs[3 * q + 1]; c2 = recs[3 * q + 2]; }
+  }
+  // one record into its half of its pair block
+  auto put = [&](uint32_t p, const float4 a, const float4 b, const float4 c, float posf) {
+    float* blk = sf + (p >> 1) * 24u;
+    const uint32_t h = p & 1u;
+    blk[0 + h] = a.x; blk[2 + h] = a.y; blk[4 + h] = a.z; blk[6 + h] = a.w;     // mx my qa qb
+    blk[8 + h] = b.x; blk[10 + h] = b.y;                                        // qc op
+    *reinterpret_cast<float4*>(blk + 12 + 4 * h) = make_float4(b.z, b.w, c.x, c.y);   // r g b depth
+    blk[20 + h] = posf;
+  };
+  for (uint32_t j0 = q_begin; j0 < q_end; j0 += HGS_BUCKET) {
+    if (!alive()) break;
+    const uint32_t qn = j0 + HGS_BUCKET + lane;
+    float4 n0 = zero4, n1 = zero4, n2 = zero4;
+    if (qn < q_end) { n0 = recs[3 * qn + 0]; n1 = recs[3 * qn + 1]; n2 = recs[3 * qn + 2]; }
+    const bool hit = (j0 + lane < q_end) && ((__float_as_uint(c2.w) & wbit) != 0u);
+    const unsigned long long ball = __ballot(hit);
+    const uint32_t cnt = (uint32_t)__popcll(ball);
+    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
+    pre(j0, cnt);
+    __builtin_amdgcn_wave_barrier();                 // previous bucket's reads are done
+    if (hit) put(pos, c0, c1, c2, __uint_as_float(j0 + lane + 1));
+    if (lane < 2 * U) put(cnt + lane, zero4, zero4, zero4, 0.0f);      // pads: opacity 0 => alpha 0 => skipped
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k0 = 0; k0 < cnt; k0 += U) {
+      RecPair rp[U / 2];
+#pragma unroll
+      for (int u = 0; u < U / 2; ++u) rp[u] = load_pair(sf + ((k0 >> 1) + u) * 24u);
+      body(rp);
+    }
+    c0 = n0; c1 = n1; c2 = n2;
+  }
+}
 // Wave-level walk over list entries [q_begin, q_end) of one tile: loads, compaction, and a
 // callback per group of 4 compacted records.  BODY(ra, rb, rc) gets float4[4] arrays;
 // PRE(j0) runs at every bucket start (bucket-state stores); ALIVE() lets the wave stop early.
@@ -156,12 +277,21 @@ template <int U>
 __device__ __forceinline__ float segment_tprod(const float4* __restrict__ recs, uint32_t i, int w,
                                                float4* __restrict__ srec, int lane, float pxf, float pyf) {
   float P = 1.0f;
-  walk_segment<U>(recs, i * HGS_SEG, (i + 1) * HGS_SEG, 1u << (28 + w), srec, lane,
-               [](uint32_t, uint32_t) {}, [] { return true; },
-               [&](const float4 (&ra)[U], const float4 (&rb)[U], const float4 (&)[U]) {
+  if constexpr (hgs_fwd_pairs(U)) {
+    walk_segment_pairs<U>(recs, i * HGS_SEG, (i + 1) * HGS_SEG, 1u << (28 + w), srec, lane,
+                          [](uint32_t, uint32_t) {}, [] { return true; },
+                          [&](const RecPair (&rp)[U / 2]) {
 #pragma unroll
-                 for (int u = 0; u < U; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
-               });
+                            for (int u = 0; u < U / 2; ++u) tprod_pair(P, pxf, pyf, rp[u]);
+                          });
+  } else {
+    walk_segment<U>(recs, i * HGS_SEG, (i + 1) * HGS_SEG, 1u << (28 + w), srec, lane,
+                    [](uint32_t, uint32_t) {}, [] { return true; },
+                    [&](const float4 (&ra)[U], const float4 (&rb)[U], const float4 (&)[U]) {
+#pragma unroll
+                      for (int u = 0; u < U; ++u) tprod_one(P, pxf, pyf, ra[u], rb[u]);
+                    });
+  }
   return P;
 }
 
@@ -272,28 +402,35 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L, 
 
   const uint32_t seg_begin = nseg > 1 ? k * HGS_SEG : 0u, seg_end = nseg > 1 ? min(n, (k + 1) * HGS_SEG) : n;
   uint32_t wcost = 0;                               // this wave's kept records per bucket (lane = bucket)
-  walk_segment<U>(
-      recs, seg_begin, seg_end, 1u << (28 + w), s_rec[w], lane,
-      [&](uint32_t j0, uint32_t cnt) {
-        // kept pairs per bucket: few views - lane i of a per-wave register keeps bucket i's count (one LDS atomic per
-        // wave at the end); many views - one LDS add per bucket (the register would cost the eighth wave per SIMD)
-        if (STORE && FINE_CLASSES) wcost = ((uint32_t)lane == (j0 - seg_begin) / HGS_BUCKET) ? cnt : wcost;
-        if (STORE && !FINE_CLASSES && lane == 0 && cnt) atomicAdd(&s_cost[(j0 - seg_begin) / HGS_BUCKET], cnt);
-        if (STORE && j0 > 0) {
-          float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
-          bs[0 * 256 + tid] = s.T;
-          bs[1 * 256 + tid] = s.C0;
-          bs[2 * 256 + tid] = s.C1;
-          bs[3 * 256 + tid] = s.C2;
-          bs[4 * 256 + tid] = s.D;
-          bs[5 * 256 + tid] = s.Wt;
-        }
-      },
-      [&] { return __ballot(!s.done) != 0ull; },      // stop when every pixel is finished
-      [&](const float4 (&ra)[U], const float4 (&rb)[U], const float4 (&rc)[U]) {
+  auto at_bucket = [&](uint32_t j0, uint32_t cnt) {
+    // kept pairs per bucket: few views - lane i of a per-wave register keeps bucket i's count (one LDS atomic per
+    // wave at the end); many views - one LDS add per bucket (the register would cost the eighth wave per SIMD)
+    if (STORE && FINE_CLASSES) wcost = ((uint32_t)lane == (j0 - seg_begin) / HGS_BUCKET) ? cnt : wcost;
+    if (STORE && !FINE_CLASSES && lane == 0 && cnt) atomicAdd(&s_cost[(j0 - seg_begin) / HGS_BUCKET], cnt);
+    if (STORE && j0 > 0) {
+      float* bs = bstate + (size_t)(bstart + j0 / HGS_BUCKET - 1) * HGS_BSTATE_FLOATS;
+      bs[0 * 256 + tid] = s.T;
+      bs[1 * 256 + tid] = s.C0;
+      bs[2 * 256 + tid] = s.C1;
+      bs[3 * 256 + tid] = s.C2;
+      bs[4 * 256 + tid] = s.D;
+      bs[5 * 256 + tid] = s.Wt;
+    }
+  };
+  auto any_pixel_left = [&] { return __ballot(!s.done) != 0ull; };      // stop when every pixel is finished
+  if constexpr (hgs_fwd_pairs(U)) {
+    walk_segment_pairs<U>(recs, seg_begin, seg_end, 1u << (28 + w), s_rec[w], lane, at_bucket, any_pixel_left,
+                          [&](const RecPair (&rp)[U / 2]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
-      });
+                            for (int u = 0; u < U / 2; ++u) blend_pair(s, pxf, pyf, rp[u]);
+                          });
+  } else {
+    walk_segment<U>(recs, seg_begin, seg_end, 1u << (28 + w), s_rec[w], lane, at_bucket, any_pixel_left,
+                    [&](const float4 (&ra)[U], const float4 (&rb)[U], const float4 (&rc)[U]) {
+#pragma unroll
+                      for (int u = 0; u < U; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
+                    });
+  }
 
   if (nseg == 1) {
     if (inside) {
