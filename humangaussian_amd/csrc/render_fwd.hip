@@ -62,7 +62,9 @@
 #ifndef HGS_FWD_UNROLL_MANY
 #define HGS_FWD_UNROLL_MANY 2
 #endif
-__host__ __device__ constexpr bool hgs_fwd_pairs(int unroll) { return HGS_FWD_PAIRS && unroll == HGS_FWD_UNROLL_FEW; }
+__host__ __device__ constexpr bool hgs_fwd_pairs(int unroll) {      // HGS_FWD_PAIRS = 2: every instantiation (to be measured)
+  return HGS_FWD_PAIRS == 2 || (HGS_FWD_PAIRS == 1 && unroll == HGS_FWD_UNROLL_FEW);
+}
 
 namespace {
 
