@@ -38,12 +38,25 @@
 #define HGS_BWD_BATCH 8                  // records per MFMA batch (8 records x {k, wgt} = 16 columns).
 #endif                                   // 4 (half-empty MFMAs, 7.8 KB LDS, 5 waves/SIMD) was measured:
                                          // 96 -> 127 us - the fp32 MFMA time is not hidden behind VALU work
+#ifndef HGS_BWD_PAIRS
+#define HGS_BWD_PAIRS 0                  // 1 (NOT measured / verified yet - check with tools/cmp_variant.py first): paired record
+#endif                                   // stage like the forward's: two compacted records interleaved in LDS,
+                                         //   mx0 mx1 my0 my1 | qa0 qa1 qb0 qb1 | qc0 qc1 op0 op1 | r0 r1 g0 g1 | b0 b1 d0 d1 | slot0 slot1
+                                         // so that the record-parallel part of the evaluation (alpha, S, 1 - a) runs in
+                                         // v_pk_* across the pair without register shuffles: 21.5 instead of 29 VALU
+                                         // instructions per record by the ISA; T and F stay a scalar chain
+typedef float hgs_f2 __attribute__((ext_vector_type(2)));
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 #define HGS_PART_FLOATS 10               // sums per (entry, quadrant)
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
 
-extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_WAVES)
+#if HGS_BWD_PAIRS
+#define HGS_BWD_OCC __attribute__((amdgpu_num_vgpr(112)))     // 112 + 16 (8 accumulators, 8 spill slots in AGPRs): keeps 4 waves per SIMD
+#else
+#define HGS_BWD_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_WAVES) HGS_BWD_OCC
 hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const SortRec* __restrict__ recs_all,
                  const float* __restrict__ bstate, const float* __restrict__ segP,
@@ -262,11 +275,22 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();                 // basis reads done: its scratch may be overwritten
+#if HGS_BWD_PAIRS
+    float* __restrict__ s_recf = reinterpret_cast<float*>(s_rec);
+    // field f (0 mx, 1 my, 2 qa, 3 qb, 4 qc, 5 op, 6 r, 7 g, 8 b, 9 depth, 10 slot) of compacted record p
+    auto rec_at = [&](uint32_t p2_, int f) -> float& { return s_recf[(p2_ >> 1) * 24u + 2u * (uint32_t)f + (p2_ & 1u)]; };
+    if (hit) {
+      rec_at(pos, 0) = c0.x; rec_at(pos, 1) = c0.y; rec_at(pos, 2) = c0.z; rec_at(pos, 3) = c0.w;
+      rec_at(pos, 4) = c1.x; rec_at(pos, 5) = c1.y; rec_at(pos, 6) = c1.z; rec_at(pos, 7) = c1.w;
+      rec_at(pos, 8) = c2.x; rec_at(pos, 9) = c2.y; rec_at(pos, 10) = __uint_as_float((uint32_t)lane);   // slot in bucket
+    }
+#else
     if (hit) {
       s_rec[3 * pos + 0] = c0;
       s_rec[3 * pos + 1] = c1;
       s_rec[3 * pos + 2] = make_float4(c2.x, c2.y, c2.z, __uint_as_float((uint32_t)lane));   // slot in bucket
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const float cxq = (float)(tile_x0 + ((w & 1) << 3)) + 3.5f;
@@ -280,9 +304,16 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float k11 = __shfl(d0, (lane + 16) & 63, 64), k02 = __shfl(d1, (lane + 16) & 63, 64);
       const uint32_t rsel = (uint32_t)lane & (HGS_BWD_BATCH - 1);   // record of the batch this lane finishes
       if (rsel >= nrec) return;
+#if HGS_BWD_PAIRS
+      const uint32_t pr_ = k0 + rsel;
+      const float4 q0r = make_float4(rec_at(pr_, 0), rec_at(pr_, 1), rec_at(pr_, 2), rec_at(pr_, 3));
+      const float4 q1r = make_float4(rec_at(pr_, 4), 0.f, 0.f, 0.f);
+      const uint32_t slot_l = __float_as_uint(rec_at(pr_, 10));
+#else
       const float4 q0r = s_rec[3 * (k0 + rsel) + 0];
       const float4 q1r = s_rec[3 * (k0 + rsel) + 1];
       const uint32_t slot_l = __float_as_uint(s_rec[3 * (k0 + rsel) + 2].w);
+#endif
       float* dst = &s_part[slot_l][0];
       if (lane < HGS_BWD_BATCH) {
         const float a = q0r.x - cxq, bb = q0r.y - cyq;
@@ -326,9 +357,15 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     auto eval_record = [&](uint32_t idx, float& kq, float& wgt) {
       const uint32_t slot = (uint32_t)__builtin_ctzll(mrem);
       mrem &= mrem - 1ull;
+#if HGS_BWD_PAIRS                              // (partial batches only: single records out of the paired layout)
+      const float4 r0 = make_float4(rec_at(idx, 0), rec_at(idx, 1), rec_at(idx, 2), rec_at(idx, 3));
+      const float4 r1 = make_float4(rec_at(idx, 4), rec_at(idx, 5), rec_at(idx, 6), rec_at(idx, 7));
+      const float2 r2 = make_float2(rec_at(idx, 8), rec_at(idx, 9));
+#else
       const float4 r0 = s_rec[3 * idx + 0];    // mx my qa qb
       const float4 r1 = s_rec[3 * idx + 1];    // qc op r g
       const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[3 * idx + 2]);    // b depth
+#endif
       // same dx/dy expressions as the forward so skip decisions agree
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       float G, alpha, m2, m3;
@@ -349,6 +386,50 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       T *= om;
       kq = am * dLda;                            // k = dL/dG * G
     };
+#if HGS_BWD_PAIRS
+    // two records of a full batch: the same operations per element as eval_record (same bits); the record-parallel
+    // part packed across the pair, then the T / F chain for record 0 and record 1 in list order
+    auto eval_pair = [&](uint32_t pair, float& kq0, float& wgt0, float& kq1, float& wgt1) {
+      const float* __restrict__ blk = s_recf + pair * 24u;
+      const float4 A = *reinterpret_cast<const float4*>(blk + 0);     // mx0 mx1 my0 my1
+      const float4 Bq = *reinterpret_cast<const float4*>(blk + 4);    // qa0 qa1 qb0 qb1
+      const float4 Cq = *reinterpret_cast<const float4*>(blk + 8);    // qc0 qc1 op0 op1
+      const float4 D = *reinterpret_cast<const float4*>(blk + 12);    // r0 r1 g0 g1
+      const float4 E = *reinterpret_cast<const float4*>(blk + 16);    // b0 b1 d0 d1
+      const uint32_t slot0 = (uint32_t)__builtin_ctzll(mrem);
+      mrem &= mrem - 1ull;
+      const uint32_t slot1 = (uint32_t)__builtin_ctzll(mrem);
+      mrem &= mrem - 1ull;
+      const hgs_f2 dx = hgs_f2{A.x, A.y} - hgs_f2{pxf, pxf};
+      const hgs_f2 dy = hgs_f2{A.z, A.w} - hgs_f2{pyf, pyf};
+      const hgs_f2 m2 = __builtin_elementwise_fma(hgs_f2{Bq.x, Bq.y}, dx, hgs_f2{Bq.z, Bq.w} * dy);
+      const hgs_f2 m3 = hgs_f2{Cq.x, Cq.y} * dy;
+      const hgs_f2 p2 = __builtin_elementwise_fma(dx, m2, m3 * dy);
+      const hgs_f2 G = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+      const hgs_f2 og = hgs_f2{Cq.z, Cq.w} * G;                        // op * G
+      const bool keep0 = (p2.x <= 0.0f) && (fminf(HGS_ALPHA_MAX, og.x) >= HGS_ALPHA_MIN);
+      const bool keep1 = (p2.y <= 0.0f) && (fminf(HGS_ALPHA_MAX, og.y) >= HGS_ALPHA_MIN);
+      const bool act0 = keep0 & (q0 + slot0 < nc), act1 = keep1 & (q0 + slot1 < nc);
+      const float am0 = act0 ? og.x : 0.0f, am1 = act1 ? og.y : 0.0f;     // un-clamped alpha, 0 when inactive
+      const hgs_f2 a = {fminf(HGS_ALPHA_MAX, am0), fminf(HGS_ALPHA_MAX, am1)};
+      const hgs_f2 S = __builtin_elementwise_fma(hgs_f2{D.x, D.y}, hgs_f2{g0, g0},
+                       __builtin_elementwise_fma(hgs_f2{D.z, D.w}, hgs_f2{g1, g1},
+                       __builtin_elementwise_fma(hgs_f2{E.x, E.y}, hgs_f2{g2, g2},
+                       __builtin_elementwise_fma(hgs_f2{E.z, E.w}, hgs_f2{gd, gd}, hgs_f2{ga, ga}))));
+      const hgs_f2 om = hgs_f2{1.0f, 1.0f} - a;
+      const float ri0 = __builtin_amdgcn_rcpf(om.x), ri1 = __builtin_amdgcn_rcpf(om.y);
+      wgt0 = a.x * T;
+      F = __builtin_fmaf(wgt0, S.x, F);
+      const float dLda0 = __builtin_fmaf(T, S.x, -((fp - F) * ri0));
+      T *= om.x;
+      kq0 = am0 * dLda0;
+      wgt1 = a.y * T;
+      F = __builtin_fmaf(wgt1, S.y, F);
+      const float dLda1 = __builtin_fmaf(T, S.y, -((fp - F) * ri1));
+      T *= om.y;
+      kq1 = am1 * dLda1;
+    };
+#endif
     for (uint32_t k0 = 0; k0 < cnt; k0 += HGS_BWD_BATCH) {
       const uint32_t nrec = min((uint32_t)HGS_BWD_BATCH, cnt - k0);
       if (nrec == HGS_BWD_BATCH) {
@@ -356,6 +437,19 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         // records, so the scheduler overlaps the LDS reads and the exp / rcp latencies of one record
         // with the arithmetic of its neighbours.  (With a wave-uniform `u < nrec` test per record
         // every record was its own block: read, wait, compute - 14 cycles per instruction per wave.)
+#if HGS_BWD_PAIRS
+#pragma unroll
+        for (int u = 0; u < HGS_BWD_BATCH; u += 2) {      // staged pair by pair: the results do not pile up in registers
+          float kqa, wga, kqb, wgb;
+          // (20 record reads in flight would need 122 + 8 registers = 3 waves per SIMD: the batch is scheduled in two halves)
+          if (u == HGS_BWD_BATCH / 2) __builtin_amdgcn_sched_barrier(0);
+          eval_pair((k0 + u) >> 1, kqa, wga, kqb, wgb);
+          stage[u * HGS_STAGE_STRIDE + lane] = kqa;
+          stage[(u + 1) * HGS_STAGE_STRIDE + lane] = kqb;
+          stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wga;
+          stage[(HGS_BWD_BATCH + u + 1) * HGS_STAGE_STRIDE + lane] = wgb;
+        }
+#else
         float kqv[HGS_BWD_BATCH], wgv[HGS_BWD_BATCH];
 #pragma unroll
         for (int u = 0; u < HGS_BWD_BATCH; ++u) eval_record(k0 + u, kqv[u], wgv[u]);
@@ -364,6 +458,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           stage[u * HGS_STAGE_STRIDE + lane] = kqv[u];
           stage[(HGS_BWD_BATCH + u) * HGS_STAGE_STRIDE + lane] = wgv[u];
         }
+#endif
       } else {
 #pragma unroll
         for (int u = 0; u < HGS_BWD_BATCH; ++u) {
