@@ -178,3 +178,42 @@ def test_config5_animation_frames_forward_only():
             if prev is not None:
                 assert float((img - prev).abs().mean()) > 1e-5          # the avatar actually moves
             prev = img
+
+
+def test_config3_8views_batched_fullsize():
+    """BASELINE configs[2] (what GaussianDreamer.py:244-266 runs per step): 100k Gaussians, SH 0, the 8 bench
+    orbit cameras @1024^2 in ONE batched call == 8 single calls BITWISE (images, radii, per-view means2D
+    gradients, view-ordered parameter sums), plus one view of the batch through the fp64-oracle gate."""
+    from humangaussian_amd import rasterize_gaussians_batch
+    B = 8
+    dev, cloud, cam0, rs0 = _setup(100_000, 0)
+    cams = [synth.orbit_camera(10.0, 30.0 + 45.0 * i, 1.75, 55.0, RES, RES) for i in range(B)]
+    rsl = [rs0._replace(viewmatrix=c.world_view_transform.to(dev), projmatrix=c.full_proj_transform.to(dev),
+                        campos=c.camera_center.to(dev), tanfovx=math.tan(c.FoVx / 2), tanfovy=math.tan(c.FoVy / 2))
+           for c in cams]
+    gen = torch.Generator().manual_seed(11)
+    gc, gd, ga = (torch.randn(s, generator=gen) * 1e-3 for s in ((B, 3, RES, RES), (B, 1, RES, RES), (B, 1, RES, RES)))
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    singles = [_hip(dev, cloud, rsl[b], [gc[b], gd[b], ga[b]]) for b in range(B)]
+
+    ins = {k: getattr(cloud, k).to(dev).requires_grad_(True) for k in names}
+    m2 = torch.zeros(B, 100_000, 3, device=dev, requires_grad=True)
+    c, r, d, a = rasterize_gaussians_batch(ins["means3D"], m2, ins["shs"], None, ins["opacities"], ins["scales"],
+                                           ins["rotations"], None, rsl)
+    torch.autograd.backward([c, d, a], [gc.to(dev), gd.to(dev), ga.to(dev)])
+    for b in range(B):
+        sc_, sr, sd, sa, sg = singles[b]
+        assert torch.equal(c[b].detach().cpu(), sc_) and torch.equal(d[b].detach().cpu(), sd), b
+        assert torch.equal(a[b].detach().cpu(), sa) and torch.equal(r[b].cpu(), sr), b
+        assert torch.equal(m2.grad[b].cpu(), sg["means2D"]), b
+    for k in names:
+        acc = singles[0][4][k].clone()
+        for b in range(1, B):
+            acc += singles[b][4][k]                  # view-ordered fp32 sum (what autograd accumulates over the loop)
+        assert torch.equal(ins[k].grad.cpu(), acc), k
+    # view 5 of the batch (a side view: different list lengths than the single-view test) through the oracle gate
+    v = 5
+    hip = (c[v].detach().cpu(), r[v].cpu(), d[v].detach().cpu(), a[v].detach().cpu(),
+           {**{k: singles[v][4][k] for k in names}, "means2D": m2.grad[v].cpu()})
+    check_against_fp64_oracle("config3_view5_of_8_batched", cloud, _oracle_settings(rsl[v], cams[v], 0), hip,
+                              [gc[v], gd[v], ga[v]])
