@@ -2,9 +2,9 @@
 // launch sequences.  No allocation, no host synchronisation, no global state.
 //
 // Forward launch chain (one stream, no host round trip), for all B views of a call at once:
-//   memset(counters) -> preprocess_fwd -> tiles [status published] -> fill (+ tile order) -> sort_{huge,large,lds}
-//   -> segT -> render_fwd (segments of long lists first, then the other tiles) -> combine
-// Backward: render_bwd (one wave per bucket) -> preprocess_bwd.
+//   preprocess_fwd -> tiles -> fill (+ tile order) [status published] -> sort_{huge,large,lds} (+ cell lists,
+//   backward work items) -> render_fwd (one workgroup per tile, heavy first)
+// Backward: render_bwd (persistent waves, four cell-list segments each) -> pair_reduce -> preprocess_bwd.
 #include "hgs_common.h"
 
 // The forward kernels and the per-Gaussian backward are included here (one translation
@@ -19,10 +19,10 @@ __device__ unsigned long long hgs_tl[HGS_TL_KERNELS][HGS_TL_SLOTS][4];
 #include "bookkeeping.hip"
 
 // render_bwd.hip is a separate translation unit (different optimisation flags)
-extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*,
+extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*, const float*,
                                             const float*, const float*, const float*, const float*,
-                                            const float*, const float*, const float*,
-                                            const float*, float*);
+                                            const float*, const float*, float*);
+extern "C" __global__ void hgs_k_pair_reduce(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
 
 namespace {
 
@@ -33,9 +33,6 @@ namespace {
 #ifndef HGS_PRE_BWD_VPAR_MIN_VIEWS
 #define HGS_PRE_BWD_VPAR_MIN_VIEWS 2   // calls with at least this many views run the per-Gaussian backward with one thread per
 #endif                                 // (Gaussian, view); fewer: one thread per Gaussian
-#ifndef HGS_SEG_RECOMPUTE_MAX
-#define HGS_SEG_RECOMPUTE_MAX 12   // longest list (in segments) for which segments recompute their predecessors' products
-#endif
 constexpr size_t ALIGN = 256;
 constexpr size_t HGS_LDS_BINS_MAX = 16384;   // T*4 bytes of LDS <= 64 KB
 #ifndef HGS_BIN_WGS_PER_VIEW_MAX
@@ -48,7 +45,7 @@ constexpr int HGS_MAX_BIN_WGS_PER_VIEW = HGS_BIN_WGS_PER_VIEW_MAX;
 constexpr int HGS_BIN_WGS_TOTAL = HGS_BIN_WGS_TOTAL_MAX;      // binning workgroups of a batch (all views)
 
 struct GeomCarve {
-  size_t geom, tile_n, tile_start, tile_bstart, tile_wgstart, tile_msegstart, tile_maxcontrib, tile_order,
+  size_t geom, tile_n, tile_start, tile_order, cell_info, items_part,
       hist, tile_gbase, tile_count, chunk_sums, chunk_base, ctr, status, total;
 };
 
@@ -77,11 +74,9 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   c.geom = take((size_t)B * P * sizeof(GeomRec));
   c.tile_n = take(TT * 4);
   c.tile_start = take(TT * 4);
-  c.tile_bstart = take(TT * 4);
-  c.tile_wgstart = take(TT * 4);
-  c.tile_msegstart = take(TT * 4);
-  c.tile_maxcontrib = take(TT * 4);
   c.tile_order = take(TT * 4);
+  c.cell_info = take(TT * 16 * sizeof(CellInfo));
+  c.items_part = take(2 * 16 * TT * sizeof(uint2));      // last (partial) segment of every cell list, by length class
   c.hist = take(lds ? (size_t)B * nwg * T * 4 : 0);
   c.tile_gbase = take(lds ? (size_t)HGS_ROW_GROUPS * TT * 4 : 0);
   c.tile_count = take(lds ? 0 : TT * 4);
@@ -93,23 +88,23 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, bstate, segT, segP, wg_tile, seg_item, total; };
+struct BinCarve { size_t keys, recs, cell_list, pairslot, cstate, items_full, total; };
 
+// Pair-sized arrays hold HGS_PAIRS_PER_ENTRY slots per entry of capacity: an entry can reach all 16 cells of
+// its tile (zoomed-in cameras), so no second capacity (and no second overflow path) exists.
 BinCarve carve_bin(int64_t cap) {
   BinCarve c;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = hgs_align_up(off + bytes, ALIGN); return o; };
   const size_t C = (size_t)(cap > 0 ? cap : 0);
+  const size_t NP = C * HGS_PAIRS_PER_ENTRY;
   c.keys = take(C * 8);
   c.recs = take(C * sizeof(SortRec));
-  c.bstate = take(((C + HGS_BUCKET - 1) / HGS_BUCKET) * HGS_BSTATE_FLOATS * sizeof(float));
-  const size_t nms = 2 * (C / HGS_SEG) + 2;      // bound on segments of multi-segment tiles
-  c.segT = take(nms * HGS_TILE_PIX * sizeof(float));
-  c.segP = take(nms * HGS_SEG_PLANES * HGS_TILE_PIX * sizeof(float));
-  c.seg_item = take((nms + 2) * 8);
-  // one backward work item per bucket: <= C/64 + (tiles with a partial bucket) <= C/64 + min(C, tiles);
-  // sized by C alone so that the carve does not depend on the image
-  c.wg_tile = take(2 * (C + C / HGS_BUCKET + 2) * 16);       // two tables (hgs_bwd_item_slot)
+  c.cell_list = take(NP * 4);
+  c.pairslot = take(NP * 4);
+  // a cell list of len entries has ceil(len / 64) - 1 stored states and ceil(len / 64) work items, len / 64 of them full
+  c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
+  c.items_full = take((NP / HGS_SEGLEN + 1) * sizeof(uint2));
   c.total = off;
   return c;
 }
@@ -123,11 +118,9 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.geom = reinterpret_cast<GeomRec*>(gp + g.geom);
   L.tile_n = reinterpret_cast<uint32_t*>(gp + g.tile_n);
   L.tile_start = reinterpret_cast<uint32_t*>(gp + g.tile_start);
-  L.tile_bstart = reinterpret_cast<uint32_t*>(gp + g.tile_bstart);
-  L.tile_wgstart = reinterpret_cast<uint32_t*>(gp + g.tile_wgstart);
-  L.tile_msegstart = reinterpret_cast<uint32_t*>(gp + g.tile_msegstart);
-  L.tile_maxcontrib = reinterpret_cast<uint32_t*>(gp + g.tile_maxcontrib);
   L.tile_order = reinterpret_cast<uint32_t*>(gp + g.tile_order);
+  L.cell_info = reinterpret_cast<CellInfo*>(gp + g.cell_info);
+  L.items_part = reinterpret_cast<uint2*>(gp + g.items_part);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.tile_gbase = reinterpret_cast<uint32_t*>(gp + g.tile_gbase);
   L.tile_count = reinterpret_cast<uint32_t*>(gp + g.tile_count);
@@ -136,11 +129,10 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.ctr = reinterpret_cast<Counters*>(gp + g.ctr);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
-  L.bstate = bp ? reinterpret_cast<float*>(bp + b.bstate) : nullptr;
-  L.segT = bp ? reinterpret_cast<float*>(bp + b.segT) : nullptr;
-  L.segP = bp ? reinterpret_cast<float*>(bp + b.segP) : nullptr;
-  L.wg_tile = bp ? reinterpret_cast<uint4*>(bp + b.wg_tile) : nullptr;
-  L.seg_item = bp ? reinterpret_cast<uint2*>(bp + b.seg_item) : nullptr;
+  L.cell_list = bp ? reinterpret_cast<uint32_t*>(bp + b.cell_list) : nullptr;
+  L.pairslot = bp ? reinterpret_cast<uint32_t*>(bp + b.pairslot) : nullptr;
+  L.cstate = bp ? reinterpret_cast<float*>(bp + b.cstate) : nullptr;
+  L.items_full = bp ? reinterpret_cast<uint2*>(bp + b.items_full) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;
 }
@@ -176,14 +168,6 @@ View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_
   if (!v.lds_bins) { v.cpw = 1; v.nwg = v.nblk; }
   v.entry_capacity = (uint32_t)(cap < 0 ? 0 : (cap > 0xffffffffll ? 0xffffffffll : cap));
   v.max_tile_hint = max_tile_hint;
-  // list-parallel blending pays for the long tail of tile lists only (same-box sweep, 100k
-  // Gaussians / lists to 1.6k: 83 us with SEG 256 + THRESH 1024, 88 us unsegmented, 91-97 us with
-  // every list cut), so only lists longer than HGS_SEG_THRESH are segmented - a pure function
-  // of the list length; a hint that rules such lists out merely skips the empty launches
-  v.seg_off = (max_tile_hint > 0 && max_tile_hint <= HGS_SEG_THRESH) ? 1 : 0;
-  // few segments per list: a segment recomputes its predecessors' transmittance products itself
-  // (work quadratic in the segment count, hence the bound) and hgs_k_fwd_segT is not launched
-  v.seg_recompute = (max_tile_hint > 0 && max_tile_hint <= HGS_SEG_RECOMPUTE_MAX * HGS_SEG) ? 1 : 0;
   return v;
 }
 
@@ -276,7 +260,7 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 10; }
+int hgs_abi_version(void) { return 11; }
 
 size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t H, int32_t W) {
   if (B < 1 || B > HGS_MAX_VIEWS || P < 0 || H <= 0 || W <= 0) return 0;
@@ -289,8 +273,9 @@ size_t hgs_img_bytes_batch(int32_t B, int32_t H, int32_t W) {
   return hgs_align_up((size_t)B * H * W * 4, ALIGN);
 }
 size_t hgs_img_bytes(int32_t H, int32_t W) { return hgs_img_bytes_batch(1, H, W); }
+// one gradient row per entry + one per (entry, cell) pair
 size_t hgs_bwd_scratch_bytes(int64_t R) {
-  return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_ROW_FLOATS * sizeof(float), ALIGN);
+  return hgs_align_up((size_t)(R > 0 ? R : 0) * (1 + HGS_PAIRS_PER_ENTRY) * HGS_ROW_FLOATS * sizeof(float), ALIGN);
 }
 
 int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
@@ -399,38 +384,14 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     HGS_STAGE(3);
   }
   HGS_STAGE(4);
-  // Blend: segment transmittances of the long lists (> HGS_SEG_THRESH entries), then ONE launch
-  // whose first seg_bound workgroups take the segments of the long lists and the next B*T the
-  // remaining tiles, then the combine of the segment partials.  Grids are capacity bounds;
-  // surplus workgroups exit on the device-side totals.
-  const bool use_seg = !v.seg_off && entry_capacity > HGS_SEG_THRESH;
-  // segments of multi-segment lists: sum ceil(n / SEG) over lists longer than THRESH <= C / SEG + C / THRESH
-  const unsigned seg_bound = use_seg ? (unsigned)(entry_capacity / HGS_SEG + entry_capacity / HGS_SEG_THRESH) + 2u : 0u;
-  if (use_seg && !v.seg_recompute) {
-    hipLaunchKernelGGL(hgs_k_fwd_segT, dim3(seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L,
-                       status_dev, L.recs, L.segT);
-    HGS_LAUNCH_CHECK();
-  }
-  // two instantiations of the blend: unroll 4 (shortest per-tile chain) for calls of few views, unroll 2
-  // (8 waves/SIMD) when several views keep the chip full (render_fwd.hip); same bits either way
-  const bool many = v.B >= HGS_SORT_256_MIN_VIEWS;
-#define HGS_LAUNCH_FWD(K)                                                                                    \
-  hipLaunchKernelGGL(K, dim3(v.TT + seg_bound), dim3(HGS_FWD_THREADS), 0, stream, v, L, (uint32_t)seg_bound, \
-                     status_dev, L.recs, L.bstate, L.segT, L.segP, out_color, out_depth, out_alpha)
-  if (store_bwd_state) {
-    if (many) HGS_LAUNCH_FWD(hgs_k_render_fwd_store_many); else HGS_LAUNCH_FWD(hgs_k_render_fwd_store);
-  } else {
-    if (many) HGS_LAUNCH_FWD(hgs_k_render_fwd_nostore_many); else HGS_LAUNCH_FWD(hgs_k_render_fwd_nostore);
-  }
-#undef HGS_LAUNCH_FWD
+  // Blend: one workgroup per tile, heavy first; four independent waves, each four cell rows (render_fwd.hip)
+  if (store_bwd_state)
+    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, status_dev, L.recs,
+                       L.cstate, out_color, out_depth, out_alpha);
+  else
+    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, status_dev, L.recs,
+                       L.cstate, out_color, out_depth, out_alpha);
   HGS_LAUNCH_CHECK();
-  if (use_seg) {
-    // tiles with more than HGS_SEG_THRESH entries occupy at most the first capacity / THRESH positions
-    const int64_t cg = entry_capacity / HGS_SEG_THRESH + 1;
-    hipLaunchKernelGGL(hgs_k_fwd_combine, dim3((unsigned)(cg < v.TT ? cg : v.TT)), dim3(HGS_FWD_THREADS), 0, stream, v, L,
-                       status_dev, L.segP, out_color, out_depth, out_alpha);
-    HGS_LAUNCH_CHECK();
-  }
   HGS_STAGE(5);
   return HGS_OK;
 }
@@ -495,20 +456,30 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
                                const_cast<void*>(img), B, P, v.H, v.W, cap);
   const hgs_status* status_dev = reinterpret_cast<const hgs_status*>(
       static_cast<const char*>(geom) + carve_geom(B, P, v.H, v.W).status);
-  // host status known: exact grid.  Unknown: capacity bound, surplus workgroups exit.
-  uint32_t groups = 0;
-  if (status) groups = status->bwd_groups;
-  else if (maybe_entries) {
-    const int64_t gb = cap / HGS_BUCKET + (cap < v.TT ? cap : (int64_t)v.TT);
-    groups = (uint32_t)gb;
-  }
+  // gradient rows: [X entries][12] then the pair rows [16 X][12], X = what the caller sized the scratch by
+  const int64_t X = status ? (int64_t)status->num_rendered : cap;
   float* rows = static_cast<float*>(bwd_scratch);
+  float* pair_rows = rows + (size_t)X * HGS_ROW_FLOATS;
   HGS_STAGE(0);
-  if (groups > 0) {
-    hipLaunchKernelGGL(hgs_k_render_bwd, dim3(groups), dim3(64 * HGS_BWD_WAVES), 0, stream, v, L, status_dev,
-                       L.recs, L.bstate, L.segP, out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth,
-                       dL_dout_alpha, rows);
+  if (maybe_entries) {
+    // persistent waves: as many as the chip holds (LDS: 11.8 KB per wave), each fetches groups of four work items
+    static int resident = 0;
+    if (resident == 0) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hgs_k_render_bwd, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+      resident = per_cu * prop.multiProcessorCount;
+    }
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)resident), dim3(64), 0, stream, v, L, status_dev, L.recs, L.cstate,
+                       out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows);
     HGS_LAUNCH_CHECK();
+    const int64_t tiles = status ? (int64_t)status->active_tiles : (int64_t)v.TT;
+    if (tiles > 0) {
+      hipLaunchKernelGGL(hgs_k_pair_reduce, dim3((unsigned)tiles), dim3(256), 0, stream, v, L, status_dev, L.recs,
+                         pair_rows, rows);
+      HGS_LAUNCH_CHECK();
+    }
   }
   HGS_STAGE(1);
 #define HGS_LAUNCH_PRE_BWD(K, GRID, THREADS, LDS)                                                     \

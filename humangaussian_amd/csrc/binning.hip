@@ -6,8 +6,7 @@
 //   1. hgs_k_tiles     many workgroups, 64 tiles each: sums the per-workgroup histogram rows
 //                      hgs_k_preprocess_fwd left (16 row groups walked by 16 waves in parallel,
 //                      rows turned into exclusive bases in place), and hands every tile its list
-//                      range, bucket-state range, backward work-item range and segment-plane range
-//                      by BUMP ALLOCATION (two 64-bit atomics per 64 tiles) - no prefix scan
+//                      range by BUMP ALLOCATION (one 64-bit atomic per 64 tiles) - no prefix scan
 //                      over the tiles, no single-workgroup latency chain, no ticket.
 //   2. hgs_k_fill      per Gaussian: scatter (depth_bits<<32 | idx) keys into its tiles' list
 //                      ranges (order inside a tile is arbitrary here); extra workgroups of the same
@@ -16,7 +15,9 @@
 //   3. hgs_k_sort_*    per tile: bitonic sort of the tile's keys IN LDS (unique keys =>
 //                      deterministic result = upstream's stable order: depth, ties by index),
 //                      then gathers the Gaussians into a depth-ordered, contiguous 48-byte
-//                      record list ("duplicated Gaussian list") that both blend kernels stream.
+//                      record list ("duplicated Gaussian list"), gives every entry its 16-bit CELL mask
+//                      (which 4x4-pixel cells of the tile it can reach, cellmask.h) and writes the tile's
+//                      16 depth-ordered cell lists + the backward work items (gather_records).
 //
 // Roofline: HBM/latency-bound integer work: 8 B/entry written + read for keys, one 64 B
 // gather + 48 B write per entry for the records.
@@ -72,32 +73,16 @@ hgs_k_tiles(View v, Layout L) {
 #pragma unroll
     for (int k = 0; k < HGS_ROW_GROUPS; ++k) n += gt[k][tl];
     if (!valid) n = 0;
-    const uint32_t nb = (n + HGS_BUCKET - 1) / HGS_BUCKET;
-    const uint32_t nseg = hgs_nseg(n);
-    const uint32_t v0 = n, v1 = nb > 0 ? nb - 1 : 0u, v2 = nb, v3 = nseg > 1 ? nseg : 0u;
-    const uint32_t i0 = hgs_wave_incl_scan(v0), i1 = hgs_wave_incl_scan(v1);
-    const uint32_t i2 = hgs_wave_incl_scan(v2), i3 = hgs_wave_incl_scan(v3);
-    // one bump allocation per counter pair for the 64 tiles (lane 63 holds the totals)
-    unsigned long long b_eb = 0, b_ws = 0;
-    if (tl == 63) {
-      const unsigned long long t_eb = (unsigned long long)i0 | ((unsigned long long)i1 << 32);
-      const unsigned long long t_ws = (unsigned long long)i2 | ((unsigned long long)i3 << 32);
-      if (t_eb) b_eb = atomicAdd(&L.ctr->alloc_eb, t_eb);
-      if (t_ws) b_ws = atomicAdd(&L.ctr->alloc_ws, t_ws);
-    }
+    const uint32_t i0 = hgs_wave_incl_scan(n);
+    // one bump allocation for the 64 tiles (lane 63 holds the total)
+    unsigned long long b_eb = 0;
+    if (tl == 63 && i0) b_eb = atomicAdd(&L.ctr->alloc_eb, (unsigned long long)i0);
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b_eb, 63);
-    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b_eb >> 32), 63);
-    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b_ws, 63);
-    const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b_ws >> 32), 63);
-    const uint32_t start = s0 + i0 - v0;
+    const uint32_t start = s0 + i0 - n;
     start_s[tl] = start;
     if (valid) {
       L.tile_n[g] = n;
       L.tile_start[g] = start;
-      L.tile_bstart[g] = s1 + i1 - v1;
-      L.tile_wgstart[g] = s2 + i2 - v2;
-      L.tile_msegstart[g] = s3 + i3 - v3;
-      L.tile_maxcontrib[g] = 0;
     }
     // class histogram (class = bit length of n; 0 = empty); the empty class is counted per wave
     const unsigned long long eb = __ballot(valid && n == 0);
@@ -146,16 +131,16 @@ __device__ __forceinline__ void place_tiles(const View& v, const Layout& L, int 
     for (int c = HGS_NCLS - 1; c >= 0; --c) { cls_base[c] = acc; acc += cls_cnt[c]; }   // heavy classes first
   }
   if (blk == 0 && tid == 64) {
-    const unsigned long long a_eb = L.ctr->alloc_eb, a_ws = L.ctr->alloc_ws;
+    const unsigned long long a_eb = L.ctr->alloc_eb;
     hgs_status st;
     st.num_rendered = (uint32_t)a_eb;
     st.active_tiles = (uint32_t)v.TT - cls_cnt[0];
-    st.num_buckets = (uint32_t)(a_eb >> 32);
-    st.bwd_groups = (uint32_t)a_ws;
+    st.num_buckets = 0;                  // (ABI v10 fields of the bucket design: unused since v11)
+    st.bwd_groups = 0;
     st.overflow = overflow_from_counters(v, L);
     st.reserved[0] = v.entry_capacity;   // carve key for hgs_backward
     st.reserved[1] = L.ctr->max_n;       // longest tile list
-    st.reserved[2] = (uint32_t)(a_ws >> 32);   // segment planes
+    st.reserved[2] = 0;
     *status = st;
     if (status_host) {            // pinned, device-mapped host memory: no in-stream copy
       *status_host = st;
@@ -255,28 +240,42 @@ hgs_k_fill_ga(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __r
 // ---------------------------------------------------------------------------- 3. sort
 namespace {
 
+// LDS tables of the record gather (one workgroup = one tile): MAXCH 64-record chunks per pass.
+template <int MAXCH>
+struct GatherLds {
+  uint32_t tab[MAXCH][17];   // per chunk: records that touch cell c (columns 0..15), pairs of the chunk (16)
+  uint32_t run[17];          // running totals over the passes of a long list (same columns)
+  uint32_t cell_tot[16];     // length of the tile's 16 cell lists
+  uint32_t cell_base[16];    // absolute first slot of each cell list
+  uint32_t pair_base;        // first pair slot of the tile
+};
+
+// After the sort: (1) gather the Gaussians into the depth-ordered 48 B record list, computing every entry's
+// 16-bit cell mask (cellmask.h); (2) allocate the tile's pair range, cell-state range and backward work
+// items; (3) write the 16 depth-ordered cell lists and, entry-major, where each (entry, cell) pair sits in
+// them (`pairslot`: the reduce kernel sums an entry's pair rows through it).  `sorted` (LDS or HBM) holds
+// the sorted keys on entry; its slots are reused for the masks.
+template <int MAXCH>
 __device__ __forceinline__ void gather_records(const View& v, const Layout& L, int g,
                                                uint32_t start, uint32_t n,
-                                               const unsigned long long* sorted, int nt) {
+                                               unsigned long long* sorted, int nt, GatherLds<MAXCH>& S) {
   const int t = g % v.T;
   const GeomRec* __restrict__ geom = L.geom + (size_t)(g / v.T) * v.P;
   const uint32_t* __restrict__ cbase = L.chunk_base + (size_t)(g / v.T) * v.nblk;
   const int tx = t % v.grid_x, ty = t / v.grid_x;
   const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
-  {  // (tile, segment) table of the long lists: the segment kernels find their work with one load
-    const uint32_t nseg = hgs_nseg(n);
-    if (nseg > 1) {
-      const uint32_t ms0 = L.tile_msegstart[g], item_bound = 2u * (uint32_t)(v.entry_capacity / HGS_SEG) + 2u;
-      for (uint32_t sg = threadIdx.x; sg < nseg && ms0 + sg < item_bound; sg += nt)
-        L.seg_item[ms0 + sg] = make_uint2((uint32_t)g, sg);
-    }
-  }
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wv = tid >> 6, nwaves = nt >> 6;
+  if (tid < 16) S.cell_tot[tid] = 0;
+  if (tid < 17) S.run[tid] = 0;
+  __syncthreads();
+  // ---- sweep 1: records + masks + cell-list lengths.
   // GU records per thread in flight: the 64 B geom gathers are dependent random reads (~1-2 us
   // each); issued one at a time they dominated the sort kernel of the heaviest tile
-  // (1 / 2 in flight: 72 / 85 VGPRs and three / two workgroups per CU instead of two - every tile then starts at
-  // t = 0, but the crowded phase is throughput-bound: 36.2 / 33.2 vs 34.5 us)
   constexpr int GU = 4;
-  for (uint32_t kb = threadIdx.x; kb < n; kb += (uint32_t)nt * GU) {
+  uint32_t mytot = 0;                                  // lane c < 16: records of this wave that touch cell c
+  for (uint32_t kb0 = 0; kb0 < n; kb0 += (uint32_t)nt * GU) {      // (wave-uniform trip count: ballots inside)
+    const uint32_t kb = kb0 + threadIdx.x;
     uint32_t idxv[GU];
     uint4 q0[GU], q1[GU], q2[GU];
     uint32_t q3[GU];
@@ -296,56 +295,137 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       const uint32_t k = kb + (uint32_t)u * nt;
-      if (k >= n) continue;
-      const uint32_t idx = idxv[u];
-      const uint4 g0 = q0[u], g1 = q1[u], g2 = q2[u];
-      // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | q3: offset
-      const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
-      const uint32_t entry = cbase[idx >> 8] + q3[u] + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
-      const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
-      const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
-      const float op = __uint_as_float(g1.y);
-      // Conservative quadrant cull: a pixel can only pass alpha >= 1/255 inside the ellipse
-      // q(d) = ca dx^2 + 2 cb dx dy + cc dy^2 <= tau, tau = 2 ln(255 op).  A quadrant (its 8x8 pixel
-      // centres span a rectangle) is kept iff the minimum of q over that rectangle is <= tau: the
-      // minimum of a convex quadratic over a box is 0 if the centre is inside, else it lies on an
-      // edge, where the free coordinate's optimum is the clamped 1-D minimiser.  (This exact test
-      // keeps 9 % fewer (entry, quadrant) pairs than the ellipse's bounding box on the 100k-Gaussian
-      // scene - tools/cull_stats.py - and every pair it drops has no live pixel.)  Margins absorb
-      // rounding; a set bit never changes results, a cleared bit must be provably empty.
       uint32_t mask = 0;
-      const float a255 = 255.0f * op;
-      if (a255 >= 0.999f) {
-        const float tau = 2.0f * __logf(fmaxf(a255, 1.0f)) * 1.001f + 0.02f;
-        const float detc = ca * cc - cb * cb;
-        if (detc > 0.0f && cc > 0.0f && ca > 0.0f) {
-          const float bc = cb / cc, ba = cb / ca;
-          auto qf = [&](float px, float py) {
-            const float dx = px - mx, dy = py - my;
-            return ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy;
-          };
+      if (k < n) {
+        const uint32_t idx = idxv[u];
+        const uint4 g0 = q0[u], g1 = q1[u], g2 = q2[u];
+        // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | q3: offset
+        const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
+        const uint32_t entry = cbase[idx >> 8] + q3[u] + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+        const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
+        const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
+        mask = hgs_cell_mask(mx, my, ca, cb, cc, __uint_as_float(g1.y), x0, y0);
+        uint4* dst = reinterpret_cast<uint4*>(&L.recs[start + k]);
+        const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
+        dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
+        dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
+        dst[2] = make_uint4(g2.x, g2.y, entry, 0u);         // .pairs follows in sweep 2
+        sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
+      }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float qx0 = x0 + (float)((q & 1) * 8), qy0 = y0 + (float)((q >> 1) * 8);
-            const float qx1 = qx0 + 7.0f, qy1 = qy0 + 7.0f;
-            float best = qf(fminf(fmaxf(mx, qx0), qx1), fminf(fmaxf(my, qy0), qy1));   // 0 when inside
-            best = fminf(best, qf(qx0, fminf(fmaxf(my - bc * (qx0 - mx), qy0), qy1)));
-            best = fminf(best, qf(qx1, fminf(fmaxf(my - bc * (qx1 - mx), qy0), qy1)));
-            best = fminf(best, qf(fminf(fmaxf(mx - ba * (qy0 - my), qx0), qx1), qy0));
-            best = fminf(best, qf(fminf(fmaxf(mx - ba * (qy1 - my), qx0), qx1), qy1));
-            const bool hit = best <= tau * 1.0005f + 1e-3f * best;
-            mask |= hit ? (1u << q) : 0u;
-          }
-        } else {
-          mask = 0xfu;   // degenerate conic: never cull
+      for (int c = 0; c < 16; ++c) {
+        const unsigned long long bal = __ballot((mask >> c) & 1u);
+        if (lane == c) mytot += (uint32_t)__popcll(bal);
+      }
+    }
+  }
+  if (lane < 16 && mytot) atomicAdd(&S.cell_tot[lane], mytot);
+  __syncthreads();
+  // ---- ranges of this tile: pairs (= cell-list slots), cell states, work items.  Wave 0, lane c = cell c.
+  if (tid < 64) {
+    const bool cl = lane < 16;
+    const uint32_t len = cl ? S.cell_tot[lane] : 0u;
+    const uint32_t nfull = len / HGS_SEGLEN, rem = len % HGS_SEGLEN;
+    const uint32_t nseg = nfull + (rem ? 1u : 0u);
+    const uint32_t nst = nseg ? nseg - 1u : 0u;
+    const uint32_t i_len = hgs_wave_incl_scan(len), i_st = hgs_wave_incl_scan(nst), i_full = hgs_wave_incl_scan(nfull);
+    const uint32_t pcls = rem ? hgs_item_class(rem) : 0u;            // 1..3 for a partial last segment
+    const unsigned long long b1 = __ballot(pcls == 1u), b2 = __ballot(pcls == 2u), b3 = __ballot(pcls == 3u);
+    // five bump allocations travel together (lanes 0..4 issue them)
+    const uint32_t t_len = (uint32_t)__builtin_amdgcn_readlane((int)i_len, 63);
+    const uint32_t t_st = (uint32_t)__builtin_amdgcn_readlane((int)i_st, 63);
+    const uint32_t t_full = (uint32_t)__builtin_amdgcn_readlane((int)i_full, 63);
+    unsigned long long got = 0;
+    if (lane == 0 && (t_len | t_st)) got = atomicAdd(&L.ctr->alloc_ps, (unsigned long long)t_len | ((unsigned long long)t_st << 32));
+    if (lane == 1 && t_full) got = atomicAdd(&L.ctr->item_cur[0], t_full);
+    if (lane == 2 && b1) got = atomicAdd(&L.ctr->item_cur[1], (uint32_t)__popcll(b1));
+    if (lane == 3 && b2) got = atomicAdd(&L.ctr->item_cur[2], (uint32_t)__popcll(b2));
+    if (lane == 4 && b3) got = atomicAdd(&L.ctr->item_cur[3], (uint32_t)__popcll(b3));
+    const uint32_t got_lo = (uint32_t)got, got_hi = (uint32_t)(got >> 32);
+    const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 0);
+    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 0);
+    const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 1);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 2);
+    const uint32_t p2 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 3);
+    const uint32_t p3 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 4);
+    if (cl) {
+      const uint32_t base = pb + i_len - len;
+      S.cell_base[lane] = base;
+      CellInfo ci;
+      ci.base = base; ci.len = len; ci.sbase = sb + i_st - nst; ci.pbase = pb;
+      L.cell_info[(size_t)g * 16 + lane] = ci;
+      const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
+      uint2* full = L.items_full + (fb + i_full - nfull);
+      for (uint32_t sgm = 0; sgm < nfull; ++sgm) full[sgm] = make_uint2(key, sgm);
+      if (rem) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const size_t ptab = (size_t)16 * v.TT;
+        uint2 it = make_uint2(key, nfull | (rem << 24));
+        if (pcls == 1u) L.items_part[p1 + (uint32_t)__popcll(b1 & below)] = it;
+        else if (pcls == 2u) L.items_part[ptab - 1 - (p2 + (uint32_t)__popcll(b2 & below))] = it;
+        else L.items_part[ptab + p3 + (uint32_t)__popcll(b3 & below)] = it;
+      }
+    }
+    if (lane == 0) S.pair_base = pb;
+  }
+  __syncthreads();
+  // ---- sweep 2: cell lists and pair slots, MAXCH chunks per pass
+  const uint32_t pair_base = S.pair_base;
+  for (uint32_t sc0 = 0; sc0 < n; sc0 += (uint32_t)MAXCH * 64u) {
+    const uint32_t nch = min((uint32_t)MAXCH, (n - sc0 + 63u) / 64u);
+    // (a) per chunk: how many of its records touch each cell
+    for (uint32_t ch = wv; ch < nch; ch += nwaves) {
+      const uint32_t k = sc0 + ch * 64u + lane;
+      const uint32_t mask = (k < n) ? (uint32_t)sorted[k] : 0u;
+      uint32_t mine = 0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const unsigned long long bal = __ballot((mask >> c) & 1u);
+        if (lane == c) mine = (uint32_t)__popcll(bal);
+      }
+      uint32_t tot = mine;                               // lanes >= 16 hold 0
+      tot += __builtin_amdgcn_update_dpp(0, (int)tot, HGS_DPP_ROW_SHR(1), 0xf, 0xf, false);
+      tot += __builtin_amdgcn_update_dpp(0, (int)tot, HGS_DPP_ROW_SHR(2), 0xf, 0xf, false);
+      tot += __builtin_amdgcn_update_dpp(0, (int)tot, HGS_DPP_ROW_SHR(4), 0xf, 0xf, false);
+      tot += __builtin_amdgcn_update_dpp(0, (int)tot, HGS_DPP_ROW_SHR(8), 0xf, 0xf, false);
+      if (lane < 16) S.tab[ch][lane] = mine;
+      if (lane == 15) S.tab[ch][16] = tot;               // pairs of the chunk
+    }
+    __syncthreads();
+    // (b) exclusive prefix over the chunks, per column, on top of the running totals of earlier passes
+    for (int col = wv; col < 17; col += nwaves) {
+      uint32_t carry = S.run[col];
+      for (uint32_t c0 = 0; c0 < nch; c0 += 64u) {
+        const uint32_t ch = c0 + lane;
+        const uint32_t x = ch < nch ? S.tab[ch][col] : 0u;
+        const uint32_t inc = hgs_wave_incl_scan(x);
+        if (ch < nch) S.tab[ch][col] = carry + inc - x;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      }
+      if (lane == 0) S.run[col] = carry;
+    }
+    __syncthreads();
+    // (c) emit
+    for (uint32_t ch = wv; ch < nch; ch += nwaves) {
+      const uint32_t k = sc0 + ch * 64u + lane;
+      const bool in = k < n;
+      const uint32_t mask = in ? (uint32_t)sorted[k] : 0u;
+      const uint32_t cnt = (uint32_t)__popc(mask);
+      const uint32_t rel = S.tab[ch][16] + hgs_wave_incl_scan(cnt) - cnt;      // entry-major, relative to the tile
+      if (in) L.recs[start + k].pairs = rel | (cnt << 27);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const bool bit = (mask >> c) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        if (bit) {
+          const uint32_t rank = S.tab[ch][c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          const uint32_t slot = S.cell_base[c] + rank;
+          L.cell_list[slot] = start + k;
+          L.pairslot[pair_base + rel + (uint32_t)__popc(mask & ((1u << c) - 1u))] = slot;
         }
       }
-      uint4* dst = reinterpret_cast<uint4*>(&L.recs[start + k]);
-      const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
-      dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
-      dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-      dst[2] = make_uint4(g2.x, g2.y, entry, (idx & 0x0fffffffu) | (mask << 28));
     }
+    __syncthreads();
   }
 }
 
@@ -588,7 +668,7 @@ __device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad
 // One tile, n <= NT*E keys: load, sort in registers/LDS, gather the records.
 template <int E, int NT>
 __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, int t,
-                                              uint32_t start, uint32_t n, u64* keys) {
+                                              uint32_t start, uint32_t n, u64* keys, GatherLds<64>& S) {
   uint32_t npad = E;
   while (npad < n) npad <<= 1;
   // Waves whose key slots all lie beyond npad would hold +inf padding only: they leave NOW (a
@@ -616,7 +696,7 @@ __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, in
 #ifdef HGS_TIMELINE
   const unsigned long long tp2 = wall_clock64();
 #endif
-  gather_records(v, L, t, start, n, keys, (int)live);
+  gather_records<64>(v, L, t, start, n, keys, (int)live, S);
 #ifdef HGS_TIMELINE
   if (threadIdx.x == 0 && blockIdx.x < HGS_TL_SLOTS) {     // phases of this tile's sort (wave 0): kernel id 5
     hgs_tl[5][blockIdx.x][0] = tp1 - tp0;
@@ -638,7 +718,7 @@ __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, in
 namespace {
 template <int NT>
 __device__ __forceinline__ void sort_lds_body(const View& v, const Layout& L, const hgs_status* __restrict__ status,
-                                              unsigned long long* keys) {
+                                              unsigned long long* keys, GatherLds<64>& S) {
   if (status->overflow) return;
   const uint32_t b = blockIdx.x;
   if (b >= status->active_tiles) return;
@@ -649,9 +729,9 @@ __device__ __forceinline__ void sort_lds_body(const View& v, const Layout& L, co
   constexpr int E0 = 1024 / NT;
   // (4 keys per thread for every list <= 2048 at 512 threads, i.e. half the waves for lists <= 1024,
   // was measured: single view 34 -> 39 us, 8 views 158 -> 150 us; not kept)
-  if (n <= 1024u) sort_one_tile<E0, NT>(v, L, t, start, n, keys);
-  else if (n <= 2048u) sort_one_tile<2 * E0, NT>(v, L, t, start, n, keys);
-  else sort_one_tile<4 * E0, NT>(v, L, t, start, n, keys);
+  if (n <= 1024u) sort_one_tile<E0, NT>(v, L, t, start, n, keys, S);
+  else if (n <= 2048u) sort_one_tile<2 * E0, NT>(v, L, t, start, n, keys, S);
+  else sort_one_tile<4 * E0, NT>(v, L, t, start, n, keys, S);
 }
 }  // namespace
 
@@ -661,20 +741,23 @@ __device__ __forceinline__ void sort_lds_body(const View& v, const Layout& L, co
 extern "C" __global__ void __launch_bounds__(HGS_SORT_NT)
 hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[4096];
+  __shared__ GatherLds<64> S;
   HGS_TL_BEGIN();
-  sort_lds_body<HGS_SORT_NT>(v, L, status, keys);
+  sort_lds_body<HGS_SORT_NT>(v, L, status, keys, S);
   HGS_TL_END(3, blockIdx.x < status->active_tiles ? L.tile_n[L.tile_order[blockIdx.x]] : 0u);
 }
 
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_sort_lds_256(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[4096];
-  sort_lds_body<256>(v, L, status, keys);
+  __shared__ GatherLds<64> S;
+  sort_lds_body<256>(v, L, status, keys, S);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
 hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long keys[16384];
+  __shared__ GatherLds<256> S;
   if (status->overflow) return;
   const uint32_t b = blockIdx.x;
   if (b >= status->active_tiles) return;
@@ -688,7 +771,7 @@ hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   for (uint32_t k = threadIdx.x; k < n; k += 1024) keys[k] = L.keys[start + k];
   __syncthreads();
   bitonic_sort<1024>(keys, n);
-  gather_records(v, L, t, start, n, keys, 1024);
+  gather_records<256>(v, L, t, start, n, keys, 1024, S);
 }
 
 // Tiles with n > 16384 (longer than LDS): the same network run in place on the tile's key
@@ -703,6 +786,7 @@ hgs_k_sort_huge(View v, Layout L, const hgs_status* __restrict__ status) {
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_n[t];
   if (n <= 16384u) return;
+  __shared__ GatherLds<256> S;
   bitonic_sort<1024>(L.keys + start, n);
-  gather_records(v, L, t, start, n, L.keys + start, 1024);
+  gather_records<256>(v, L, t, start, n, L.keys + start, 1024, S);
 }

@@ -8,57 +8,53 @@
 //
 //   geom buffer   (saved for backward)          bin buffer (sized by entry capacity C, all views)
 //   ---------------------------------           --------------------------------------------
-//   GeomRec  geom[B*P]           64 B each      uint64  keys[C]     (depth_bits<<32 | idx)
-//   uint32   tile_n[B*T]         list length    SortRec recs[C]     48 B, depth-sorted per tile
-//   uint32   tile_start[B*T]     first entry    float   bstate[C/64][6][256]  per-bucket pixel state
-//   uint32   tile_bstart[B*T]    first bucket state       float segT[2C/SEG][256], segP[2C/SEG][7][256]
-//   uint32   tile_wgstart[B*T]   first backward item      uint2 seg_item[], wg_tile[]
-//   uint32   tile_msegstart[B*T] first segment plane
-//   uint32   tile_maxcontrib[B*T]               img buffer:  uint32 n_contrib[B][H*W]
-//   uint32   tile_order[B*T]     heavy first    bwd scratch: float grad_rows[R][12]
+//   GeomRec  geom[B*P]           64 B each      uint64  keys[C]        (depth_bits<<32 | idx)
+//   uint32   tile_n[B*T]         list length    SortRec recs[C]        48 B, depth-sorted per tile
+//   uint32   tile_start[B*T]     first entry    uint32  cell_list[16C] record indices, CELL-major per tile
+//   uint32   tile_order[B*T]     heavy first    uint32  pairslot[16C]  entry-major -> slot in cell_list
+//   CellInfo cell_info[B*T][16]  the 16 cell    float   cstate[C/4][6][16]  pixel state every 64 cell-list entries
+//            lists of a tile                    uint2   items_full[C/4] backward work items (full segments)
+//   uint2    items_part[3][16 B*T] backward work items (last, partial segment of every cell list)
 //   uint32   hist[B*nwg][T]      per-binning-workgroup tile histograms (T <= 16384)
 //   uint32   tile_gbase[RG][B*T] absolute base of a row group inside the tile's list
 //   uint32   chunk_sums/base[B*P/256]  entry-id ranges of the 256-Gaussian chunks
-//   Counters ctr                 bump allocators, class histogram, ticket
-//   hgs_status
+//   Counters ctr                 bump allocators, class histogram, tickets
+//   hgs_status                                  img buffer:  uint32 n_contrib[B][H*W]
+//                                               bwd scratch: float grad_rows[R][12], pair_rows[16R][12]
 //
-// A tile's list, its bucket states, its backward work items and its segment planes are RANGES
-// handed out by bump allocation (one 64-bit atomic per 64 tiles), not by a prefix scan over the
-// tiles: where a range lives does not influence any result, so nothing is lost, and the
-// single-workgroup scan chain of the first design (21 us of latency for 32 KB of data) is gone.
-// The same holds for a Gaussian's entry-id range (`GeomRec::offset`).
+// A 16x16 tile is cut into 16 CELLS of 4x4 pixels.  The sort kernel gives every entry a 16-bit cell
+// mask (cellmask.h: the exact ellipse-vs-rectangle test of alpha >= 1/255) and writes, per tile, 16
+// depth-ordered CELL LISTS (indices of the records that can touch the cell).  Both blend kernels walk
+// cell lists: a wave64 is four ROWS of 16 lanes, row = one cell (4x4 pixels), and every row streams
+// ITS OWN list - a Gaussian costs lane time only in the cells it reaches (57 lane slots per entry
+// instead of 97 with 8x8 quadrants, 256 without culling, tools/cell_stats.py).
 //
-// wave = 64 lanes everywhere; a "bucket" is 64 consecutive entries of one tile's list.
+// A tile's list and its pair range are RANGES handed out by bump allocation, not by a prefix scan
+// over the tiles: where a range lives does not influence any result.
+//
+// wave = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/hgs_rast.h"
+#include "cellmask.h"
 
 #define HGS_TILE 16
 #define HGS_TILE_PIX 256
 #define HGS_BLOCK 256          // Gaussians per preprocess / fill chunk
-#define HGS_BUCKET 64          // entries per backward bucket (= one wave)
-#ifndef HGS_BWD_WAVES
-#define HGS_BWD_WAVES 1        // waves per backward bucket (each sweeps 4 / HGS_BWD_WAVES quadrants);
-                               // measured 1 / 2 / 4: 96 / 98 / 100 us (100k Gaussians), 165 / 207 / 231 us (500k)
-#endif
 #define HGS_ROW_GROUPS 16      // histogram row groups walked in parallel by hgs_k_tiles (one wave each)
 #define HGS_TILES_PER_WG 64    // tiles per hgs_k_tiles workgroup
-#ifndef HGS_SEG
-#define HGS_SEG 256            // entries per forward segment (list-parallel blend), multiple of 64
-#endif
-#ifndef HGS_SEG_THRESH
-#define HGS_SEG_THRESH 1024    // only tile lists longer than this are cut into segments: short
-                               // lists blend faster in one piece (measured)
-#endif
-#define HGS_SEG_PLANES 7       // per-segment pixel planes: C0 C1 C2 D W Tend(signed) last(bits)
+#define HGS_RB 16              // records a row stages per batch (= lanes of a row)
+#define HGS_SEGLEN 64          // cell-list entries per backward work item; the forward stores the pixel state
+                               // of a cell at every multiple of this
+#define HGS_PAIRS_PER_ENTRY 16 // capacity of the pair arrays per entry of capacity (worst case: every cell)
 #define HGS_NEAR_Z 0.2f
 #define HGS_ALPHA_MIN (1.0f / 255.0f)
 #define HGS_ALPHA_MAX 0.99f
 #define HGS_T_EPS 0.0001f
-#define HGS_BSTATE_FLOATS (6 * HGS_TILE_PIX)   // T, C0, C1, C2, D, W per pixel
-#define HGS_ROW_FLOATS 12                       // grad row per entry (10 used)
+#define HGS_CSTATE_FLOATS (6 * 16)             // T, C0, C1, C2, D, W for the 16 pixels of a cell
+#define HGS_ROW_FLOATS 12                       // gradient row per entry / per (entry, cell) pair (10 used)
 #define HGS_NCLS 33                             // tile classes by log2(list length); class 0 = empty
 
 struct __attribute__((aligned(16))) GeomRec {   // 64 B, one per (view, Gaussian)
@@ -81,59 +77,58 @@ struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian
   float qa, qb, qc;     // conic folded for exp2: qa=-0.5*ca*log2e, qb=-cb*log2e, qc=-0.5*cc*log2e
   float op, r, g, b, depth;
   uint32_t entry;       // entry id = geom.offset + position of the tile in the rect
-  uint32_t idx_mask;    // Gaussian index within the view (low 28 bits) | quadrant cull mask << 28
+  uint32_t pairs;       // low 27 bits: first pair of this entry relative to the tile's pair range (entry-major),
+                        // high 5 bits: number of pairs (= cells the entry can touch, 0..16)
 };
 #define HGS_LOG2E 1.4426950408889634f
 
+struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a tile
+  uint32_t base;        // first slot of the list in cell_list / pair_rows (absolute)
+  uint32_t len;         // records in the list
+  uint32_t sbase;       // first pixel-state slot (cstate): slot sbase + s - 1 holds the state before entry 64 s
+  uint32_t pbase;       // the TILE's first pair slot (entry-major index space of pairslot)
+};
+
 // Device-side counters of one forward call (zeroed by the first workgroup of the preprocess kernel).
 struct Counters {
-  unsigned long long alloc_eb;   // low: entries handed out to tiles (= R when done), high: bucket states
-  unsigned long long alloc_ws;   // low: backward work items,                         high: segment planes
+  unsigned long long alloc_eb;   // low: entries handed out to tiles (= R when done)
+  unsigned long long alloc_ps;   // low: pairs handed out to tiles, high: cell states
   uint32_t entry_alloc;          // entry ids handed out to Gaussians (= R when done)
-  uint32_t ticket;               // hgs_k_tiles workgroups that have finished
+  uint32_t bwd_ticket;           // next group of four backward work items (persistent waves; reset by the reduce kernel)
   uint32_t max_n;                // longest tile list
   uint32_t pad;
-  uint32_t bwd_cur[4];           // backward work items placed so far, per cost class (0 = most expensive): classes 0 / 1
-                                 // fill the first item table from its front / back, classes 2 / 3 the second one
+  uint32_t item_cur[4];          // backward work items placed so far: [0] full segments, [1..3] partial ones by length
   uint32_t cls_hist[HGS_NCLS];   // tiles per class
   uint32_t cls_cur[HGS_NCLS];    // tile_order cursor per class (starts at the class base, heavy first)
 };
 
-// Backward work items are dispatched in table order, and the kernel ends with its last item: the
-// forward sorts them into four cost classes (kept (entry, quadrant) pairs of the bucket) so that
-// expensive buckets start first and the cheapest ones fill the tail.  Classes 0 and 1 share one
-// table (front / back), classes 2 and 3 a second one: no class needs to know another's size while
-// the forward is still placing items.  Position r of class c among `total` items:
-__host__ __device__ __forceinline__ size_t hgs_bwd_item_slot(uint32_t cls, uint32_t r, uint32_t total, uint32_t capacity) {
-  const size_t table = (cls >> 1) ? (size_t)capacity + capacity / HGS_BUCKET + 2 : 0;
-  return table + ((cls & 1u) ? (size_t)(total - 1u - r) : (size_t)r);
+// Backward work item = HGS_SEGLEN consecutive entries of one cell list (the last item of a list may be
+// shorter).  Four items make a wave (one per row), so items are handed out longest first and in classes of
+// similar length: class 0 = full segments; 1 / 2 / 3 = partial ones with >= 43 / >= 22 / fewer entries.
+__host__ __device__ __forceinline__ uint32_t hgs_item_class(uint32_t cnt) {
+  return cnt >= HGS_SEGLEN ? 0u : (cnt >= 43u ? 1u : (cnt >= 22u ? 2u : 3u));
 }
 
 struct Layout {          // pointers carved out of the caller's buffers
   GeomRec* geom;
   uint32_t* tile_n;
   uint32_t* tile_start;
-  uint32_t* tile_bstart;
-  uint32_t* tile_wgstart;
-  uint32_t* tile_msegstart;   // index of a tile's first segment plane (tiles with more than one segment)
-  uint32_t* tile_maxcontrib;
   uint32_t* tile_order;
   uint32_t* hist;             // [B*nwg][T] per-workgroup tile histograms -> exclusive bases inside a row group
   uint32_t* tile_gbase;       // [HGS_ROW_GROUPS][B*T] absolute base of each row group in the tile's list
   uint32_t* tile_count;       // [B*T] global-atomic path only (T > 16384): counts, then fill cursor
   uint32_t* chunk_sums;       // [B*nblk] tiles_touched summed over a 256-Gaussian chunk
   uint32_t* chunk_base;       // [B*nblk] first entry id of the chunk (bump-allocated)
+  CellInfo* cell_info;        // [B*T][16]
+  uint2* items_part;          // [2][16 B*T]: table 0 holds class 1 (from the front) and class 2 (from the back), table 1 class 3
   Counters* ctr;
-  uint2* seg_item;            // [<= 2C/HGS_SEG + 4] (tile, segment) of every segment of the long lists
-  uint4* wg_tile;             // two tables of [C + C/64 + 2]: (tile, bucket, list start, list length) of every backward
-                              // work item, by cost class (hgs_bwd_item_slot)
-                              // (written by the forward: the backward wave finds its records with ONE load)
   unsigned long long* keys;
   SortRec* recs;
-  float* bstate;
-  float* segT;             // [2C/SEG][256]   product of (1-alpha) over a (non-last) segment
-  float* segP;             // [2C/SEG][7][256] per-segment partial sums -> exclusive prefix (base)
-  uint32_t* n_contrib;     // [B][H*W]
+  uint32_t* cell_list;        // [16 C]
+  uint32_t* pairslot;         // [16 C]
+  float* cstate;              // [C/4 + 1][6][16]
+  uint2* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, segment)
+  uint32_t* n_contrib;        // [B][H*W]  1 + cell-list rank of the pixel's last contributor
 };
 
 struct Cam {             // per-view constants (device pointers stay with the caller)
@@ -153,28 +148,15 @@ struct View {            // per-call constants, passed by value to every kernel
   int32_t cpw, nwg, lds_bins;        // chunks per binning workgroup, binning workgroups PER VIEW, LDS path?
   uint32_t entry_capacity;
   int32_t max_tile_hint;             // >0: caller promises no tile list is longer (else overflow bit 2)
-  int32_t seg_off;                   // 1: the caller's hint proves no list exceeds HGS_SEG_THRESH
-  int32_t seg_recompute;             // 1: the hint proves lists have <= 12 segments: no segT pre-pass
   int32_t act;                       // HGS_ACT_* bits: inputs are RAW parameters, activations fused into preprocess
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// number of forward segments of a tile list of n entries (a pure function of n, so results do
-// not depend on hints or call history)
-__host__ __device__ __forceinline__ uint32_t hgs_nseg(uint32_t n) {
-  return n > HGS_SEG_THRESH ? (n + HGS_SEG - 1) / HGS_SEG : 1u;
-}
-
-// Forward pixel ownership: four waves per tile, wave w owns the 8x8 quadrant (w&1, w>>1),
-// lane l is (l&7, l>>3) inside it.  `pf` in [0,256) (= forward thread index) is the index
-// under which the forward stores per-pixel bucket / segment state; the backward and the
-// combine kernel map it back to a pixel with the same function.
-__device__ __forceinline__ void hgs_fwd_thread_pixel(int pf, int& lx, int& ly) {
-  const int w = pf >> 6, l = pf & 63;
-  lx = ((w & 1) << 3) | (l & 7);
-  ly = ((w >> 1) << 3) | (l >> 3);
-}
+// Pixel ownership in both blend kernels: wave w of a tile's workgroup owns the 8x8 quadrant (w&1, w>>1); its row j
+// (lanes 16 j .. 16 j + 15) owns the 4x4 cell (2 (w&1) + (j&1), 2 (w>>1) + (j>>1)); lane i of the row is pixel
+// (i & 3, i >> 2) of the cell.  Cell index c = cy * 4 + cx (the bit order of hgs_cell_mask).
+__device__ __forceinline__ int hgs_cell_of(int w, int j) { return (((w >> 1) << 1) + (j >> 1)) * 4 + ((w & 1) << 1) + (j & 1); }
 #define HGS_FWD_THREADS 256
 
 // The one place alpha is evaluated, shared by forward and backward so both take the

@@ -56,8 +56,8 @@ typedef struct hgs_settings {
 typedef struct hgs_status {
   uint32_t num_rendered;   /* R = sum of tiles touched (upstream's `num_rendered`)      */
   uint32_t active_tiles;   /* tiles with a non-empty list                              */
-  uint32_t num_buckets;    /* 64-Gaussian bucket states the forward stored             */
-  uint32_t bwd_groups;     /* workgroups hgs_backward launches for the blend backward  */
+  uint32_t num_buckets;    /* unused since ABI v11 (0)                                 */
+  uint32_t bwd_groups;     /* unused since ABI v11 (0): the blend backward runs persistent waves */
   uint32_t overflow;       /* != 0: outputs are INVALID.  bit0: R exceeded              */
                            /* entry_capacity (retry with >= num_rendered); bit1: a tile */
                            /* list exceeded max_tile_entries_hint (retry with hint 0)   */
