@@ -6,6 +6,7 @@
 //   backward work items) -> render_fwd (one workgroup per tile, heavy first)
 // Backward: render_bwd (persistent waves, four cell-list segments each) -> pair_reduce -> preprocess_bwd.
 #include "hgs_common.h"
+#include <stdlib.h>
 
 // The forward kernels and the per-Gaussian backward are included here (one translation
 // unit, SLP vectorisation on: the forward blend is latency-bound and profits from v_pk_*).
@@ -462,21 +463,22 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   float* pair_rows = rows + (size_t)X * HGS_ROW_FLOATS;
   HGS_STAGE(0);
   if (maybe_entries) {
-    // persistent waves: as many as the chip holds (LDS: 11.8 KB per wave), each fetches groups of four work items
+    // persistent waves: as many as the chip holds (LDS: 11.8 KB per wave => 12 per CU, 3 per SIMD), each fetches
+    // groups of four work items
     static int resident = 0;
     if (resident == 0) {
-      int per_cu = 0, dev = 0;
-      hipDeviceProp_t prop;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hgs_k_render_bwd, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
-      resident = per_cu * prop.multiProcessorCount;
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+      int per_cu = 12;
+      if (const char* e = getenv("HGS_BWD_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;     // (experiments)
+      resident = per_cu * cus;
     }
     hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)resident), dim3(64), 0, stream, v, L, status_dev, L.recs, L.cstate,
                        out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows);
     HGS_LAUNCH_CHECK();
-    const int64_t tiles = status ? (int64_t)status->active_tiles : (int64_t)v.TT;
-    if (tiles > 0) {
-      hipLaunchKernelGGL(hgs_k_pair_reduce, dim3((unsigned)tiles), dim3(256), 0, stream, v, L, status_dev, L.recs,
+    if (X > 0) {
+      hipLaunchKernelGGL(hgs_k_pair_reduce, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
                          pair_rows, rows);
       HGS_LAUNCH_CHECK();
     }

@@ -240,6 +240,59 @@ hgs_k_fill_ga(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __r
 // ---------------------------------------------------------------------------- 3. sort
 namespace {
 
+// Ranges of one tile, from the lengths of its 16 cell lists: pairs (= cell-list slots), cell states, work items.
+// Wave 0 of the workgroup, lane c = cell c.  Writes cell_info, the items, cell_base[] and pair_base (LDS).
+__device__ __forceinline__ void hgs_alloc_cell_ranges(const View& v, const Layout& L, int g, const uint32_t* cell_tot,
+                                                      uint32_t* cell_base, uint32_t& pair_base_out) {
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  if (tid < 64) {
+    const bool cl = lane < 16;
+    const uint32_t len = cl ? cell_tot[lane] : 0u;
+    const uint32_t nfull = len / HGS_SEGLEN, rem = len % HGS_SEGLEN;
+    const uint32_t nseg = nfull + (rem ? 1u : 0u);
+    const uint32_t nst = nseg ? nseg - 1u : 0u;
+    const uint32_t i_len = hgs_wave_incl_scan(len), i_st = hgs_wave_incl_scan(nst), i_full = hgs_wave_incl_scan(nfull);
+    const uint32_t pcls = rem ? hgs_item_class(rem) : 0u;            // 1..3 for a partial last segment
+    const unsigned long long b1 = __ballot(pcls == 1u), b2 = __ballot(pcls == 2u), b3 = __ballot(pcls == 3u);
+    // the bump allocations travel together: ONE atomic instruction, lanes 0..2 on three 64-bit counters (a device-scope
+    // atomic is a trip to the memory side of the fabric: five of them in a row were 13 us of every tile's chain)
+    const uint32_t t_len = (uint32_t)__builtin_amdgcn_readlane((int)i_len, 63);
+    const uint32_t t_st = (uint32_t)__builtin_amdgcn_readlane((int)i_st, 63);
+    const uint32_t t_full = (uint32_t)__builtin_amdgcn_readlane((int)i_full, 63);
+    const unsigned long long add = lane == 0 ? ((unsigned long long)t_len | ((unsigned long long)t_st << 32))
+                                 : lane == 1 ? ((unsigned long long)t_full | ((unsigned long long)__popcll(b1) << 32))
+                                             : ((unsigned long long)__popcll(b2) | ((unsigned long long)__popcll(b3) << 32));
+    unsigned long long got = 0;
+    if (lane < 3 && add) got = atomicAdd(&L.ctr->alloc3[lane], add);
+    const uint32_t got_lo = (uint32_t)got, got_hi = (uint32_t)(got >> 32);
+    const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 0);
+    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 0);
+    const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 1);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 1);
+    const uint32_t p2 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 2);
+    const uint32_t p3 = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 2);
+    if (cl) {
+      const uint32_t base = pb + i_len - len;
+      cell_base[lane] = base;
+      CellInfo ci;
+      ci.base = base; ci.len = len; ci.sbase = sb + i_st - nst; ci.pbase = pb;
+      L.cell_info[(size_t)g * 16 + lane] = ci;
+      const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
+      uint2* full = L.items_full + (fb + i_full - nfull);
+      for (uint32_t sgm = 0; sgm < nfull; ++sgm) full[sgm] = make_uint2(key, sgm);
+      if (rem) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const size_t ptab = (size_t)16 * v.TT;
+        uint2 it = make_uint2(key, nfull | (rem << 24));
+        if (pcls == 1u) L.items_part[p1 + (uint32_t)__popcll(b1 & below)] = it;
+        else if (pcls == 2u) L.items_part[ptab - 1 - (p2 + (uint32_t)__popcll(b2 & below))] = it;
+        else L.items_part[ptab + p3 + (uint32_t)__popcll(b3 & below)] = it;
+      }
+    }
+    if (lane == 0) pair_base_out = pb;
+  }
+}
+
 // LDS tables of the record gather (one workgroup = one tile): MAXCH 64-record chunks per pass.
 template <int MAXCH>
 struct GatherLds {
@@ -309,7 +362,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
         dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
         dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-        dst[2] = make_uint4(g2.x, g2.y, entry, 0u);         // .pairs follows in sweep 2
+        dst[2] = make_uint4(g2.x, g2.y, entry | ((uint32_t)__popc(mask) << 27), 0u);         // .pairs follows in sweep 2
         sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
       }
 #pragma unroll
@@ -321,53 +374,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
   }
   if (lane < 16 && mytot) atomicAdd(&S.cell_tot[lane], mytot);
   __syncthreads();
-  // ---- ranges of this tile: pairs (= cell-list slots), cell states, work items.  Wave 0, lane c = cell c.
-  if (tid < 64) {
-    const bool cl = lane < 16;
-    const uint32_t len = cl ? S.cell_tot[lane] : 0u;
-    const uint32_t nfull = len / HGS_SEGLEN, rem = len % HGS_SEGLEN;
-    const uint32_t nseg = nfull + (rem ? 1u : 0u);
-    const uint32_t nst = nseg ? nseg - 1u : 0u;
-    const uint32_t i_len = hgs_wave_incl_scan(len), i_st = hgs_wave_incl_scan(nst), i_full = hgs_wave_incl_scan(nfull);
-    const uint32_t pcls = rem ? hgs_item_class(rem) : 0u;            // 1..3 for a partial last segment
-    const unsigned long long b1 = __ballot(pcls == 1u), b2 = __ballot(pcls == 2u), b3 = __ballot(pcls == 3u);
-    // five bump allocations travel together (lanes 0..4 issue them)
-    const uint32_t t_len = (uint32_t)__builtin_amdgcn_readlane((int)i_len, 63);
-    const uint32_t t_st = (uint32_t)__builtin_amdgcn_readlane((int)i_st, 63);
-    const uint32_t t_full = (uint32_t)__builtin_amdgcn_readlane((int)i_full, 63);
-    unsigned long long got = 0;
-    if (lane == 0 && (t_len | t_st)) got = atomicAdd(&L.ctr->alloc_ps, (unsigned long long)t_len | ((unsigned long long)t_st << 32));
-    if (lane == 1 && t_full) got = atomicAdd(&L.ctr->item_cur[0], t_full);
-    if (lane == 2 && b1) got = atomicAdd(&L.ctr->item_cur[1], (uint32_t)__popcll(b1));
-    if (lane == 3 && b2) got = atomicAdd(&L.ctr->item_cur[2], (uint32_t)__popcll(b2));
-    if (lane == 4 && b3) got = atomicAdd(&L.ctr->item_cur[3], (uint32_t)__popcll(b3));
-    const uint32_t got_lo = (uint32_t)got, got_hi = (uint32_t)(got >> 32);
-    const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 0);
-    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 0);
-    const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 1);
-    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 2);
-    const uint32_t p2 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 3);
-    const uint32_t p3 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 4);
-    if (cl) {
-      const uint32_t base = pb + i_len - len;
-      S.cell_base[lane] = base;
-      CellInfo ci;
-      ci.base = base; ci.len = len; ci.sbase = sb + i_st - nst; ci.pbase = pb;
-      L.cell_info[(size_t)g * 16 + lane] = ci;
-      const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
-      uint2* full = L.items_full + (fb + i_full - nfull);
-      for (uint32_t sgm = 0; sgm < nfull; ++sgm) full[sgm] = make_uint2(key, sgm);
-      if (rem) {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const size_t ptab = (size_t)16 * v.TT;
-        uint2 it = make_uint2(key, nfull | (rem << 24));
-        if (pcls == 1u) L.items_part[p1 + (uint32_t)__popcll(b1 & below)] = it;
-        else if (pcls == 2u) L.items_part[ptab - 1 - (p2 + (uint32_t)__popcll(b2 & below))] = it;
-        else L.items_part[ptab + p3 + (uint32_t)__popcll(b3 & below)] = it;
-      }
-    }
-    if (lane == 0) S.pair_base = pb;
-  }
+  hgs_alloc_cell_ranges(v, L, g, S.cell_tot, S.cell_base, S.pair_base);
   __syncthreads();
   // ---- sweep 2: cell lists and pair slots, MAXCH chunks per pass
   const uint32_t pair_base = S.pair_base;
@@ -412,7 +419,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
       const uint32_t mask = in ? (uint32_t)sorted[k] : 0u;
       const uint32_t cnt = (uint32_t)__popc(mask);
       const uint32_t rel = S.tab[ch][16] + hgs_wave_incl_scan(cnt) - cnt;      // entry-major, relative to the tile
-      if (in) L.recs[start + k].pairs = rel | (cnt << 27);
+      if (in) L.recs[start + k].pairs = pair_base + rel;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const bool bit = (mask >> c) & 1u;
@@ -427,6 +434,162 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
     }
     __syncthreads();
   }
+}
+
+// ---- the same for lists of at most MAXCH * 64 entries (every sort class but `huge`), without ballots:
+// a record's 16 mask bits are SPREAD into four words of four byte counters (bit 4 w + b -> byte b of word w);
+// a DPP wave scan of those four words then yields, for all 16 cells at once, how many records of the 64-record
+// chunk touch each cell before this lane (<= 64: a byte holds it).  One table pass, no recount.
+__device__ __forceinline__ uint32_t hgs_spread4(uint32_t nib) {          // 4 bits -> 4 bytes of 0 / 1
+  return (nib * 0x00204081u) & 0x01010101u;
+}
+__device__ __forceinline__ uint32_t hgs_bytesum(uint32_t w) { return __builtin_amdgcn_sad_u8(w, 0u, 0u); }
+
+template <int MAXCH>
+__device__ __forceinline__ void gather_records_single(const View& v, const Layout& L, int g,
+                                                      uint32_t start, uint32_t n,
+                                                      unsigned long long* sorted, int nt, GatherLds<MAXCH>& S) {
+  const int t = g % v.T;
+  const GeomRec* __restrict__ geom = L.geom + (size_t)(g / v.T) * v.P;
+  const uint32_t* __restrict__ cbase = L.chunk_base + (size_t)(g / v.T) * v.nblk;
+  const int tx = t % v.grid_x, ty = t / v.grid_x;
+  const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wv = tid >> 6, nwaves = nt >> 6;
+  const uint32_t nch = (n + 63u) / 64u;                 // <= MAXCH
+#ifdef HGS_TIMELINE
+  const unsigned long long tg0 = wall_clock64();
+#define HGS_TG(i) const unsigned long long tg##i = wall_clock64()
+#else
+#define HGS_TG(i)
+#endif
+  // ---- sweep 1: records + masks; per chunk the packed per-cell counts (tab[ch][0..3]) and its pairs (tab[ch][16])
+  constexpr int GU = 4;
+  for (uint32_t kb0 = 0; kb0 < n; kb0 += (uint32_t)nt * GU) {      // (wave-uniform trip count: wave scans inside)
+    const uint32_t kb = kb0 + threadIdx.x;
+    uint32_t idxv[GU];
+    uint4 q0[GU], q1[GU], q2[GU];
+    uint32_t q3[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const uint32_t k = kb + (uint32_t)u * nt;
+      idxv[u] = (k < n) ? (uint32_t)sorted[k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const uint32_t k = kb + (uint32_t)u * nt;
+      if (k < n) {
+        const uint4* gp = reinterpret_cast<const uint4*>(&geom[idxv[u]]);
+        q0[u] = gp[0]; q1[u] = gp[1]; q2[u] = gp[2]; q3[u] = gp[3].x;        // g3: only the entry-id offset
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const uint32_t k = kb + (uint32_t)u * nt;
+      if (kb0 + (uint32_t)u * nt + (uint32_t)(wv * 64) >= n) continue;       // (wave-uniform) chunk beyond the list
+      uint32_t mask = 0;
+      if (k < n) {
+        const uint32_t idx = idxv[u];
+        const uint4 g0 = q0[u], g1 = q1[u], g2 = q2[u];
+        // g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi | q3: offset
+        const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;
+        const uint32_t entry = cbase[idx >> 8] + q3[u] + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx));
+        const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);
+        const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x);
+        mask = hgs_cell_mask(mx, my, ca, cb, cc, __uint_as_float(g1.y), x0, y0);
+        uint4* dst = reinterpret_cast<uint4*>(&L.recs[start + k]);
+        const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
+        dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
+        dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
+        dst[2] = make_uint4(g2.x, g2.y, entry | ((uint32_t)__popc(mask) << 27), 0u);         // .pairs follows in sweep 2
+        sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
+      }
+      const uint32_t ch = k >> 6;
+      uint32_t tot[4];
+#pragma unroll
+      for (int wd = 0; wd < 4; ++wd) tot[wd] = hgs_wave_incl_scan(hgs_spread4((mask >> (4 * wd)) & 0xfu));
+      if (lane == 63) {
+        S.tab[ch][0] = tot[0]; S.tab[ch][1] = tot[1]; S.tab[ch][2] = tot[2]; S.tab[ch][3] = tot[3];
+        S.tab[ch][16] = hgs_bytesum(tot[0]) + hgs_bytesum(tot[1]) + hgs_bytesum(tot[2]) + hgs_bytesum(tot[3]);
+      }
+    }
+  }
+  __syncthreads();
+  HGS_TG(1);
+  // ---- exclusive prefix over the chunks for the 16 cells (unpacked to 32 bits, columns 0..15 rewritten in
+  // place AFTER every wave has read its packed words) and for the pairs (column 16); totals -> cell_tot
+  {
+    uint32_t pk[(MAXCH + 63) / 64][4];
+#pragma unroll
+    for (int r = 0; r < (MAXCH + 63) / 64; ++r) {
+      const uint32_t ch = (uint32_t)r * 64u + lane;
+#pragma unroll
+      for (int wd = 0; wd < 4; ++wd) pk[r][wd] = (wv < 5 && ch < nch) ? S.tab[ch][wd] : 0u;
+    }
+    __syncthreads();
+    // wave wd < 4 unpacks word wd (cells 4 wd .. 4 wd + 3); wave 4 (or wave 0 when there are fewer) scans the pairs
+    for (int col = wv; col < 5; col += nwaves) {
+      uint32_t carry[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int r = 0; r < (MAXCH + 63) / 64; ++r) {
+        const uint32_t ch = (uint32_t)r * 64u + lane;
+        if ((uint32_t)r * 64u >= nch) break;
+        if (col < 4) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const uint32_t x = (pk[r][col] >> (8 * b)) & 0xffu;
+            const uint32_t inc = hgs_wave_incl_scan(x);
+            if (ch < nch) S.tab[ch][4 * col + b] = carry[b] + inc - x;
+            carry[b] += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+          }
+        } else {
+          const uint32_t x = ch < nch ? S.tab[ch][16] : 0u;
+          const uint32_t inc = hgs_wave_incl_scan(x);
+          if (ch < nch) S.tab[ch][16] = carry[0] + inc - x;
+          carry[0] += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+      }
+      if (col < 4 && lane < 4) S.cell_tot[4 * col + lane] = lane == 0 ? carry[0] : lane == 1 ? carry[1] : lane == 2 ? carry[2] : carry[3];
+    }
+  }
+  __syncthreads();
+  HGS_TG(2);
+  hgs_alloc_cell_ranges(v, L, g, S.cell_tot, S.cell_base, S.pair_base);
+  __syncthreads();
+  HGS_TG(3);
+  // ---- sweep 2: cell lists and pair slots
+  const uint32_t pair_base = S.pair_base;
+  for (uint32_t ch = wv; ch < nch; ch += nwaves) {
+    const uint32_t k = ch * 64u + lane;
+    const bool in = k < n;
+    uint32_t mask = in ? (uint32_t)sorted[k] : 0u;
+    uint32_t ex[4], before = 0;                          // records of this chunk before this lane, per cell (bytes)
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+      const uint32_t mine = hgs_spread4((mask >> (4 * wd)) & 0xfu);
+      ex[wd] = hgs_wave_incl_scan(mine) - mine;
+      before += hgs_bytesum(ex[wd]);
+    }
+    const uint32_t rel = S.tab[ch][16] + before;          // entry-major, relative to the tile
+    if (in) L.recs[start + k].pairs = pair_base + rel;
+    uint32_t r = 0;
+    while (mask) {
+      const int c = __builtin_ctz(mask);
+      mask &= mask - 1u;
+      const uint32_t exw = (c < 8) ? (c < 4 ? ex[0] : ex[1]) : (c < 12 ? ex[2] : ex[3]);
+      const uint32_t slot = S.cell_base[c] + S.tab[ch][c] + ((exw >> (8 * (c & 3))) & 0xffu);
+      L.cell_list[slot] = start + k;
+      L.pairslot[pair_base + rel + r] = slot;
+      ++r;
+    }
+  }
+#ifdef HGS_TIMELINE
+  if (threadIdx.x == 0 && blockIdx.x < HGS_TL_SLOTS) {      // phases of this tile's gather (wave 0), 10 ns ticks, 16 bits each
+    const unsigned long long tg4 = wall_clock64();
+    auto cl = [](unsigned long long d) { return d > 0xffffull ? 0xffffull : d; };
+    hgs_tl[2][blockIdx.x][0] = cl(tg1 - tg0) | (cl(tg2 - tg1) << 16) | (cl(tg3 - tg2) << 32) | (cl(tg4 - tg3) << 48);
+  }
+#endif
 }
 
 // Bitonic network in its "all comparators ascending" form (first stage of every merge
@@ -696,7 +859,7 @@ __device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, in
 #ifdef HGS_TIMELINE
   const unsigned long long tp2 = wall_clock64();
 #endif
-  gather_records<64>(v, L, t, start, n, keys, (int)live, S);
+  gather_records_single<64>(v, L, t, start, n, keys, (int)live, S);
 #ifdef HGS_TIMELINE
   if (threadIdx.x == 0 && blockIdx.x < HGS_TL_SLOTS) {     // phases of this tile's sort (wave 0): kernel id 5
     hgs_tl[5][blockIdx.x][0] = tp1 - tp0;
@@ -771,7 +934,7 @@ hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   for (uint32_t k = threadIdx.x; k < n; k += 1024) keys[k] = L.keys[start + k];
   __syncthreads();
   bitonic_sort<1024>(keys, n);
-  gather_records<256>(v, L, t, start, n, keys, 1024, S);
+  gather_records_single<256>(v, L, t, start, n, keys, 1024, S);
 }
 
 // Tiles with n > 16384 (longer than LDS): the same network run in place on the tile's key

@@ -46,6 +46,8 @@
 #define HGS_ROW_GROUPS 16      // histogram row groups walked in parallel by hgs_k_tiles (one wave each)
 #define HGS_TILES_PER_WG 64    // tiles per hgs_k_tiles workgroup
 #define HGS_RB 16              // records a row stages per batch (= lanes of a row)
+#define HGS_ROW_F4 (HGS_RB * 3 + 1)   // float4 per staged row: 16 records of 48 B + 16 B, so that the four rows of a wave
+                               // (which read four DIFFERENT records per ds_read_b128) sit on different LDS banks
 #define HGS_SEGLEN 64          // cell-list entries per backward work item; the forward stores the pixel state
                                // of a cell at every multiple of this
 #define HGS_PAIRS_PER_ENTRY 16 // capacity of the pair arrays per entry of capacity (worst case: every cell)
@@ -76,9 +78,9 @@ struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian
   float mx, my;         // pixel-space mean
   float qa, qb, qc;     // conic folded for exp2: qa=-0.5*ca*log2e, qb=-cb*log2e, qc=-0.5*cc*log2e
   float op, r, g, b, depth;
-  uint32_t entry;       // entry id = geom.offset + position of the tile in the rect
-  uint32_t pairs;       // low 27 bits: first pair of this entry relative to the tile's pair range (entry-major),
-                        // high 5 bits: number of pairs (= cells the entry can touch, 0..16)
+  uint32_t entry;       // low 27 bits: entry id = geom.offset + position of the tile in the rect;
+                        // high 5 bits: number of (entry, cell) pairs = cells the entry can reach (0..16)
+  uint32_t pairs;       // first pair of this entry in `pairslot` (entry-major index space)
 };
 #define HGS_LOG2E 1.4426950408889634f
 
@@ -92,12 +94,13 @@ struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a
 // Device-side counters of one forward call (zeroed by the first workgroup of the preprocess kernel).
 struct Counters {
   unsigned long long alloc_eb;   // low: entries handed out to tiles (= R when done)
-  unsigned long long alloc_ps;   // low: pairs handed out to tiles, high: cell states
+  unsigned long long alloc3[3];  // bump allocators of the sort kernel (ONE three-lane atomic per tile): [0] low: pairs handed out
+                                 // to tiles, high: cell states; [1] low / high: backward work items of class 0 (full segments) /
+                                 // class 1; [2] low / high: class 2 / class 3
   uint32_t entry_alloc;          // entry ids handed out to Gaussians (= R when done)
-  uint32_t bwd_ticket;           // next group of four backward work items (persistent waves; reset by the reduce kernel)
+  uint32_t pad0;
   uint32_t max_n;                // longest tile list
   uint32_t pad;
-  uint32_t item_cur[4];          // backward work items placed so far: [0] full segments, [1..3] partial ones by length
   uint32_t cls_hist[HGS_NCLS];   // tiles per class
   uint32_t cls_cur[HGS_NCLS];    // tile_order cursor per class (starts at the class base, heavy first)
 };

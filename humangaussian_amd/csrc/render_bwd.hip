@@ -5,7 +5,8 @@
 // that can reach it, depth-ordered; written by the sort kernel): the forward stored the cell's per-pixel
 // running state (T, C, D, W) at every 64th entry, so all items are independent.  A wave64 is FOUR ROWS of
 // 16 lanes; each row takes one work item (any cell of any tile), lane = pixel of the row's cell.  Persistent
-// waves fetch groups of four items, longest first (full segments, then partial ones by length class).
+// waves take groups of four items round-robin from a longest-first table (full segments, then partial ones by
+// length class).
 //
 // Per row iteration (one record at 16 pixels), with
 //       S_j = c_j . g_C + d_j g_D + g_A   (g_* = incoming pixel gradients),
@@ -39,6 +40,12 @@
 // This file is its own translation unit (it compiles in parallel with api.hip; same flags).
 #include "hgs_common.h"
 
+#ifndef HGS_BWD_AHEAD
+#define HGS_BWD_AHEAD 2                // records whose LDS reads run ahead of the evaluation
+#endif
+#ifndef HGS_ABL
+#define HGS_ABL 0                      // timing experiments only (bit 0: no MFMA, 1: no evaluation, 2: no pair-row stores, 3: no record gather)
+#endif
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
@@ -68,17 +75,18 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                  const float* __restrict__ dL_dalpha, float* __restrict__ pair_rows) {
-  __shared__ float4 s_rec[4 * HGS_RB * 3];                                         // [row][record][3]
+  __shared__ float4 s_rec[4 * HGS_ROW_F4];                                         // [row][record][3] (+ pad: rows on different banks)
   __shared__ __attribute__((aligned(16))) float stage_k[HGS_RB * HGS_STAGE_STRIDE];   // [iteration][pixel lane]
   __shared__ __attribute__((aligned(16))) float stage_w[HGS_RB * HGS_STAGE_STRIDE];
   if (status->overflow) return;
   const int lane = (int)threadIdx.x;
   const int j = lane >> 4, i = lane & 15;
-  const uint32_t n0 = L.ctr->item_cur[0], n1 = L.ctr->item_cur[1], n2 = L.ctr->item_cur[2], n3 = L.ctr->item_cur[3];
+  const uint32_t n0 = (uint32_t)L.ctr->alloc3[1], n1 = (uint32_t)(L.ctr->alloc3[1] >> 32);      // items per class
+  const uint32_t n2 = (uint32_t)L.ctr->alloc3[2], n3 = (uint32_t)(L.ctr->alloc3[2] >> 32);
   const uint32_t ngroups = (n0 + n1 + n2 + n3 + 3u) / 4u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all);
-  float4* __restrict__ srow = s_rec + (j * HGS_RB) * 3;
+  float4* __restrict__ srow = s_rec + j * HGS_ROW_F4;
 
   // ---- MFMA operand A of the two moment chains: constants of the lane.  Lane l supplies A[m = l & 15][kk = l >> 4];
   // m = (cell jj = m >> 2, quantity q = m & 3); block diagonal: zero unless jj == kk.  Instruction t: in-cell pixel t.
@@ -94,12 +102,19 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     A2[t] = diag ? f2 : 0.0f;
   }
 
-  for (;;) {
-    // ---- next group of four items (persistent wave; the ticket is reset by hgs_k_pair_reduce)
-    uint32_t grp = 0;
-    if (lane == 0) grp = atomicAdd(&L.ctr->bwd_ticket, 1u);
-    grp = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp);
-    if (grp >= ngroups) break;
+#ifdef HGS_TIMELINE
+  // per group: wall start | end | batches  (into L.keys: free after the sort)
+  unsigned long long tl_w0 = 0;
+  uint32_t tl_nb = 0;
+#endif
+#define HGS_TACC(i)
+  // Persistent waves, static round-robin over the groups of four items: wave w takes groups w, w + W, ... - the
+  // table is longest first, so every wave gets a similar mix.  (A shared ticket - one device-scope atomic per group on
+  // ONE address - serialised at the memory side of the fabric: ~10 ns each, 110 us for the 10^4 fetches of a view.)
+  for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+#ifdef HGS_TIMELINE
+    tl_w0 = wall_clock64(); tl_nb = 0;
+#endif
     uint2 item = make_uint2(0u, 0u);
     const bool have = fetch_item(v, L, 4u * grp + (uint32_t)j, n0, n1, n2, n3, item);
     const uint32_t key = item.x, seg = item.y & 0xffffffu;
@@ -199,12 +214,17 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float il = 1.0f / HGS_LOG2E;
       const float opi = (pop != 0.0f) ? 1.0f / pop : 0.0f;
       float4* row = reinterpret_cast<float4*>(prow + (size_t)(it0 + (uint32_t)i) * HGS_ROW_FLOATS);
+      if (HGS_ABL & 4) { if (k00 == 123.456f) row[0] = zero4; return; }
       row[0] = make_float4(x0 * il, x1 * il, sxx * -0.5f, sxy * -1.0f);
       row[1] = make_float4(syy * -0.5f, k00 * opi, a3[0], a3[1]);
       row[2] = make_float4(a3[2], a3[3], 0.0f, 0.0f);
     };
 
+    HGS_TACC(0);
     for (uint32_t it0 = 0; it0 < maxcnt; it0 += HGS_RB) {
+#ifdef HGS_TIMELINE
+      ++tl_nb;
+#endif
       // does any pixel of any row still contribute at or behind this batch?  (positions: lane 16 j holds the batch's first record)
       const uint32_t bfirst = (uint32_t)__shfl((int)__float_as_uint(c2.w), lane & 48, 64);
       const unsigned long long act = __ballot((it0 < cnt) && (bfirst <= nc));
@@ -215,7 +235,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       }
       // next batch's records, the indices after that (also when this batch is skipped)
       c0 = zero4; c1 = zero4; c2 = zero4;
-      if (idx_next != 0xffffffffu) {
+      if (idx_next != 0xffffffffu && !(HGS_ABL & 8)) {
         c0 = recs[3 * (size_t)idx_next]; c1 = recs[3 * (size_t)idx_next + 1]; c2 = recs[3 * (size_t)idx_next + 2];
         c2.w = __uint_as_float(idx_next - tstart1);
       }
@@ -233,11 +253,20 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // ---- 16 iterations: everything that depends on (pixel, record); T and F are the only carried values
-#pragma unroll 4
+      if (!(HGS_ABL & 2)) {
+      // (the LDS reads of record u + HGS_BWD_AHEAD are in flight while record u is evaluated)
+      float4 q0[HGS_BWD_AHEAD], q1[HGS_BWD_AHEAD], q2[HGS_BWD_AHEAD];
+#pragma unroll
+      for (int u = 0; u < HGS_BWD_AHEAD; ++u) { q0[u] = srow[3 * u + 0]; q1[u] = srow[3 * u + 1]; q2[u] = srow[3 * u + 2]; }
+#pragma unroll
       for (int u = 0; u < HGS_RB; ++u) {
-        const float4 r0 = srow[3 * u + 0];    // mx my qa qb
-        const float4 r1 = srow[3 * u + 1];    // qc op r g
-        const float4 r2 = srow[3 * u + 2];    // b depth - position in the tile list
+        const float4 r0 = q0[u % HGS_BWD_AHEAD];    // mx my qa qb
+        const float4 r1 = q1[u % HGS_BWD_AHEAD];    // qc op r g
+        const float4 r2 = q2[u % HGS_BWD_AHEAD];    // b depth - position in the tile list
+        if (u + HGS_BWD_AHEAD < HGS_RB) {
+          q0[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 0]; q1[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 1];
+          q2[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 2];
+        }
         // same dx/dy expressions as the forward so skip decisions agree
         const float dx = r0.x - pxf, dy = r0.y - pyf;
         float G, alpha, m2, m3;
@@ -256,11 +285,14 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         stage_k[u * HGS_STAGE_STRIDE + lane] = am * dLda;      // k = dL/dG * G
         stage_w[u * HGS_STAGE_STRIDE + lane] = wgt;
       }
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      HGS_TACC(1);
       // keep the previous batch's accumulators in AGPRs up to here: read any earlier and the wave
       // waits for its MFMA chains before evaluating this batch (no overlap)
       if (pending) { asm volatile("" : "+a"(pa1), "+a"(pa2), "+a"(pa3)); finish(pa1, pa2, pa3, pit); }
+      HGS_TACC(3);
       // operand B: lane 16 kk + n reads (iteration n, pixels of row kk): 16 consecutive floats per stage
       hgs_f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
       {
@@ -274,6 +306,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           const float wx[4] = {bw.x, bw.y, bw.z, bw.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            if (HGS_ABL & 1) continue;
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * q4 + r], kx[r], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[4 * q4 + r], kx[r], acc2, 0, 0, 0);
             acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[4 * q4 + r], wx[r], acc3, 0, 0, 0);
@@ -282,44 +315,62 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();                 // the next batch overwrites the stages
+      HGS_TACC(2);
       pa1 = acc1; pa2 = acc2; pa3 = acc3;
       pmx = mxr; pmy = myr; pqa = qar; pqb = qbr; pqc = qcr; pop = opr;
       pit = it0;
       pending = true;
     }
     if (pending) finish(pa1, pa2, pa3, pit);
+#ifdef HGS_TIMELINE
+    if (lane == 0) {
+      unsigned long long* o = L.keys + (size_t)grp * 4;
+      o[0] = tl_w0; o[1] = wall_clock64(); o[2] = tl_nb; o[3] = (unsigned long long)(cnt) | 1ull << 63;
+    }
+#endif
   }
 }
 
 // ------------------------------------------------------------------------------ pair reduction
 // One gradient row per tile entry = the sum of the entry's (entry, cell) pair rows, cells in ascending order
-// (deterministic).  Workgroup = one tile (heavy first), thread = entry; an entry's pair slots sit behind each
-// other in `pairslot` (entry-major), so neighbouring threads read neighbouring slots.
+// (deterministic).  Thread = entry (record index); an entry's pair slots sit behind each other in `pairslot`
+// (entry-major), so neighbouring threads read neighbouring slots.
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
                   const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) L.ctr->bwd_ticket = 0;      // the next backward over this state starts at group 0
-  if (status->overflow || blockIdx.x >= status->active_tiles) return;
-  const int g = (int)L.tile_order[blockIdx.x];
-  const uint32_t start = L.tile_start[g], n = L.tile_n[g];
-  if (n == 0) return;
-  const uint32_t pbase = L.cell_info[(size_t)g * 16].pbase;
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (status->overflow || p >= status->num_rendered) return;
+  const uint2 ep = *reinterpret_cast<const uint2*>(&recs_all[p].entry);    // entry id | pairs << 27, first pair
+  const uint32_t entry = ep.x & 0x7ffffffu, cnt = ep.x >> 27;
+  const uint32_t* __restrict__ ps = L.pairslot + ep.y;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (uint32_t k = threadIdx.x; k < n; k += 256) {
-    const uint2 ep = *reinterpret_cast<const uint2*>(&recs_all[start + k].entry);    // entry id, pairs
-    const uint32_t rel = ep.y & 0x7ffffffu, cnt = ep.y >> 27;
-    const uint32_t* __restrict__ ps = L.pairslot + pbase + rel;
-    float4 s0 = zero4, s1 = zero4;
-    float2 s2 = make_float2(0.f, 0.f);
-    for (uint32_t r = 0; r < cnt; ++r) {
-      const float4* row = reinterpret_cast<const float4*>(pair_rows + (size_t)ps[r] * HGS_ROW_FLOATS);
-      const float4 a = row[0], b = row[1];
-      const float2 c = *reinterpret_cast<const float2*>(&row[2]);
-      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-      s2.x += c.x; s2.y += c.y;
+  float4 s0 = zero4, s1 = zero4;
+  float2 s2 = make_float2(0.f, 0.f);
+  constexpr uint32_t U = 4;                 // pair rows in flight per thread
+  for (uint32_t r0 = 0; r0 < cnt; r0 += U) {
+    uint32_t sl[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) sl[u] = (r0 + u < cnt) ? ps[r0 + u] : 0xffffffffu;
+    float4 a[U], b[U];
+    float2 c[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      a[u] = zero4; b[u] = zero4; c[u] = make_float2(0.f, 0.f);
+      if (sl[u] != 0xffffffffu) {
+        const float4* row = reinterpret_cast<const float4*>(pair_rows + (size_t)sl[u] * HGS_ROW_FLOATS);
+        a[u] = row[0]; b[u] = row[1];
+        c[u] = *reinterpret_cast<const float2*>(&row[2]);
+      }
     }
-    float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)ep.x * HGS_ROW_FLOATS);
-    dst[0] = s0; dst[1] = s1; dst[2] = make_float4(s2.x, s2.y, 0.0f, 0.0f);
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      if (r0 + u < cnt) {                   // (adding the zeros of an absent row could turn -0 into +0)
+        s0.x += a[u].x; s0.y += a[u].y; s0.z += a[u].z; s0.w += a[u].w;
+        s1.x += b[u].x; s1.y += b[u].y; s1.z += b[u].z; s1.w += b[u].w;
+        s2.x += c[u].x; s2.y += c[u].y;
+      }
+    }
   }
+  float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
+  dst[0] = s0; dst[1] = s1; dst[2] = make_float4(s2.x, s2.y, 0.0f, 0.0f);
 }

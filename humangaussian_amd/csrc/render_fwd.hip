@@ -56,7 +56,9 @@ __device__ __forceinline__ void blend_one(PixState& s, float pxf, float pyf, con
 
 }  // namespace
 
-#define HGS_FWD_GROUP 4          // records of a batch whose LDS reads are issued together
+#ifndef HGS_FWD_GROUP
+#define HGS_FWD_GROUP 2          // records of a batch whose LDS reads are issued together (one group ahead of the blend)
+#endif
 
 template <bool STORE>
 __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
@@ -66,7 +68,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
                                                 float* __restrict__ out_color,
                                                 float* __restrict__ out_depth,
                                                 float* __restrict__ out_alpha) {
-  __shared__ float4 s_rec[HGS_FWD_THREADS / 64][4 * HGS_RB * 3];      // [wave][row][record][3]: 3 KB per wave
+  __shared__ float4 s_rec[HGS_FWD_THREADS / 64][4 * HGS_ROW_F4];      // [wave][row][record][3] (+ pad): 3 KB per wave
   const bool overflow = status->overflow != 0;
   const uint32_t p = blockIdx.x;
   if (p >= (uint32_t)v.TT) return;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
   }
   const uint32_t* __restrict__ list = L.cell_list + base;
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all);
-  float4* __restrict__ srow = s_rec[w] + (j * HGS_RB) * 3;            // this row's 16 staged records
+  float4* __restrict__ srow = s_rec[w] + j * HGS_ROW_F4;              // this row's 16 staged records
 
   PixState s;
   s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
@@ -135,16 +137,26 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
     idx_next = (row_on && in2 < len) ? list[in2] : 0xffffffffu;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-    for (int u0 = 0; u0 < HGS_RB; u0 += HGS_FWD_GROUP) {
-      float4 ra[HGS_FWD_GROUP], rb[HGS_FWD_GROUP], rc[HGS_FWD_GROUP];
+    // groups of HGS_FWD_GROUP records; the LDS reads of group k + 1 are in flight while group k is blended
+    float4 ra[HGS_FWD_GROUP], rb[HGS_FWD_GROUP], rc[HGS_FWD_GROUP];
 #pragma unroll
-      for (int u = 0; u < HGS_FWD_GROUP; ++u) {
-        ra[u] = srow[3 * (u0 + u) + 0]; rb[u] = srow[3 * (u0 + u) + 1];
-        rc[u] = srow[3 * (u0 + u) + 2];
+    for (int u = 0; u < HGS_FWD_GROUP; ++u) { ra[u] = srow[3 * u + 0]; rb[u] = srow[3 * u + 1]; rc[u] = srow[3 * u + 2]; }
+#pragma unroll
+    for (int u0 = 0; u0 < HGS_RB; u0 += HGS_FWD_GROUP) {
+      float4 na[HGS_FWD_GROUP], nb[HGS_FWD_GROUP], nc[HGS_FWD_GROUP];
+      if (u0 + HGS_FWD_GROUP < HGS_RB) {
+#pragma unroll
+        for (int u = 0; u < HGS_FWD_GROUP; ++u) {
+          na[u] = srow[3 * (u0 + HGS_FWD_GROUP + u) + 0]; nb[u] = srow[3 * (u0 + HGS_FWD_GROUP + u) + 1];
+          nc[u] = srow[3 * (u0 + HGS_FWD_GROUP + u) + 2];
+        }
       }
 #pragma unroll
       for (int u = 0; u < HGS_FWD_GROUP; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
+      if (u0 + HGS_FWD_GROUP < HGS_RB) {
+#pragma unroll
+        for (int u = 0; u < HGS_FWD_GROUP; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
+      }
     }
   }
 
