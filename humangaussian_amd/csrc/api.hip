@@ -7,6 +7,7 @@
 // Backward: render_bwd (persistent waves, four cell-list segments each) -> pair_reduce -> preprocess_bwd.
 #include "hgs_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 // The forward kernels and the per-Gaussian backward are included here (one translation
 // unit, SLP vectorisation on: the forward blend is latency-bound and profits from v_pk_*).
@@ -46,7 +47,7 @@ constexpr int HGS_MAX_BIN_WGS_PER_VIEW = HGS_BIN_WGS_PER_VIEW_MAX;
 constexpr int HGS_BIN_WGS_TOTAL = HGS_BIN_WGS_TOTAL_MAX;      // binning workgroups of a batch (all views)
 
 struct GeomCarve {
-  size_t geom, tile_n, tile_start, tile_order, cell_info, items_part,
+  size_t geom, tile_n, tile_start, tile_order, cell_info, items_part, fwd_cells,
       hist, tile_gbase, tile_count, chunk_sums, chunk_base, ctr, status, total;
 };
 
@@ -78,6 +79,7 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   c.tile_order = take(TT * 4);
   c.cell_info = take(TT * 16 * sizeof(CellInfo));
   c.items_part = take(2 * 16 * TT * sizeof(uint2));      // last (partial) segment of every cell list, by length class
+  c.fwd_cells = take((size_t)HGS_NFC * 16 * TT * 4);       // non-empty cells by length class
   c.hist = take(lds ? (size_t)B * nwg * T * 4 : 0);
   c.tile_gbase = take(lds ? (size_t)HGS_ROW_GROUPS * TT * 4 : 0);
   c.tile_count = take(lds ? 0 : TT * 4);
@@ -89,7 +91,7 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, cell_list, pairslot, cstate, items_full, total; };
+struct BinCarve { size_t keys, recs, cell_list, cstate, items_full, total; };
 
 // Pair-sized arrays hold HGS_PAIRS_PER_ENTRY slots per entry of capacity: an entry can reach all 16 cells of
 // its tile (zoomed-in cameras), so no second capacity (and no second overflow path) exists.
@@ -101,8 +103,7 @@ BinCarve carve_bin(int64_t cap) {
   const size_t NP = C * HGS_PAIRS_PER_ENTRY;
   c.keys = take(C * 8);
   c.recs = take(C * sizeof(SortRec));
-  c.cell_list = take(NP * 4);
-  c.pairslot = take(NP * 4);
+  c.cell_list = take(NP * 8);
   // a cell list of len entries has ceil(len / 64) - 1 stored states and ceil(len / 64) work items, len / 64 of them full
   c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
   c.items_full = take((NP / HGS_SEGLEN + 1) * sizeof(uint2));
@@ -122,6 +123,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.tile_order = reinterpret_cast<uint32_t*>(gp + g.tile_order);
   L.cell_info = reinterpret_cast<CellInfo*>(gp + g.cell_info);
   L.items_part = reinterpret_cast<uint2*>(gp + g.items_part);
+  L.fwd_cells = reinterpret_cast<uint32_t*>(gp + g.fwd_cells);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.tile_gbase = reinterpret_cast<uint32_t*>(gp + g.tile_gbase);
   L.tile_count = reinterpret_cast<uint32_t*>(gp + g.tile_count);
@@ -130,8 +132,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.ctr = reinterpret_cast<Counters*>(gp + g.ctr);
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
-  L.cell_list = bp ? reinterpret_cast<uint32_t*>(bp + b.cell_list) : nullptr;
-  L.pairslot = bp ? reinterpret_cast<uint32_t*>(bp + b.pairslot) : nullptr;
+  L.cell_list = bp ? reinterpret_cast<uint2*>(bp + b.cell_list) : nullptr;
   L.cstate = bp ? reinterpret_cast<float*>(bp + b.cstate) : nullptr;
   L.items_full = bp ? reinterpret_cast<uint2*>(bp + b.items_full) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
@@ -376,7 +377,8 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
       hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
       HGS_LAUNCH_CHECK();
     }
-    if (v.B >= HGS_SORT_256_MIN_VIEWS)
+    static const int sort_force = getenv("HGS_SORT_SHAPE") ? atoi(getenv("HGS_SORT_SHAPE")) : 0;     // (experiments: 256 / 512)
+    if (sort_force == 256 || (sort_force != 512 && v.B >= HGS_SORT_256_MIN_VIEWS))
       hipLaunchKernelGGL(hgs_k_sort_lds_256, dim3(class_grid(1)), dim3(256), 0, stream, v, L, status_dev);
     else
       hipLaunchKernelGGL(hgs_k_sort_lds, dim3(class_grid(1)), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
@@ -385,13 +387,28 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     HGS_STAGE(3);
   }
   HGS_STAGE(4);
-  // Blend: one workgroup per tile, heavy first; four independent waves, each four cell rows (render_fwd.hip)
-  if (store_bwd_state)
-    hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, status_dev, L.recs,
-                       L.cstate, out_color, out_depth, out_alpha);
-  else
-    hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, status_dev, L.recs,
-                       L.cstate, out_color, out_depth, out_alpha);
+  // Blend: waves of four cells of one length class, longest first, then the background of the empty cells
+  // (render_fwd.hip).  Non-empty cells <= min(16 B T, pairs): a capacity bound, surplus waves leave at once.
+  {
+    // persistent cell waves: enough to fill the chip (4 waves per block; 4 blocks per CU), never more than the cells
+    const int64_t cells = std::min<int64_t>((int64_t)16 * v.TT, (int64_t)HGS_PAIRS_PER_ENTRY * entry_capacity);
+    static int fwd_blocks = 0;
+    if (fwd_blocks == 0) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+      int per_cu = 4;
+      if (const char* e = getenv("HGS_FWD_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;     // (experiments)
+      fwd_blocks = per_cu * cus;
+    }
+    const unsigned cell_blocks = (unsigned)std::min<int64_t>(fwd_blocks, (cells + 3) / 4);
+    if (store_bwd_state)
+      hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(cell_blocks + v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
+                         status_dev, L.recs, L.cstate, out_color, out_depth, out_alpha);
+    else
+      hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(cell_blocks + v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
+                         status_dev, L.recs, L.cstate, out_color, out_depth, out_alpha);
+  }
   HGS_LAUNCH_CHECK();
   HGS_STAGE(5);
   return HGS_OK;

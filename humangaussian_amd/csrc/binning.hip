@@ -259,11 +259,23 @@ __device__ __forceinline__ void hgs_alloc_cell_ranges(const View& v, const Layou
     const uint32_t t_len = (uint32_t)__builtin_amdgcn_readlane((int)i_len, 63);
     const uint32_t t_st = (uint32_t)__builtin_amdgcn_readlane((int)i_st, 63);
     const uint32_t t_full = (uint32_t)__builtin_amdgcn_readlane((int)i_full, 63);
+    // forward work items: every non-empty cell goes into the table of its length class; lane 3 + c allocates for class c
+    const uint32_t fcls = hgs_cell_class(len);
+    unsigned long long fb_ = 0;                        // cells of this tile in "my" class (lanes 3 .. 3 + HGS_NFC - 1)
+    uint32_t frank = 0;                                // rank of this lane's cell inside its class, within the tile
+#pragma unroll
+    for (int c = 0; c < HGS_NFC; ++c) {
+      const unsigned long long bc = __ballot(cl && len && fcls == (uint32_t)c);
+      if (lane == 3 + c) fb_ = bc;
+      if (fcls == (uint32_t)c) frank = (uint32_t)__popcll(bc & ((1ull << lane) - 1ull));
+    }
     const unsigned long long add = lane == 0 ? ((unsigned long long)t_len | ((unsigned long long)t_st << 32))
                                  : lane == 1 ? ((unsigned long long)t_full | ((unsigned long long)__popcll(b1) << 32))
-                                             : ((unsigned long long)__popcll(b2) | ((unsigned long long)__popcll(b3) << 32));
+                                 : lane == 2 ? ((unsigned long long)__popcll(b2) | ((unsigned long long)__popcll(b3) << 32))
+                                             : (unsigned long long)__popcll(fb_);
     unsigned long long got = 0;
-    if (lane < 3 && add) got = atomicAdd(&L.ctr->alloc3[lane], add);
+    if (lane < 3 + HGS_NFC && add) got = atomicAdd(&L.ctr->alloc3[lane], add);
+    const uint32_t fpos = (uint32_t)__shfl((int)(uint32_t)got, 3 + (int)fcls, 64) + frank;
     const uint32_t got_lo = (uint32_t)got, got_hi = (uint32_t)(got >> 32);
     const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 0);
     const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 0);
@@ -278,6 +290,7 @@ __device__ __forceinline__ void hgs_alloc_cell_ranges(const View& v, const Layou
       ci.base = base; ci.len = len; ci.sbase = sb + i_st - nst; ci.pbase = pb;
       L.cell_info[(size_t)g * 16 + lane] = ci;
       const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
+      if (len) L.fwd_cells[(size_t)fcls * 16u * v.TT + fpos] = key;
       uint2* full = L.items_full + (fb + i_full - nfull);
       for (uint32_t sgm = 0; sgm < nfull; ++sgm) full[sgm] = make_uint2(key, sgm);
       if (rem) {
@@ -305,8 +318,8 @@ struct GatherLds {
 
 // After the sort: (1) gather the Gaussians into the depth-ordered 48 B record list, computing every entry's
 // 16-bit cell mask (cellmask.h); (2) allocate the tile's pair range, cell-state range and backward work
-// items; (3) write the 16 depth-ordered cell lists and, entry-major, where each (entry, cell) pair sits in
-// them (`pairslot`: the reduce kernel sums an entry's pair rows through it).  `sorted` (LDS or HBM) holds
+// items; (3) write the 16 depth-ordered cell lists: (record index, pair id) per element; pair ids are entry-major,
+// so the backward's pair rows of one entry lie behind each other for the reduce kernel.  `sorted` (LDS or HBM) holds
 // the sorted keys on entry; its slots are reused for the masks.
 template <int MAXCH>
 __device__ __forceinline__ void gather_records(const View& v, const Layout& L, int g,
@@ -427,8 +440,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         if (bit) {
           const uint32_t rank = S.tab[ch][c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
           const uint32_t slot = S.cell_base[c] + rank;
-          L.cell_list[slot] = start + k;
-          L.pairslot[pair_base + rel + (uint32_t)__popc(mask & ((1u << c) - 1u))] = slot;
+          L.cell_list[slot] = make_uint2(start + k, pair_base + rel + (uint32_t)__popc(mask & ((1u << c) - 1u)));
         }
       }
     }
@@ -578,8 +590,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
       mask &= mask - 1u;
       const uint32_t exw = (c < 8) ? (c < 4 ? ex[0] : ex[1]) : (c < 12 ? ex[2] : ex[3]);
       const uint32_t slot = S.cell_base[c] + S.tab[ch][c] + ((exw >> (8 * (c & 3))) & 0xffu);
-      L.cell_list[slot] = start + k;
-      L.pairslot[pair_base + rel + r] = slot;
+      L.cell_list[slot] = make_uint2(start + k, pair_base + rel + r);
       ++r;
     }
   }

@@ -10,11 +10,12 @@
 //   ---------------------------------           --------------------------------------------
 //   GeomRec  geom[B*P]           64 B each      uint64  keys[C]        (depth_bits<<32 | idx)
 //   uint32   tile_n[B*T]         list length    SortRec recs[C]        48 B, depth-sorted per tile
-//   uint32   tile_start[B*T]     first entry    uint32  cell_list[16C] record indices, CELL-major per tile
-//   uint32   tile_order[B*T]     heavy first    uint32  pairslot[16C]  entry-major -> slot in cell_list
+//   uint32   tile_start[B*T]     first entry    uint2   cell_list[16C] (record index, pair id), CELL-major per tile
+//   uint32   tile_order[B*T]     heavy first                   pair ids are ENTRY-major: the pairs of an entry are neighbours
 //   CellInfo cell_info[B*T][16]  the 16 cell    float   cstate[C/4][6][16]  pixel state every 64 cell-list entries
 //            lists of a tile                    uint2   items_full[C/4] backward work items (full segments)
-//   uint2    items_part[3][16 B*T] backward work items (last, partial segment of every cell list)
+//   uint2    items_part[2][16 B*T] backward work items (last, partial segment of every cell list)
+//   uint32   fwd_cells[11][16 B*T] forward work items: non-empty cells by length class
 //   uint32   hist[B*nwg][T]      per-binning-workgroup tile histograms (T <= 16384)
 //   uint32   tile_gbase[RG][B*T] absolute base of a row group inside the tile's list
 //   uint32   chunk_sums/base[B*P/256]  entry-id ranges of the 256-Gaussian chunks
@@ -58,6 +59,7 @@
 #define HGS_CSTATE_FLOATS (6 * 16)             // T, C0, C1, C2, D, W for the 16 pixels of a cell
 #define HGS_ROW_FLOATS 12                       // gradient row per entry / per (entry, cell) pair (10 used)
 #define HGS_NCLS 33                             // tile classes by log2(list length); class 0 = empty
+#define HGS_NFC 11                              // length classes of the non-empty cells (forward work items)
 
 struct __attribute__((aligned(16))) GeomRec {   // 64 B, one per (view, Gaussian)
   float mx, my;         // pixel-space mean
@@ -80,23 +82,24 @@ struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian
   float op, r, g, b, depth;
   uint32_t entry;       // low 27 bits: entry id = geom.offset + position of the tile in the rect;
                         // high 5 bits: number of (entry, cell) pairs = cells the entry can reach (0..16)
-  uint32_t pairs;       // first pair of this entry in `pairslot` (entry-major index space)
+  uint32_t pairs;       // id of this entry's first (entry, cell) pair; pair ids are entry-major (the backward's pair rows)
 };
 #define HGS_LOG2E 1.4426950408889634f
 
 struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a tile
-  uint32_t base;        // first slot of the list in cell_list / pair_rows (absolute)
+  uint32_t base;        // first slot of the list in cell_list (absolute)
   uint32_t len;         // records in the list
   uint32_t sbase;       // first pixel-state slot (cstate): slot sbase + s - 1 holds the state before entry 64 s
-  uint32_t pbase;       // the TILE's first pair slot (entry-major index space of pairslot)
+  uint32_t pbase;       // the TILE's first pair id
 };
 
 // Device-side counters of one forward call (zeroed by the first workgroup of the preprocess kernel).
 struct Counters {
   unsigned long long alloc_eb;   // low: entries handed out to tiles (= R when done)
-  unsigned long long alloc3[3];  // bump allocators of the sort kernel (ONE three-lane atomic per tile): [0] low: pairs handed out
-                                 // to tiles, high: cell states; [1] low / high: backward work items of class 0 (full segments) /
-                                 // class 1; [2] low / high: class 2 / class 3
+  unsigned long long alloc3[3 + HGS_NFC];   // bump allocators of the sort kernel (ONE multi-lane atomic per tile - same-address
+                                 // device-scope atomics serialise at ~10 ns each): [0] low: pairs handed out to tiles, high:
+                                 // cell states; [1] low / high: backward work items of class 0 (full segments) / class 1;
+                                 // [2] low / high: class 2 / class 3; [3 + c]: non-empty cells of length class c (forward items)
   uint32_t entry_alloc;          // entry ids handed out to Gaussians (= R when done)
   uint32_t pad0;
   uint32_t max_n;                // longest tile list
@@ -112,6 +115,13 @@ __host__ __device__ __forceinline__ uint32_t hgs_item_class(uint32_t cnt) {
   return cnt >= HGS_SEGLEN ? 0u : (cnt >= 43u ? 1u : (cnt >= 22u ? 2u : 3u));
 }
 
+// Forward work item = one non-empty cell; a wave takes four cells of one class (rows of similar length end
+// together), classes in descending length: batches of 16 records >= 33, 25, 17, 13, 9, 7, 5, then 4, 3, 2, 1.
+__host__ __device__ __forceinline__ uint32_t hgs_cell_class(uint32_t len) {
+  const uint32_t nb = (len + HGS_RB - 1) / HGS_RB;
+  return nb >= 33u ? 0u : nb >= 25u ? 1u : nb >= 17u ? 2u : nb >= 13u ? 3u : nb >= 9u ? 4u : nb >= 7u ? 5u : nb >= 5u ? 6u : 11u - nb;
+}
+
 struct Layout {          // pointers carved out of the caller's buffers
   GeomRec* geom;
   uint32_t* tile_n;
@@ -123,12 +133,12 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* chunk_sums;       // [B*nblk] tiles_touched summed over a 256-Gaussian chunk
   uint32_t* chunk_base;       // [B*nblk] first entry id of the chunk (bump-allocated)
   CellInfo* cell_info;        // [B*T][16]
+  uint32_t* fwd_cells;        // [HGS_NFC][16 B*T]: cell keys (g * 16 + c) of the non-empty cells, per length class
   uint2* items_part;          // [2][16 B*T]: table 0 holds class 1 (from the front) and class 2 (from the back), table 1 class 3
   Counters* ctr;
   unsigned long long* keys;
   SortRec* recs;
-  uint32_t* cell_list;        // [16 C]
-  uint32_t* pairslot;         // [16 C]
+  uint2* cell_list;           // [16 C]: (record index, pair id)
   float* cstate;              // [C/4 + 1][6][16]
   uint2* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, segment)
   uint32_t* n_contrib;        // [B][H*W]  1 + cell-list rank of the pixel's last contributor

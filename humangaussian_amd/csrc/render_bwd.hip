@@ -29,7 +29,7 @@
 // The accumulator layout then puts ALL TEN sums of (row kk, record n) into lane 16 kk + n - the lane that
 // gathered that record - so the moment -> gradient conversion and the 48 B pair row need no shuffles.
 //
-// An (entry, cell) pair row lands at the pair's cell-list slot; hgs_k_pair_reduce adds the pair rows of
+// An (entry, cell) pair row lands at the pair's id (entry-major); hgs_k_pair_reduce adds the pair rows of
 // every entry in cell order (fixed order: no atomics, bitwise reproducible) into one 48 B gradient row per
 // entry, which hgs_k_preprocess_bwd sums per Gaussian.
 //
@@ -41,7 +41,7 @@
 #include "hgs_common.h"
 
 #ifndef HGS_BWD_AHEAD
-#define HGS_BWD_AHEAD 2                // records whose LDS reads run ahead of the evaluation
+#define HGS_BWD_AHEAD 1                // records whose LDS reads run ahead of the evaluation
 #endif
 #ifndef HGS_ABL
 #define HGS_ABL 0                      // timing experiments only (bit 0: no MFMA, 1: no evaluation, 2: no pair-row stores, 3: no record gather)
@@ -131,8 +131,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     const float cxq = (float)cx0 + 1.5f, cyq = (float)cy0 + 1.5f;      // cell centre
     const uint32_t e0 = seg * HGS_SEGLEN;                              // cell-list rank of the item's first entry
     const uint32_t tstart1 = have ? L.tile_start[g] - 1u : 0u;         // record index - tstart1 = 1-based position in the tile list
-    const uint32_t* __restrict__ list = L.cell_list + ci.base + e0;
-    float* __restrict__ prow = pair_rows + (size_t)(ci.base + e0) * HGS_ROW_FLOATS;
+    const uint2* __restrict__ list = L.cell_list + ci.base + e0;      // (record index, pair id)
 
     // per-pixel inputs
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, fp = 0.f;
@@ -180,13 +179,15 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     maxcnt = max(maxcnt, (uint32_t)__builtin_amdgcn_readlane((int)cnt, 48));
 
     // software pipeline of the record stream: indices two batches ahead, records one batch ahead
-    uint32_t idx_next = ((uint32_t)i < cnt) ? list[i] : 0xffffffffu;
+    const uint2 nol = make_uint2(0xffffffffu, 0u);
+    uint2 le_next = ((uint32_t)i < cnt) ? list[i] : nol;
+    uint32_t pid_cur = le_next.y;                       // pair id of the lane's record of the current batch
     float4 c0 = zero4, c1 = zero4, c2 = zero4;
-    if (idx_next != 0xffffffffu) {
-      c0 = recs[3 * (size_t)idx_next]; c1 = recs[3 * (size_t)idx_next + 1]; c2 = recs[3 * (size_t)idx_next + 2];
-      c2.w = __uint_as_float(idx_next - tstart1);
+    if (le_next.x != 0xffffffffu) {
+      c0 = recs[3 * (size_t)le_next.x]; c1 = recs[3 * (size_t)le_next.x + 1]; c2 = recs[3 * (size_t)le_next.x + 2];
+      c2.w = __uint_as_float(le_next.x - tstart1);
     }
-    idx_next = (HGS_RB + (uint32_t)i < cnt) ? list[HGS_RB + i] : 0xffffffffu;
+    le_next = (HGS_RB + (uint32_t)i < cnt) ? list[HGS_RB + i] : nol;
     {
       // A pixel whose last contributor (n_contrib, a tile-list position) lies before the item's first record
       // finished before this item - its forward row may have stopped without storing the state - and is never active.
@@ -197,7 +198,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     // the MFMA chains of batch b run while the wave evaluates batch b + 1; their results are picked up after that
     hgs_f32x4 pa1 = {0.f, 0.f, 0.f, 0.f}, pa2 = {0.f, 0.f, 0.f, 0.f}, pa3 = {0.f, 0.f, 0.f, 0.f};
     float pmx = 0.f, pmy = 0.f, pqa = 0.f, pqb = 0.f, pqc = 0.f, pop = 0.f;      // the lane's record of the pending batch
-    uint32_t pit = 0;
+    uint32_t pit = 0, ppid = 0;
     bool pending = false;
     // moments -> gradient sums of (this row, record i of the batch), written to the pair's slot
     auto finish = [&](const hgs_f32x4& a1, const hgs_f32x4& a2, const hgs_f32x4& a3, uint32_t it0) {
@@ -213,7 +214,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float x1 = __builtin_fmaf(pqb, sdx, (pqc + pqc) * sdy);
       const float il = 1.0f / HGS_LOG2E;
       const float opi = (pop != 0.0f) ? 1.0f / pop : 0.0f;
-      float4* row = reinterpret_cast<float4*>(prow + (size_t)(it0 + (uint32_t)i) * HGS_ROW_FLOATS);
+      float4* row = reinterpret_cast<float4*>(pair_rows + (size_t)ppid * HGS_ROW_FLOATS);
       if (HGS_ABL & 4) { if (k00 == 123.456f) row[0] = zero4; return; }
       row[0] = make_float4(x0 * il, x1 * il, sxx * -0.5f, sxy * -1.0f);
       row[1] = make_float4(syy * -0.5f, k00 * opi, a3[0], a3[1]);
@@ -235,17 +236,19 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       }
       // next batch's records, the indices after that (also when this batch is skipped)
       c0 = zero4; c1 = zero4; c2 = zero4;
-      if (idx_next != 0xffffffffu && !(HGS_ABL & 8)) {
-        c0 = recs[3 * (size_t)idx_next]; c1 = recs[3 * (size_t)idx_next + 1]; c2 = recs[3 * (size_t)idx_next + 2];
-        c2.w = __uint_as_float(idx_next - tstart1);
+      const uint32_t pid_this = pid_cur;
+      pid_cur = le_next.y;
+      if (le_next.x != 0xffffffffu && !(HGS_ABL & 8)) {
+        c0 = recs[3 * (size_t)le_next.x]; c1 = recs[3 * (size_t)le_next.x + 1]; c2 = recs[3 * (size_t)le_next.x + 2];
+        c2.w = __uint_as_float(le_next.x - tstart1);
       }
       const uint32_t in2 = it0 + 2 * HGS_RB + (uint32_t)i;
-      idx_next = (in2 < cnt) ? list[in2] : 0xffffffffu;
+      le_next = (in2 < cnt) ? list[in2] : nol;
       if (act == 0ull) {
         // nothing contributes any more (every pixel terminated before): zero pair rows, no evaluation
         if (pending) { asm volatile("" : "+a"(pa1), "+a"(pa2), "+a"(pa3)); finish(pa1, pa2, pa3, pit); pending = false; }
         if (it0 + (uint32_t)i < cnt) {
-          float4* row = reinterpret_cast<float4*>(prow + (size_t)(it0 + (uint32_t)i) * HGS_ROW_FLOATS);
+          float4* row = reinterpret_cast<float4*>(pair_rows + (size_t)pid_this * HGS_ROW_FLOATS);
           row[0] = zero4; row[1] = zero4; row[2] = zero4;
         }
         continue;
@@ -267,6 +270,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           q0[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 0]; q1[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 1];
           q2[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 2];
         }
+        __builtin_amdgcn_sched_barrier(0x7f);       // LDS reads stay ahead of the evaluation (the scheduler would sink them to their use)
         // same dx/dy expressions as the forward so skip decisions agree
         const float dx = r0.x - pxf, dy = r0.y - pyf;
         float G, alpha, m2, m3;
@@ -318,7 +322,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       HGS_TACC(2);
       pa1 = acc1; pa2 = acc2; pa3 = acc3;
       pmx = mxr; pmy = myr; pqa = qar; pqb = qbr; pqc = qcr; pop = opr;
-      pit = it0;
+      pit = it0; ppid = pid_this;
       pending = true;
     }
     if (pending) finish(pa1, pa2, pa3, pit);
@@ -333,33 +337,29 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 
 // ------------------------------------------------------------------------------ pair reduction
 // One gradient row per tile entry = the sum of the entry's (entry, cell) pair rows, cells in ascending order
-// (deterministic).  Thread = entry (record index); an entry's pair slots sit behind each other in `pairslot`
-// (entry-major), so neighbouring threads read neighbouring slots.
+// (deterministic).  Thread = entry (record index); pair ids are entry-major, so an entry's rows lie behind each
+// other and neighbouring threads read neighbouring rows: a streaming pass.
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
                   const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   if (status->overflow || p >= status->num_rendered) return;
-  const uint2 ep = *reinterpret_cast<const uint2*>(&recs_all[p].entry);    // entry id | pairs << 27, first pair
+  const uint2 ep = *reinterpret_cast<const uint2*>(&recs_all[p].entry);    // entry id | pairs << 27, first pair id
   const uint32_t entry = ep.x & 0x7ffffffu, cnt = ep.x >> 27;
-  const uint32_t* __restrict__ ps = L.pairslot + ep.y;
+  const float4* __restrict__ rows = reinterpret_cast<const float4*>(pair_rows + (size_t)ep.y * HGS_ROW_FLOATS);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 s0 = zero4, s1 = zero4;
   float2 s2 = make_float2(0.f, 0.f);
   constexpr uint32_t U = 4;                 // pair rows in flight per thread
   for (uint32_t r0 = 0; r0 < cnt; r0 += U) {
-    uint32_t sl[U];
-#pragma unroll
-    for (uint32_t u = 0; u < U; ++u) sl[u] = (r0 + u < cnt) ? ps[r0 + u] : 0xffffffffu;
     float4 a[U], b[U];
     float2 c[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u) {
       a[u] = zero4; b[u] = zero4; c[u] = make_float2(0.f, 0.f);
-      if (sl[u] != 0xffffffffu) {
-        const float4* row = reinterpret_cast<const float4*>(pair_rows + (size_t)sl[u] * HGS_ROW_FLOATS);
-        a[u] = row[0]; b[u] = row[1];
-        c[u] = *reinterpret_cast<const float2*>(&row[2]);
+      if (r0 + u < cnt) {
+        a[u] = rows[3 * (r0 + u)]; b[u] = rows[3 * (r0 + u) + 1];
+        c[u] = *reinterpret_cast<const float2*>(&rows[3 * (r0 + u) + 2]);
       }
     }
 #pragma unroll

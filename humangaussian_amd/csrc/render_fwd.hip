@@ -3,10 +3,12 @@
 // Upstream runs one thread block per 16x16 tile, every thread walks the tile's whole depth-sorted list and
 // evaluates every Gaussian at its pixel; on an avatar a Gaussian reaches alpha >= 1/255 on ~34 of those 256
 // pixels.  Here the tile is cut into 16 cells of 4x4 pixels and the sort kernel has written, per tile, 16
-// depth-ordered CELL LISTS holding only the records that can reach each cell (cellmask.h, exact).  One
-// workgroup = one tile = four independent wave64 (no workgroup barrier); wave w owns the 8x8 quadrant
-// (w&1, w>>1) and is FOUR ROWS of 16 lanes: row j = one cell, lane = one pixel, and every row streams
-// ITS OWN cell list:
+// depth-ordered CELL LISTS holding only the records that can reach each cell (cellmask.h, exact), and has
+// placed every non-empty cell into a table by LENGTH CLASS.  A wave64 is FOUR ROWS of 16 lanes; it takes four
+// cells of the same class - any cells of any tiles, longest classes first - row j = one cell, lane = one pixel,
+// and every row streams ITS OWN cell list (waves are independent: no workgroup barrier).  With the tile as
+// the unit of work (first version) a CU got ~3 active tiles of very different weight and the kernel ended
+// with the CU that drew the heaviest ones (48 us, half of it tail); rows of equal length also end together.
 //   1. the row's 16 lanes gather the next 16 records of the list (index load two batches ahead, 48 B record
 //      gather one batch ahead: both latencies hide behind the blend of the current batch) and stage them in
 //      a wave-private LDS slice;
@@ -28,97 +30,254 @@
 namespace {
 
 struct PixState {
-  float T, C0, C1, C2, D, Wt;
+  float T;          // running transmittance; 0 once the pixel has terminated (or lies outside the image)
+  float Tout;       // transmittance after the last blended record (what the background sees)
+  float C0, C1, C2, D, Wt;
   uint32_t last;
-  bool done;
 };
 
 // Blend one staged record into the lane's pixel, fully predicated.  r2.w carries the record's 1-based
 // position in the TILE's list (upstream's `contributor` count); pad records have opacity 0 and never blend.
+//
+// Upstream's rule - skip (power > 0 or alpha < 1/255), stop at test_T < 1e-4 WITHOUT blending that Gaussian,
+// nothing behind it counts - as arithmetic on ONE carried value: a terminated pixel's T becomes 0, so every
+// later test_T is 0 < 1e-4 and blends nothing.  The carried chain per record is v_mul -> v_cmp -> v_cndmask;
+// with a separate `done` flag it ran through four scalar mask operations per record (VALU -> SALU -> VALU
+// round trips), which is what a wave alone on its SIMD - the tail of this kernel - was waiting for.
+// Same values as the flag formulation, bit for bit (a skipped record multiplies T by exactly 1).
 __device__ __forceinline__ void blend_one(PixState& s, float pxf, float pyf, const float4 r0,
                                           const float4 r1, const float4 r2) {
   float G, alpha, m2, m3;
   const bool keep = hgs_eval_alpha(r0.x - pxf, r0.y - pyf, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
-  const bool live = keep && !s.done;
-  const float test_T = s.T * (1.0f - alpha);
-  const bool stop = live && (test_T < HGS_T_EPS);
-  const bool upd = live && !stop;
-  s.done = s.done || stop;
-  const float wgt = upd ? alpha * s.T : 0.0f;
+  const float ak = keep ? alpha : 0.0f;                 // off the carried chain
+  const float test_T = s.T * (1.0f - ak);
+  const bool ok = test_T >= HGS_T_EPS;                  // false from the terminating record on
+  const float wgt = ok ? ak * s.T : 0.0f;
+  s.T = ok ? test_T : 0.0f;
+  const bool upd = keep && ok;
   s.C0 = __builtin_fmaf(r1.z, wgt, s.C0);
   s.C1 = __builtin_fmaf(r1.w, wgt, s.C1);
   s.C2 = __builtin_fmaf(r2.x, wgt, s.C2);
   s.D = __builtin_fmaf(r2.y, wgt, s.D);
   s.Wt += wgt;
-  s.T = upd ? test_T : s.T;
+  s.Tout = upd ? test_T : s.Tout;
   s.last = upd ? __float_as_uint(r2.w) : s.last;
 }
 
 }  // namespace
 
+#ifndef HGS_FWD_C4
+#define HGS_FWD_C4 4            // length classes 0 .. HGS_FWD_C4 - 1 (>= 13 batches of 16 records) are walked four records at a time
+#endif
+typedef unsigned hgs_u32x2 __attribute__((ext_vector_type(2)));
 #ifndef HGS_FWD_GROUP
 #define HGS_FWD_GROUP 2          // records of a batch whose LDS reads are issued together (one group ahead of the blend)
 #endif
 
+// ---- LONG cell lists (length classes < HGS_FWD_C4: more than 192 records): ONE cell per wave, FOUR RECORDS per
+// iteration.  A wave issues one instruction per 4 cycles at best, so a 400-record list walked one record at a time
+// is a 20 us chain even with the SIMD to itself - the tail of this kernel (max wave 46 us at 100k Gaussians).
+// Here row r evaluates record 4 k + r at all 16 pixels; the transmittance in front of it is the carried T times the
+// product of (1 - alpha) of the rows before it - two cross-row exchanges (v_permlane16_swap / 32_swap, no LDS).
+// Upstream's stop rule needs no flag: products only shrink, so once a row fails test_T >= 1e-4 every later row
+// of the iteration fails with it.  Each lane sums the contributions of ITS records; the four rows are added at the
+// state boundaries (every 64 records = every staged block) and at the end, in a fixed order.
+__device__ __forceinline__ float hgs_xor16(float x, int lane) {
+  const hgs_u32x2 s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float((lane & 16) ? s2.x : s2.y);
+}
+__device__ __forceinline__ float hgs_xor32(float x, int lane) {
+  const hgs_u32x2 s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float((lane & 32) ? s2.x : s2.y);
+}
+// sum / min / max over the four rows (lanes l, l ^ 16, l ^ 32, l ^ 48), same association in every lane
+__device__ __forceinline__ float hgs_rows_sum(float x, int lane) {
+  const float p = hgs_xor16(x, lane);
+  const float s01 = (lane & 16) ? p + x : x + p;          // row (even) + row (odd)
+  const float q = hgs_xor32(s01, lane);
+  return (lane & 32) ? q + s01 : s01 + q;                 // rows (0 + 1) + rows (2 + 3)
+}
+
 template <bool STORE>
-__device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
-                                                const hgs_status* __restrict__ status,
-                                                const SortRec* __restrict__ recs_all,
-                                                float* __restrict__ cstate,
-                                                float* __restrict__ out_color,
-                                                float* __restrict__ out_depth,
-                                                float* __restrict__ out_alpha) {
-  __shared__ float4 s_rec[HGS_FWD_THREADS / 64][4 * HGS_ROW_F4];      // [wave][row][record][3] (+ pad): 3 KB per wave
-  const bool overflow = status->overflow != 0;
-  const uint32_t p = blockIdx.x;
-  if (p >= (uint32_t)v.TT) return;
-  const int g = overflow ? (int)p : (int)L.tile_order[p];   // lists are invalid on overflow: background only
+__device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L, uint32_t key,
+                                                 const SortRec* __restrict__ recs_all,
+                                                 float* __restrict__ cstate,
+                                                 float* __restrict__ out_color,
+                                                 float* __restrict__ out_depth,
+                                                 float* __restrict__ out_alpha, float4* __restrict__ s_rec_w) {
+  const int lane = (int)threadIdx.x & 63;
+  const int r = lane >> 4, i = lane & 15;
+  const int g = (int)(key >> 4), c = (int)(key & 15u);
   const int bview = g / v.T, t = g % v.T;
   const size_t HW = (size_t)v.H * v.W;
-  out_color += (size_t)bview * 3 * HW;
-  out_depth += (size_t)bview * HW;
-  out_alpha += (size_t)bview * HW;
-  uint32_t* __restrict__ n_contrib = L.n_contrib + (size_t)bview * HW;
-  const float* __restrict__ bg = v.cam[bview].bg;
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
-  const int j = lane >> 4, i = lane & 15;
-  const int c = hgs_cell_of(w, j);
   const int px = (t % v.grid_x) * HGS_TILE + (c & 3) * HGS_CELL + (i & 3);
   const int py = (t / v.grid_x) * HGS_TILE + (c >> 2) * HGS_CELL + (i >> 2);
   const bool inside = (px < v.W) && (py < v.H);
   const float pxf = (float)px, pyf = (float)py;
+  const uint32_t tstart1 = L.tile_start[g] - 1u;
+  const CellInfo ci = L.cell_info[key];
+  const uint32_t len = ci.len, sbase = ci.sbase;
+  const uint2* __restrict__ list = L.cell_list + ci.base;
+  const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  const uint32_t n_tile = overflow ? 0u : L.tile_n[g];
-  const uint32_t tstart1 = n_tile ? L.tile_start[g] - 1u : 0u;        // record index - tstart1 = 1-based list position
+  float T = inside ? 1.0f : 0.0f;                 // carried transmittance of the pixel (the same in its four lanes)
+  float tmin = 1.0f;                              // transmittance behind the lane's last blended record
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, Wt = 0.f;
+  uint32_t last = 0;
+
+  auto load_idx = [&](uint32_t e) { return (e < len) ? list[e].x : 0xffffffffu; };
+  auto gather = [&](uint32_t idx, float4& r0, float4& r1, float4& r2) {
+    r0 = zero4; r1 = zero4; r2 = zero4;
+    if (idx != 0xffffffffu) {
+      r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1]; r2 = recs[3 * (size_t)idx + 2];
+      r2.w = __uint_as_float(idx - tstart1);
+    }
+  };
+  // blocks of 64 records, one per lane; index two blocks ahead, records one block ahead
+  float4 c0, c1, c2;
+  gather(load_idx((uint32_t)lane), c0, c1, c2);
+  uint32_t idx_next = load_idx(64u + (uint32_t)lane);
+
+  for (uint32_t it0 = 0; it0 < len; it0 += 64u) {
+    if (__ballot(T != 0.0f) == 0ull) break;          // every pixel has terminated
+    if (STORE && it0 > 0) {                          // pixel state in front of record it0 (a multiple of HGS_SEGLEN = 64)
+      const float s0 = hgs_rows_sum(C0, lane), s1 = hgs_rows_sum(C1, lane), s2 = hgs_rows_sum(C2, lane);
+      const float sd = hgs_rows_sum(D, lane), sw = hgs_rows_sum(Wt, lane);
+      if (r == 0) {
+        float* cs = cstate + (size_t)(sbase + it0 / HGS_SEGLEN - 1) * HGS_CSTATE_FLOATS + i;
+        cs[0 * 16] = T; cs[1 * 16] = s0; cs[2 * 16] = s1; cs[3 * 16] = s2; cs[4 * 16] = sd; cs[5 * 16] = sw;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                 // the previous block's LDS reads are done
+    s_rec_w[3 * lane + 0] = c0; s_rec_w[3 * lane + 1] = c1; s_rec_w[3 * lane + 2] = c2;
+    gather(idx_next, c0, c1, c2);
+    idx_next = load_idx(it0 + 128u + (uint32_t)lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float4* __restrict__ myrec = s_rec_w + 3 * r;          // record 4 k + r of the block
+    float4 ra = myrec[0], rb = myrec[1], rc = myrec[2];
+#pragma unroll 2
+    for (int k = 0; k < 16; ++k) {
+      float4 na = zero4, nb = zero4, nc = zero4;
+      if (k + 1 < 16) { na = myrec[12 * (k + 1) + 0]; nb = myrec[12 * (k + 1) + 1]; nc = myrec[12 * (k + 1) + 2]; }
+      __builtin_amdgcn_sched_barrier(0x7f);
+      float G, alpha, m2, m3;
+      const bool keep = hgs_eval_alpha(ra.x - pxf, ra.y - pyf, ra.z, ra.w, rb.x, rb.y, G, alpha, m2, m3);
+      const float ak = keep ? alpha : 0.0f;
+      const float a = 1.0f - ak;
+      // exclusive prefix of a over the four rows of this pixel, and the product of all four
+      const float p1 = hgs_xor16(a, lane);
+      const float p01 = a * p1;                            // rows (0, 1) or (2, 3): the same value in both rows
+      const float q = hgs_xor32(p01, lane);
+      const float excl = ((lane & 16) ? p1 : 1.0f) * ((lane & 32) ? q : 1.0f);
+      const float Tb = T * excl;                           // transmittance in front of this record
+      const float test_T = Tb * a;
+      const bool ok = test_T >= HGS_T_EPS;
+      const float wgt = ok ? ak * Tb : 0.0f;
+      const bool upd = keep && ok;
+      C0 = __builtin_fmaf(rb.z, wgt, C0);
+      C1 = __builtin_fmaf(rb.w, wgt, C1);
+      C2 = __builtin_fmaf(rc.x, wgt, C2);
+      D = __builtin_fmaf(rc.y, wgt, D);
+      Wt += wgt;
+      tmin = upd ? test_T : tmin;
+      last = upd ? __float_as_uint(rc.w) : last;
+      // the pixel goes on iff all four rows passed (a skipped record passes with a = 1)
+      const unsigned long long okm = __ballot(ok);
+      const unsigned long long all4 = okm & (okm >> 16) & (okm >> 32) & (okm >> 48);     // bit px: scalar unit
+      T = ((all4 >> (lane & 15)) & 1ull) ? T * (p01 * q) : 0.0f;
+      ra = na; rb = nb; rc = nc;
+    }
+  }
+  // the four rows of a pixel -> its outputs
+  const float s0 = hgs_rows_sum(C0, lane), s1 = hgs_rows_sum(C1, lane), s2 = hgs_rows_sum(C2, lane);
+  const float sd = hgs_rows_sum(D, lane), sw = hgs_rows_sum(Wt, lane);
+  float tm = fminf(tmin, hgs_xor16(tmin, lane));
+  tm = fminf(tm, hgs_xor32(tm, lane));
+  uint32_t lm = max(last, __float_as_uint(hgs_xor16(__uint_as_float(last), lane)));
+  lm = max(lm, __float_as_uint(hgs_xor32(__uint_as_float(lm), lane)));
+  if (inside && r == 0) {
+    const float* __restrict__ bg = v.cam[bview].bg;
+    const size_t pix = (size_t)py * v.W + px, o1 = (size_t)bview * HW, o3 = 3 * o1;
+    out_color[o3 + 0 * HW + pix] = s0 + tm * bg[0];
+    out_color[o3 + 1 * HW + pix] = s1 + tm * bg[1];
+    out_color[o3 + 2 * HW + pix] = s2 + tm * bg[2];
+    out_depth[o1 + pix] = sd;
+    out_alpha[o1 + pix] = sw;
+    L.n_contrib[o1 + pix] = lm;
+  }
+}
+
+// One wave = four cells of one length class.
+template <bool STORE>
+__device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L, uint32_t wave_id, int w,
+                                                 const SortRec* __restrict__ recs_all,
+                                                 float* __restrict__ cstate,
+                                                 float* __restrict__ out_color,
+                                                 float* __restrict__ out_depth,
+                                                 float* __restrict__ out_alpha, float4* __restrict__ s_rec_w) {
+  const int lane = (int)threadIdx.x & 63;
+  const int j = lane >> 4, i = lane & 15;
+  // item q of the class tables, longest class first
+  uint32_t q = 4u * wave_id + (uint32_t)j;            // (wave_id counts from the first wave behind the long cells)
+  uint32_t key = 0;
+  bool have = false;
+  int mycls = HGS_NFC;
+  {
+    const size_t cap16 = (size_t)16 * v.TT;
+    uint32_t total = 0;
+#pragma unroll
+    for (int c = HGS_FWD_C4; c < HGS_NFC; ++c) {
+      const uint32_t nc = (uint32_t)L.ctr->alloc3[3 + c];     // (wave-uniform scalar loads)
+      if (!have && q < nc) { key = L.fwd_cells[c * cap16 + q]; have = true; mycls = c; }
+      q -= have ? 0u : nc;
+      total += nc;
+    }
+    if (4u * wave_id >= total) return;                  // surplus wave
+  }
+  const int g = (int)(key >> 4), c = (int)(key & 15u);
+  const int bview = g / v.T, t = g % v.T;
+  const size_t HW = (size_t)v.H * v.W;
+  const int px = (t % v.grid_x) * HGS_TILE + (c & 3) * HGS_CELL + (i & 3);
+  const int py = (t / v.grid_x) * HGS_TILE + (c >> 2) * HGS_CELL + (i >> 2);
+  const bool inside = have && (px < v.W) && (py < v.H);
+  const float pxf = (float)px, pyf = (float)py;
+
+  const uint32_t tstart1 = have ? L.tile_start[g] - 1u : 0u;          // record index - tstart1 = 1-based list position
   uint32_t len = 0, base = 0, sbase = 0;
-  if (n_tile) {                                       // (empty tiles have no cell table)
-    const CellInfo ci = L.cell_info[(size_t)g * 16 + c];
+  if (have) {
+    const CellInfo ci = L.cell_info[key];
     len = ci.len; base = ci.base; sbase = ci.sbase;
   }
-  const uint32_t* __restrict__ list = L.cell_list + base;
+  const uint2* __restrict__ list = L.cell_list + base;
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all);
-  float4* __restrict__ srow = s_rec[w] + j * HGS_ROW_F4;              // this row's 16 staged records
+  float4* __restrict__ srow = s_rec_w + j * HGS_ROW_F4;               // this row's 16 staged records
 
   PixState s;
-  s.T = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
+  s.T = inside ? 1.0f : 0.0f;
+  s.Tout = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
   s.last = 0;
-  s.done = !inside;
 
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // software pipeline: indices two batches ahead, records one batch ahead
-  uint32_t idx_next = ((uint32_t)i < len) ? list[i] : 0xffffffffu;                 // batch 0
-  float4 c0 = zero4, c1 = zero4, c2 = zero4;
-  if (idx_next != 0xffffffffu) {
-    c0 = recs[3 * (size_t)idx_next]; c1 = recs[3 * (size_t)idx_next + 1]; c2 = recs[3 * (size_t)idx_next + 2];
-    c2.w = __uint_as_float(idx_next - tstart1);
-  }
-  idx_next = (HGS_RB + (uint32_t)i < len) ? list[HGS_RB + i] : 0xffffffffu;        // batch 1
+  // Software pipeline of the record stream: the index of batch b + 3 and the 48 B record gather of batch b + 2
+  // are issued while batch b is blended.
+  auto load_idx = [&](uint32_t e) { return (e < len) ? list[e].x : 0xffffffffu; };
+  auto gather = [&](uint32_t idx, float4& r0, float4& r1, float4& r2) {
+    r0 = zero4; r1 = zero4; r2 = zero4;
+    if (idx != 0xffffffffu) {
+      r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1]; r2 = recs[3 * (size_t)idx + 2];
+      r2.w = __uint_as_float(idx - tstart1);
+    }
+  };
+  float4 c0, c1, c2, d0, d1, d2;                    // records of batch b (c) and b + 1 (d)
+  gather(load_idx((uint32_t)i), c0, c1, c2);
+  gather(load_idx(HGS_RB + (uint32_t)i), d0, d1, d2);
+  uint32_t idx_next = load_idx(2 * HGS_RB + (uint32_t)i);                  // batch b + 2
 
   for (uint32_t it0 = 0;; it0 += HGS_RB) {
     // rows still at work: list not exhausted and a pixel not finished
-    const unsigned long long act = __ballot((it0 < len) && !s.done);
+    const unsigned long long act = __ballot((it0 < len) && (s.T != 0.0f));
     if (act == 0ull) break;
     const bool row_on = ((act >> (lane & 48)) & 0xffffull) != 0ull;
     if (STORE && row_on && it0 > 0 && (it0 % HGS_SEGLEN) == 0) {
@@ -127,14 +286,9 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
     }
     __builtin_amdgcn_wave_barrier();                 // the previous batch's LDS reads are done
     srow[3 * i + 0] = c0; srow[3 * i + 1] = c1; srow[3 * i + 2] = c2;
-    // next batch's records (its indices arrived during the previous batch), then the indices after that
-    c0 = zero4; c1 = zero4; c2 = zero4;
-    if (row_on && idx_next != 0xffffffffu) {
-      c0 = recs[3 * (size_t)idx_next]; c1 = recs[3 * (size_t)idx_next + 1]; c2 = recs[3 * (size_t)idx_next + 2];
-      c2.w = __uint_as_float(idx_next - tstart1);
-    }
-    const uint32_t in2 = it0 + 2 * HGS_RB + (uint32_t)i;
-    idx_next = (row_on && in2 < len) ? list[in2] : 0xffffffffu;
+    c0 = d0; c1 = d1; c2 = d2;
+    gather(row_on ? idx_next : 0xffffffffu, d0, d1, d2);
+    idx_next = row_on ? load_idx(it0 + 3 * HGS_RB + (uint32_t)i) : 0xffffffffu;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // groups of HGS_FWD_GROUP records; the LDS reads of group k + 1 are in flight while group k is blended
@@ -151,8 +305,12 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
           nc[u] = srow[3 * (u0 + HGS_FWD_GROUP + u) + 2];
         }
       }
+      // the machine scheduler would sink those reads to their first use (and expose one LDS round trip per group):
+      // LDS instructions may not cross this point, everything else may
+      __builtin_amdgcn_sched_barrier(0x7f);
 #pragma unroll
       for (int u = 0; u < HGS_FWD_GROUP; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
+      __builtin_amdgcn_sched_barrier(0x7f);
       if (u0 + HGS_FWD_GROUP < HGS_RB) {
 #pragma unroll
         for (int u = 0; u < HGS_FWD_GROUP; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
@@ -161,24 +319,83 @@ __device__ __forceinline__ void render_fwd_body(const View& v, const Layout& L,
   }
 
   if (inside) {
-    const size_t pix = (size_t)py * v.W + px;
-    out_color[0 * HW + pix] = s.C0 + s.T * bg[0];
-    out_color[1 * HW + pix] = s.C1 + s.T * bg[1];
-    out_color[2 * HW + pix] = s.C2 + s.T * bg[2];
-    out_depth[pix] = s.D;
-    out_alpha[pix] = s.Wt;
-    n_contrib[pix] = s.last;
+    const float* __restrict__ bg = v.cam[bview].bg;
+    const size_t pix = (size_t)py * v.W + px, o1 = (size_t)bview * HW, o3 = 3 * o1;
+    out_color[o3 + 0 * HW + pix] = s.C0 + s.Tout * bg[0];
+    out_color[o3 + 1 * HW + pix] = s.C1 + s.Tout * bg[1];
+    out_color[o3 + 2 * HW + pix] = s.C2 + s.Tout * bg[2];
+    out_depth[o1 + pix] = s.D;
+    out_alpha[o1 + pix] = s.Wt;
+    L.n_contrib[o1 + pix] = s.last;
   }
 }
 
+// The pixels of EMPTY cells (and of every cell when the lists are invalid): background, zero depth / alpha.
+// One workgroup per tile, thread = pixel in row-major order (coalesced stores).
+__device__ __forceinline__ void render_fwd_background(const View& v, const Layout& L, bool overflow, int g,
+                                                      float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                      float* __restrict__ out_alpha) {
+  const int bview = g / v.T, t = g % v.T;
+  const int lx = (int)threadIdx.x & 15, ly = (int)threadIdx.x >> 4;
+  const int px = (t % v.grid_x) * HGS_TILE + lx, py = (t / v.grid_x) * HGS_TILE + ly;
+  if (px >= v.W || py >= v.H) return;
+  bool empty = overflow || L.tile_n[g] == 0u;
+  if (!empty) empty = L.cell_info[(size_t)g * 16 + (ly >> 2) * 4 + (lx >> 2)].len == 0u;
+  if (!empty) return;
+  const float* __restrict__ bg = v.cam[bview].bg;
+  const size_t HW = (size_t)v.H * v.W, pix = (size_t)py * v.W + px, o1 = (size_t)bview * HW, o3 = 3 * o1;
+  out_color[o3 + 0 * HW + pix] = bg[0];
+  out_color[o3 + 1 * HW + pix] = bg[1];
+  out_color[o3 + 2 * HW + pix] = bg[2];
+  out_depth[o1 + pix] = 0.0f;
+  out_alpha[o1 + pix] = 0.0f;
+  L.n_contrib[o1 + pix] = 0u;
+}
+
+// Launch: blocks [0, cell_blocks) hold four PERSISTENT cell waves each: wave w takes work items w, w + W, ... (long cells
+// first, one each; then groups of four cells by descending length class) - the item count is only known on the device,
+// and a capacity-sized grid cost more in empty waves (56k of them, ~1 us each) than the blending itself; blocks
+// [cell_blocks, cell_blocks + B*T) write the background of the empty cells.
 #define HGS_RENDER_FWD_KERNEL(NAME, STORE)                                                                 \
   extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS) NAME(                                       \
-      View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs,             \
-      float* __restrict__ cstate, float* __restrict__ out_color, float* __restrict__ out_depth,              \
-      float* __restrict__ out_alpha) {                                                                       \
+      View v, Layout L, uint32_t cell_blocks, const hgs_status* __restrict__ status,                         \
+      const SortRec* __restrict__ recs, float* __restrict__ cstate, float* __restrict__ out_color,           \
+      float* __restrict__ out_depth, float* __restrict__ out_alpha) {                                        \
+    __shared__ float4 s_rec[HGS_FWD_THREADS / 64][4 * HGS_ROW_F4];      /* [wave][row][record][3] (+ pad) */  \
+    const bool overflow = status->overflow != 0;                                                             \
+    if (blockIdx.x >= cell_blocks) {                                                                         \
+      const uint32_t g = blockIdx.x - cell_blocks;                                                           \
+      if (g < (uint32_t)v.TT) render_fwd_background(v, L, overflow, (int)g, out_color, out_depth, out_alpha); \
+      return;                                                                                                \
+    }                                                                                                        \
+    if (overflow) return;                                                                                    \
     HGS_TL_BEGIN();                                                                                          \
-    render_fwd_body<STORE>(v, L, status, recs, cstate, out_color, out_depth, out_alpha);                     \
-    HGS_TL_END(4, blockIdx.x < (uint32_t)v.TT ? L.tile_n[L.tile_order[blockIdx.x]] : 0u);                    \
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);                                     \
+    uint32_t cnt4[HGS_FWD_C4 + 1], n4 = 0, nrest = 0;     /* long cells per class; the other cells */        \
+    _Pragma("unroll") for (int c = 0; c < HGS_NFC; ++c) {                                                    \
+      const uint32_t nc = (uint32_t)L.ctr->alloc3[3 + c];                                                    \
+      if (c < HGS_FWD_C4) { cnt4[c] = nc; n4 += nc; } else nrest += nc;                                      \
+    }                                                                                                        \
+    /* Items are sorted longest first.  Blocks b, b + ncu, b + 2 ncu, ... share a CU (ncu = cell_blocks / 4), wave w of */ \
+    /* each its SIMD w: the waves of one SIMD take items in SNAKE order (round rho: rho S + simd for even rho, */        \
+    /* rho S + S - 1 - simd for odd rho), so every SIMD gets a heavy + light mix of about the same total. */              \
+    const uint32_t nitems = n4 + (nrest + 3u) / 4u;                                                          \
+    const uint32_t ncu = max(1u, cell_blocks / 4u), S = ncu * 4u;                                            \
+    const uint32_t simd = (blockIdx.x % ncu) * 4u + (uint32_t)w;                                             \
+    for (uint32_t rho = blockIdx.x / ncu; rho * S < nitems; rho += (cell_blocks + ncu - 1u) / ncu) {         \
+      const uint32_t it = rho * S + ((rho & 1u) ? S - 1u - simd : simd);                                     \
+      if (it >= nitems) continue;                                                                            \
+      if (it < n4) {                                                                                         \
+        uint32_t q = it;                                                                                     \
+        int c4 = 0;                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < HGS_FWD_C4 - 1; ++c) if (c4 == c && q >= cnt4[c]) { q -= cnt4[c]; c4 = c + 1; } \
+        render_fwd_cell4<STORE>(v, L, L.fwd_cells[(size_t)c4 * 16 * v.TT + q], recs, cstate, out_color,     \
+                                out_depth, out_alpha, s_rec[w]);                                             \
+      } else {                                                                                               \
+        render_fwd_cells<STORE>(v, L, it - n4, w, recs, cstate, out_color, out_depth, out_alpha, s_rec[w]);  \
+      }                                                                                                      \
+    }                                                                                                        \
+    HGS_TL_END(4, 1u);                                                                                       \
   }
 HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_store, true)
 HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_nostore, false)
