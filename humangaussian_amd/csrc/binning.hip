@@ -476,7 +476,10 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
 #define HGS_TG(i)
 #endif
   // ---- sweep 1: records + masks; per chunk the packed per-cell counts (tab[ch][0..3]) and its pairs (tab[ch][16])
-  constexpr int GU = 4;
+#ifndef HGS_SORT_GU
+#define HGS_SORT_GU 2
+#endif
+  constexpr int GU = HGS_SORT_GU;
   for (uint32_t kb0 = 0; kb0 < n; kb0 += (uint32_t)nt * GU) {      // (wave-uniform trip count: wave scans inside)
     const uint32_t kb = kb0 + threadIdx.x;
     uint32_t idxv[GU];

@@ -350,7 +350,10 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 s0 = zero4, s1 = zero4;
   float2 s2 = make_float2(0.f, 0.f);
-  constexpr uint32_t U = 4;                 // pair rows in flight per thread
+#ifndef HGS_RED_U
+#define HGS_RED_U 16
+#endif
+  constexpr uint32_t U = HGS_RED_U;         // pair rows in flight per thread
   for (uint32_t r0 = 0; r0 < cnt; r0 += U) {
     float4 a[U], b[U];
     float2 c[U];
