@@ -38,7 +38,7 @@ INIT_STEPS = 100               # un-timed first-use steps before the W warm-up s
                                # estimates settle and the GPU leaves its idle clocks (some boxes need > 20 ms for that)
 
 FWD_STAGES = ["preprocess_fwd", "tiles", "fill", "sort", "render_fwd"]
-BWD_STAGES = ["render_bwd", "preprocess_bwd"]
+BWD_STAGES = ["render_bwd", "pair_reduce", "preprocess_bwd"]
 
 
 def algorithmic_bytes(stage, P, M, R, npix, T, B=1):
@@ -51,7 +51,8 @@ def algorithmic_bytes(stage, P, M, R, npix, T, B=1):
         "fill": B * P * 16 + 12 * R,
         "sort": 24 * R,
         "render_fwd": 44 * R + 24 * npix * B,
-        "render_bwd": 84 * R + 28 * npix * B,
+        "render_bwd": 44 * R + 28 * npix * B,     # records in, pixel gradients / outputs in (84 R for the
+        "pair_reduce": 40 * R,                    # blend backward = 44 R in + 40 R of per-entry gradient out, written by the reduction)
         "preprocess_bwd": P * (60 + 12 * M + 44 + 12 * M) + B * P * (64 + 12) + 40 * R,
     }[stage]
 
@@ -189,7 +190,7 @@ def main():
         def stage_times(self, nprof=20):
             """Per-kernel-stage times from events the LIBRARY records on its launch stream."""
             fwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-            bwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            bwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             for e in fwd_ev + bwd_ev:
                 e.record()
             torch.cuda.synchronize()
@@ -272,11 +273,14 @@ def main():
     dom = max(stage_us, key=stage_us.get)
     dom_bytes = algorithmic_bytes(dom, P, M, R, npix, T, B)
     achieved = dom_bytes / (stage_us[dom] * 1e-6) / 1e9
-    traffic = None
+    # HBM-side bytes of the dominant kernel from the committed PMC passes (tools/profile_round.sh), with the commit
+    # they were taken at: the two must be read together (the counters cannot be collected inside this process)
+    traffic, traffic_commit = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath) and B == 1:
         try:
-            traffic = json.load(open(tpath)).get(dom)
+            tj = json.load(open(tpath))
+            traffic, traffic_commit = tj.get(dom), tj.get("_commit")
         except Exception:
             traffic = None
     path_bytes = sum(algorithmic_bytes(k, P, M, R, npix, T, B) for k in stage_us if not (args.forward_only and k in BWD_STAGES))
@@ -364,8 +368,9 @@ def main():
                        "parallelism": f"view-parallel x{world}" + (f", collective {collective_mode[0]}" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": {"file": "profiles/pmc_traffic.json", "commit": traffic_commit},
                          "algorithmic_bytes": dom_bytes, "avg_us": stage_us[dom],
-                         "note": "blend kernels are VALU/MFMA-issue-bound (the backward pixel sums run on fp32 MFMA); "
+                         "note": "blend kernels are VALU / LDS / MFMA-issue-bound (the backward's pixel sums run on fp32 MFMA); "
                                  "HBM fraction reported as BASELINE.json asks",
                          "path": {"algorithmic_bytes": path_bytes, "gpu_us_sum": gpu_us,
                                   "achieved": path_bytes / (gpu_us * 1e-6) / 1e9,

@@ -494,13 +494,15 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)resident), dim3(64), 0, stream, v, L, status_dev, L.recs, L.cstate,
                        out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows);
     HGS_LAUNCH_CHECK();
+    HGS_STAGE(1);
     if (X > 0) {
       hipLaunchKernelGGL(hgs_k_pair_reduce, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
                          pair_rows, rows);
       HGS_LAUNCH_CHECK();
     }
   }
-  HGS_STAGE(1);
+  if (!maybe_entries) HGS_STAGE(1);
+  HGS_STAGE(2);
 #define HGS_LAUNCH_PRE_BWD(K, GRID, THREADS, LDS)                                                     \
   hipLaunchKernelGGL(K, dim3(GRID), dim3(THREADS), LDS, stream, v, L, status_dev, rows, means3D, shs, \
                      colors_precomp, opacities, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, \
@@ -532,7 +534,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   }
 #undef HGS_LAUNCH_PRE_BWD
   HGS_LAUNCH_CHECK();
-  HGS_STAGE(2);
+  HGS_STAGE(3);
   return HGS_OK;
 }
 

@@ -83,6 +83,7 @@ DevState& state_for(int dev) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (dev < 0 || dev >= (int)g_states.size()) throw std::runtime_error("bad device index");
   if (!g_states[dev]) {
+    DeviceSwitch guard((c10::DeviceIndex)dev);          // the event belongs to `dev`, whatever device is current
     auto* st = new DevState();
     st->status_ring = at::zeros({RING, 8}, at::TensorOptions().dtype(at::kInt)).pin_memory();
     static_assert(sizeof(hgs_status) == 32, "hgs_status is 8 words");
@@ -236,13 +237,16 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     std::lock_guard<std::mutex> lk(st.mu);
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
     Estimate& est = st.est[std::make_tuple(B, H, W)];
-    int64_t cap = P > 0 ? (est.capacity > 0 ? est.capacity : round_capacity(4 * P * B)) : 0;
+    int64_t cap = P > 0 ? (est.capacity > 0 ? est.capacity : round_capacity(3 * P * B)) : 0;
     int32_t hint = (int32_t)est.tile_hint;
     // one allocation for the four opaque regions [geom | img | bin | backward rows] (the fork keeps
     // three such byte tensors for its backward); a capacity retry re-allocates only the last two
     const int64_t g_sz = al256(hgs_geom_bytes_batch((int32_t)B, (int32_t)P, (int32_t)H, (int32_t)W));
     const int64_t i_sz = al256(hgs_img_bytes_batch((int32_t)B, (int32_t)H, (int32_t)W));
-    int64_t b_sz = al256(hgs_bin_bytes(cap)), s_sz = want_grad ? al256(hgs_bwd_scratch_bytes(cap)) : 0;
+    // (the backward's pair rows - 16 x 48 B per entry - are allocated by backward() for its own duration: they would
+    // otherwise be held by every view of a step until its backward runs)
+    int64_t b_sz = al256(hgs_bin_bytes(cap));
+    const int64_t s_sz = 0;
     const auto bopt = at::TensorOptions().dtype(at::kByte).device(dev);
     plan->work = at::empty({g_sz + i_sz + b_sz + s_sz}, bopt);
     char* base = static_cast<char*>(plan->work.data_ptr());
@@ -278,7 +282,6 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       if (h.overflow & 1u) {                    // R exceeded the capacity: grow, re-run
         cap = round_capacity((int64_t)(h.num_rendered * 1.25) + 1);
         b_sz = al256(hgs_bin_bytes(cap));
-        s_sz = want_grad ? al256(hgs_bwd_scratch_bytes(cap)) : 0;
         plan->work2 = at::empty({b_sz + s_sz}, bopt);
         plan->bin = static_cast<char*>(plan->work2.data_ptr());
         plan->rows = plan->bin + b_sz;
@@ -353,6 +356,9 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     if (plan->has_sr) { d_sc = at::empty({P, 3}, fopt); d_ro = at::empty({P, 4}, fopt); }
     if (plan->has_cv) d_cv = at::empty({P, 6}, fopt);
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+    Tensor scratch = at::empty({al256(hgs_bwd_scratch_bytes((int64_t)plan->status.num_rendered))},
+                               at::TensorOptions().dtype(at::kByte).device(dev));
+    plan->rows = static_cast<char*>(scratch.data_ptr());
     const int rc = hgs_backward_batch_act(
         plan->settings.s.data(), plan->B, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_), fptr(ro_),
         fptr(cv_), plan->P > 0 ? radii.data_ptr<int32_t>() : nullptr, fptr(color), fptr(depth), fptr(alpha), fptr(gc),
@@ -519,8 +525,9 @@ std::vector<Tensor> densify_stats(const Tensor& grad_means2D, const Tensor& radi
     throw std::runtime_error("xyz_gradient_accum / denom / max_radii2D must have num_points elements");
   Tensor keep_u8;
   if (keep.has_value() && keep->defined()) {
+    if (keep->device() != dev) throw std::runtime_error("keep mask must live on the device of radii");
     keep_u8 = keep->to(at::kByte).contiguous();
-    if (keep_u8.device() != dev || keep_u8.numel() != P) throw std::runtime_error("keep mask must have num_points elements on the device");
+    if (keep_u8.numel() != P) throw std::runtime_error("keep mask must have num_points elements on the device");
   }
   Tensor rmax = at::empty({P}, rc.options());
   Tensor vis = at::empty({P}, rc.options().dtype(at::kByte));
@@ -568,6 +575,13 @@ std::vector<Tensor> compact_rows(const Tensor& keep, const std::vector<Tensor>& 
   const c10::Device dev = keep.device();
   if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
   DeviceSwitch guard(dev.index());
+  for (const Tensor& t : tensors) {
+    if (t.device() != dev) throw std::runtime_error("compact_rows: every tensor must live on the device of `keep`");
+    if (t.scalar_type() != at::kFloat)
+      throw std::runtime_error("compact_rows: fp32 tensors only (got " + std::string(c10::toString(t.scalar_type())) +
+                               "): gather other dtypes with index_select on the returned row count");
+    if (t.dim() < 1) throw std::runtime_error("compact_rows: tensors need a leading num_points dimension");
+  }
   const Tensor k = keep.to(at::kByte).contiguous();
   const int64_t P = k.numel();
   hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
@@ -621,6 +635,11 @@ void set_stage_events(const c10::optional<std::vector<int64_t>>& fwd, const c10:
 }
 
 py::dict device_state(int64_t dev) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (dev < 0 || dev >= (int64_t)g_states.size()) throw std::runtime_error("bad device index");
+    if (!g_states[dev]) return py::dict();             // nothing has run on this device yet: no state is created here
+  }
   DevState& st = state_for((int)dev);
   std::lock_guard<std::mutex> lk(st.mu);
   py::dict d;

@@ -82,9 +82,9 @@ size_t hgs_img_bytes_batch(int32_t B, int32_t image_height, int32_t image_width)
 /* Optional per-stage timing (measurement only; pass NULL in production): `stage_events`
  * is a HOST array of hipEvent_t handles; entry k (if non-NULL) is recorded on `stream`
  * after stage k.  Forward: 0 start, 1 preprocess, 2 tile tables, 3 fill (+ status), 4 sort, 5 blend.
- * Backward: 0 start, 1 blend backward, 2 preprocess backward. */
+ * Backward: 0 start, 1 blend backward, 2 pair reduction, 3 preprocess backward. */
 #define HGS_FWD_STAGES 6
-#define HGS_BWD_STAGES 3
+#define HGS_BWD_STAGES 4
 
 /* ---- forward: replaces _C.rasterize_gaussians --------------------------------------
  * Exactly one of shs / colors_precomp and exactly one of {scales,rotations} /

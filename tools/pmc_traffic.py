@@ -5,9 +5,9 @@ sit at the L2's fabric side, so Infinity-Cache hits are included: an upper bound
 import collections, csv, json, sys
 
 STAGE = [("hgs_k_preprocess_fwd", "preprocess_fwd"), ("hgs_k_tiles", "tiles"),
-         ("hgs_k_fill", "fill"), ("hgs_k_sort", "sort"), ("hgs_k_fwd_segT", "render_fwd"),
-         ("hgs_k_render_fwd", "render_fwd"), ("hgs_k_fwd_combine", "render_fwd"),
-         ("hgs_k_render_bwd", "render_bwd"), ("hgs_k_preprocess_bwd", "preprocess_bwd")]
+         ("hgs_k_fill", "fill"), ("hgs_k_sort", "sort"), ("hgs_k_render_fwd", "render_fwd"),
+         ("hgs_k_render_bwd", "render_bwd"), ("hgs_k_pair_reduce", "pair_reduce"),
+         ("hgs_k_preprocess_bwd", "preprocess_bwd")]
 
 
 def load(path, counter):
@@ -30,6 +30,7 @@ f, nf = load(sys.argv[1], "FETCH_SIZE")
 w, nw = load(sys.argv[2], "WRITE_SIZE")
 out = {st: (2.0 * f.get(st, 0.0) / nf + w.get(st, 0.0) / nw) * 1024.0 for st in sorted(set(f) | set(w))}
 out["_steps"] = [nf, nw]
+out["_commit"] = sys.argv[3] if len(sys.argv) > 3 else "unknown"      # the build the passes ran on
 out["_note"] = ("per-step HBM-side bytes per stage = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate "
                 "rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts 64 B per 128 B request for wide "
                 "coalesced reads; WRITE_SIZE uncalibrated); config 2; working set < 256 MiB Infinity "

@@ -1,5 +1,5 @@
 # Round-end measurement artifacts (run on the GPU box through gpurun):
-#   bash tools/profile_round.sh <tag>     e.g. r02
+#   bash tools/profile_round.sh <tag> <commit>     e.g. r03 $(git rev-parse --short HEAD)   (the box has no .git: pass the hash)
 # 1) PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) -> profiles/pmc_traffic.json
 # 2) SQ counter passes for the blend / sort kernels -> gpurun_out/sq_<tag>.json
 # 3) rocprofv3 --kernel-trace --stats of the default bench command (extras and CPU baseline off)
@@ -10,7 +10,7 @@ cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5"
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$TAG -o run -- $BENCH > $O/pmc_fetch_$TAG.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$TAG -o run -- $BENCH > $O/pmc_write_$TAG.log 2>&1
-python $R/tools/pmc_traffic.py $O/pmc_fetch_$TAG/run_counter_collection.csv $O/pmc_write_$TAG/run_counter_collection.csv > $O/pmc_traffic_$TAG.json
+python $R/tools/pmc_traffic.py $O/pmc_fetch_$TAG/run_counter_collection.csv $O/pmc_write_$TAG/run_counter_collection.csv "${2:-unknown}" > $O/pmc_traffic_$TAG.json
 cp $O/pmc_traffic_$TAG.json $R/profiles/pmc_traffic.json
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
@@ -35,7 +35,7 @@ for d in sorted(glob.glob(f"{R}/gpurun_out/pmc_sq*_{tag}")):
         for n,v in c.items():
             out[k][n]=sum(v)/len(v)
 json.dump(out, open(f"{R}/gpurun_out/sq_{tag}.json","w"), indent=1)
-for k in ("hgs_k_render_bwd","hgs_k_render_fwd_store","hgs_k_sort_lds"):
+for k in ("hgs_k_render_bwd","hgs_k_render_fwd_store","hgs_k_sort_lds","hgs_k_pair_reduce"):
     print(k, {n: round(v) for n,v in out.get(k,{}).items()})
 PY
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o run -- python $R/bench.py --no-cpu-baseline --no-extra > $O/prof_$TAG.log 2>&1
