@@ -140,10 +140,14 @@ __device__ __forceinline__ void place_tiles(const View& v, const Layout& L, int 
     st.overflow = overflow_from_counters(v, L);
     st.reserved[0] = v.entry_capacity;   // carve key for hgs_backward
     st.reserved[1] = L.ctr->max_n;       // longest tile list
-    st.reserved[2] = 0;
+    st.reserved[2] = 1;                  // "complete" marker (see the host mirror below)
     *status = st;
-    if (status_host) {            // pinned, device-mapped host memory: no in-stream copy
-      *status_host = st;
+    if (status_host) {            // pinned, device-mapped host memory: no in-stream copy.  reserved[2] = 1 is written LAST,
+      volatile uint32_t* hs = reinterpret_cast<volatile uint32_t*>(status_host);      // behind a system-scope fence: a host
+      const uint32_t* sw = reinterpret_cast<const uint32_t*>(&st);                    // that cleared it can POLL the word
+      for (int k = 0; k < 7; ++k) hs[k] = sw[k];                                      // instead of waiting for an event
+      __threadfence_system();
+      hs[7] = 1u;
       __threadfence_system();
     }
   }

@@ -57,7 +57,10 @@
 #define HGS_ALPHA_MAX 0.99f
 #define HGS_T_EPS 0.0001f
 #define HGS_CSTATE_FLOATS (6 * 16)             // T, C0, C1, C2, D, W for the 16 pixels of a cell
-#define HGS_ROW_FLOATS 12                       // gradient row per entry / per (entry, cell) pair (10 used)
+#ifndef HGS_ROW_FLOATS
+#define HGS_ROW_FLOATS 12                       // gradient row per entry / per (entry, cell) pair (10 used); 64 B rows
+#endif                                          // (whole ECC granules per scattered store) measured slower: the rows are bandwidth
+#define HGS_GROW_F4 (HGS_ROW_FLOATS / 4)          // float4 per gradient row
 #define HGS_NCLS 33                             // tile classes by log2(list length); class 0 = empty
 #define HGS_NFC 11                              // length classes of the non-empty cells (forward work items)
 

@@ -468,7 +468,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
       const int rh = (int)(g.rect_hi >> 16) - (int)(g.rect_lo >> 16);
       const int tt = rw * rh;
       const float4* rows = reinterpret_cast<const float4*>(grad_rows) +
-                           3 * (size_t)(L.chunk_base[(size_t)b * v.nblk + (i >> 8)] + g.offset);
+                           HGS_GROW_F4 * (size_t)(L.chunk_base[(size_t)b * v.nblk + (i >> 8)] + g.offset);
 #ifndef HGS_ROWS_UNROLL_MANY
 #define HGS_ROWS_UNROLL_MANY 4
 #endif
@@ -482,7 +482,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
           const int k = min(k0 + u, tt - 1);
-          r0[u] = rows[3 * k + 0]; r1[u] = rows[3 * k + 1]; r2[u] = rows[3 * k + 2];
+          r0[u] = rows[HGS_GROW_F4 * k + 0]; r1[u] = rows[HGS_GROW_F4 * k + 1]; r2[u] = rows[HGS_GROW_F4 * k + 2];
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {

@@ -17,7 +17,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <map>
 #include <tuple>
 #include <mutex>
@@ -260,21 +262,36 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     for (; attempt < 4; ++attempt) {
       const int slot = st.ring_pos;
       st.ring_pos = (st.ring_pos + 1) % RING;
+      // The library stores the status into this pinned slot from the fill launch and sets reserved[2] = 1 LAST (behind a
+      // system-scope fence): the host polls that word.  (An event recorded behind the fill stage cost the GPU ~6 us of
+      // idle time per forward: the record is a barrier packet with a system-scope release in the middle of the chain.)
+      volatile uint32_t* ready = &st.ring[slot].reserved[2];
+      *ready = 0u;
+      std::atomic_thread_fence(std::memory_order_seq_cst);
       const int rc = hgs_forward_batch_act(plan->settings.s.data(), (int32_t)B, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_),
                                            fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth),
                                            fptr_mut(alpha), P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom,
                                            plan->bin, cap, plan->img, want_grad ? 1 : 0, hint, &st.ring[slot], /*mapped=*/1,
-                                           st.status_event, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(),
+                                           /*status_event=*/nullptr, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(),
                                            (int32_t)act, stream);
       check_rc(rc, "hgs_forward_batch");
       // `debug=True` is upstream's switch for surfacing device errors at the call that caused
       // them (std::runtime_error): synchronise and report
       if (debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer forward (debug=True)");
-      // One host wait per forward, like upstream's blocking read of num_rendered - but only for
-      // the status (stored by the tiles kernel): fill, sort and blend are already enqueued and keep
-      // the GPU busy while the host goes on to autograd and the backward launch.
+      // One host wait per forward, like upstream's blocking read of num_rendered - but only for the status: sort and
+      // blend are already enqueued and keep the GPU busy while the host goes on to autograd and the backward launch.
       const auto tw = std::chrono::steady_clock::now();
-      hip_ok(hipEventSynchronize(st.status_event), "hipEventSynchronize");
+      for (uint64_t spins = 0; *ready == 0u; ++spins) {
+        if ((spins & 0x3ff) == 0x3ff) {
+          if (std::chrono::steady_clock::now() - tw > std::chrono::seconds(2)) {       // (a device error: surface it)
+            hip_ok(hipStreamSynchronize(stream), "rasterizer forward");
+            if (*ready == 0u) throw std::runtime_error("libhgs_rast: the forward finished without publishing its status");
+            break;
+          }
+          std::this_thread::yield();
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_seq_cst);
       st.wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw).count();
       h = st.ring[slot];
       if (!h.overflow) break;
