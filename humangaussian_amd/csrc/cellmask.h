@@ -56,3 +56,40 @@ HGS_HD uint32_t hgs_cell_mask(float mx, float my, float ca, float cb, float cc, 
   }
   return mask;
 }
+
+// Tile-level version of the same test: can the Gaussian reach alpha >= 1/255 anywhere on the tile's 16 x 16 pixel
+// centres?  Exact minimum of q over the rectangle (the minimum of a convex quadratic over a box is 0 if the centre is
+// inside, else it lies on an edge, where the free coordinate's optimum is the clamped 1-D minimiser), with the same
+// inflated tau as hgs_cell_mask and the rectangle grown by the same eps: a SUPERSET of "hgs_cell_mask != 0".
+// The binning stage drops (Gaussian, tile) pairs that fail it (22 % of upstream's entries on an avatar): they
+// cannot change any pixel.  Evaluated from the GeomRec fields by preprocess_fwd (count), fill (scatter) and
+// preprocess_bwd (which rows exist): the same inputs, the same decision.
+HGS_HD bool hgs_tile_hit(float mx, float my, float ca, float cb, float cc, float op, float x0, float y0) {
+  const float a255 = 255.0f * op;
+  if (!(a255 >= 0.999f)) return false;
+  const float det = ca * cc - cb * cb;
+  if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return true;
+  const float tau = 2.0f * logf(fmaxf(a255, 1.0f)) * 1.002f + 0.03f;
+  const float eps = 4e-3f;
+  const float xa = x0 - eps, xb = x0 + 15.0f + eps, ya = y0 - eps, yb = y0 + 15.0f + eps;
+  const float bc = cb / cc, ba = cb / ca;
+  float best;
+  {
+    const float dx = fminf(fmaxf(mx, xa), xb) - mx, dy = fminf(fmaxf(my, ya), yb) - my;      // 0 when the centre is inside
+    best = ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy;
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    {  // vertical edges x = xa / xb
+      const float dx = (e ? xb : xa) - mx;
+      const float dy = fminf(fmaxf(my - bc * dx, ya), yb) - my;
+      best = fminf(best, ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy);
+    }
+    {  // horizontal edges y = ya / yb
+      const float dy = (e ? yb : ya) - my;
+      const float dx = fminf(fmaxf(mx - ba * dy, xa), xb) - mx;
+      best = fminf(best, ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy);
+    }
+  }
+  return best <= tau * 1.0005f + 1e-3f * best;
+}

@@ -18,6 +18,7 @@ def lib(tmp_path_factory):
                            os.path.join(ROOT, "tests", "cellmask_host.cpp"), "-o", so])
     L = ctypes.CDLL(so)
     L.hgs_cell_mask_host.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9
+    L.hgs_tile_hit_host.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9
     return L
 
 
@@ -26,6 +27,13 @@ def _masks(lib, mx, my, ca, cb, cc, op, x0, y0):
     out = np.zeros(len(arrs[0]), np.uint32)
     lib.hgs_cell_mask_host(len(out), *[a.ctypes.data for a in arrs], out.ctypes.data)
     return out
+
+
+def _tile_hits(lib, mx, my, ca, cb, cc, op, x0, y0):
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (mx, my, ca, cb, cc, op, x0, y0)]
+    out = np.zeros(len(arrs[0]), np.uint32)
+    lib.hgs_tile_hit_host(len(out), *[a.ctypes.data for a in arrs], out.ctypes.data)
+    return out.astype(bool)
 
 
 def _live_cells(mx, my, ca, cb, cc, op, x0, y0):
@@ -98,3 +106,18 @@ def test_cell_mask_edge_cases(lib):
     assert _masks(lib, one(5.5), one(5.5), one(3.3), one(0), one(3.3), one(0.9), one(0), one(0))[0] == 1 << 5
     # far away: nothing
     assert _masks(lib, one(500), one(500), one(1), one(0), one(1), one(0.9), one(0), one(0))[0] == 0
+
+
+def test_tile_hit_is_a_superset_of_the_cell_mask_and_of_every_live_pixel(lib):
+    """The binning stage drops a (Gaussian, tile) pair when hgs_tile_hit fails: it must hold whenever a cell bit is
+    set (the blend kernels walk cell lists built from the kept entries) and whenever any pixel of the tile is live."""
+    kept = live_any = n = 0
+    for seed in range(4):
+        e = _random_entries(60000, 10 + seed)
+        hit = _tile_hits(lib, *e)
+        m = _masks(lib, *e)
+        live_cells, _ = _live_cells(*e)
+        assert not ((m != 0) & ~hit).any()
+        assert not ((live_cells != 0) & ~hit).any()
+        kept += int(hit.sum()); live_any += int((live_cells != 0).sum()); n += len(hit)
+    assert kept <= 1.15 * live_any + 0.01 * n, (kept, live_any, n)      # tight: few tiles kept without a live pixel
