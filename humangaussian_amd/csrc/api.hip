@@ -91,7 +91,7 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, cell_list, cstate, items_full, total; };
+struct BinCarve { size_t keys, recs, cell_list, entpair, cstate, items_full, total; };
 
 // Pair-sized arrays hold HGS_PAIRS_PER_ENTRY slots per entry of capacity: an entry can reach all 16 cells of
 // its tile (zoomed-in cameras), so no second capacity (and no second overflow path) exists.
@@ -104,6 +104,7 @@ BinCarve carve_bin(int64_t cap) {
   c.keys = take(C * 8);
   c.recs = take(C * sizeof(SortRec));
   c.cell_list = take(NP * 8);
+  c.entpair = take(C * 8);
   // a cell list of len entries has ceil(len / 64) - 1 stored states and ceil(len / 64) work items, len / 64 of them full
   c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
   c.items_full = take((NP / HGS_SEGLEN + 1) * sizeof(uint2));
@@ -133,6 +134,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.cell_list = bp ? reinterpret_cast<uint2*>(bp + b.cell_list) : nullptr;
+  L.entpair = bp ? reinterpret_cast<uint2*>(bp + b.entpair) : nullptr;
   L.cstate = bp ? reinterpret_cast<float*>(bp + b.cstate) : nullptr;
   L.items_full = bp ? reinterpret_cast<uint2*>(bp + b.items_full) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);

@@ -379,7 +379,8 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
         dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
         dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-        dst[2] = make_uint4(g2.x, g2.y, entry | ((uint32_t)__popc(mask) << 27), 0u);         // .pairs follows in sweep 2
+        dst[2] = make_uint4(g2.x, g2.y, entry, 0u);
+        L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);      // (.y, the first pair id, follows in sweep 2)
         sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
       }
 #pragma unroll
@@ -436,7 +437,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
       const uint32_t mask = in ? (uint32_t)sorted[k] : 0u;
       const uint32_t cnt = (uint32_t)__popc(mask);
       const uint32_t rel = S.tab[ch][16] + hgs_wave_incl_scan(cnt) - cnt;      // entry-major, relative to the tile
-      if (in) L.recs[start + k].pairs = pair_base + rel;
+      if (in) L.entpair[start + k].y = pair_base + rel;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const bool bit = (mask >> c) & 1u;
@@ -520,7 +521,8 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
         const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
         dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
         dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-        dst[2] = make_uint4(g2.x, g2.y, entry | ((uint32_t)__popc(mask) << 27), 0u);         // .pairs follows in sweep 2
+        dst[2] = make_uint4(g2.x, g2.y, entry, 0u);
+        L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);      // (.y, the first pair id, follows in sweep 2)
         sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
       }
       const uint32_t ch = k >> 6;
@@ -590,7 +592,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
       before += hgs_bytesum(ex[wd]);
     }
     const uint32_t rel = S.tab[ch][16] + before;          // entry-major, relative to the tile
-    if (in) L.recs[start + k].pairs = pair_base + rel;
+    if (in) L.entpair[start + k].y = pair_base + rel;
     uint32_t r = 0;
     while (mask) {
       const int c = __builtin_ctz(mask);

@@ -85,7 +85,7 @@ struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian
   float op, r, g, b, depth;
   uint32_t entry;       // low 27 bits: entry id = geom.offset + position of the tile in the rect;
                         // high 5 bits: number of (entry, cell) pairs = cells the entry can reach (0..16)
-  uint32_t pairs;       // id of this entry's first (entry, cell) pair; pair ids are entry-major (the backward's pair rows)
+  uint32_t pairs;       // (unused: the pair table of the reduction is `entpair`)
 };
 #define HGS_LOG2E 1.4426950408889634f
 
@@ -142,6 +142,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   unsigned long long* keys;
   SortRec* recs;
   uint2* cell_list;           // [16 C]: (record index, pair id)
+  uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first pair id) - what the pair reduction reads
   float* cstate;              // [C/4 + 1][6][16]
   uint2* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, segment)
   uint32_t* n_contrib;        // [B][H*W]  1 + cell-list rank of the pixel's last contributor

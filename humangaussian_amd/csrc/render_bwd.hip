@@ -360,7 +360,7 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
   if (p - (uint32_t)lane >= R) return;                       // (wave-uniform)
   const bool have = p < R;
   uint2 ep = make_uint2(0u, 0u);
-  if (have) ep = *reinterpret_cast<const uint2*>(&recs_all[p].entry);    // entry id | pairs << 27, first pair id
+  if (have) ep = L.entpair[p];                                // entry id | pairs << 27, first pair id
   const uint32_t entry = ep.x & 0x7ffffffu, cnt = ep.x >> 27;
   const uint32_t incl = hgs_wave_incl_scan(cnt), off = incl - cnt;
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
