@@ -43,9 +43,6 @@
 #ifndef HGS_BWD_AHEAD
 #define HGS_BWD_AHEAD 1                // records whose LDS reads run ahead of the evaluation
 #endif
-#ifndef HGS_ABL
-#define HGS_ABL 0                      // timing experiments only (bit 0: no MFMA, 1: no evaluation, 2: no pair-row stores, 3: no record gather)
-#endif
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
@@ -107,7 +104,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   unsigned long long tl_w0 = 0;
   uint32_t tl_nb = 0;
 #endif
-#define HGS_TACC(i)
   // Persistent waves, static round-robin over the groups of four items: wave w takes groups w, w + W, ... - the
   // table is longest first, so every wave gets a similar mix.  (A shared ticket - one device-scope atomic per group on
   // ONE address - serialised at the memory side of the fabric: ~10 ns each, 110 us for the 10^4 fetches of a view.)
@@ -215,7 +211,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float il = 1.0f / HGS_LOG2E;
       const float opi = (pop != 0.0f) ? 1.0f / pop : 0.0f;
       float4* row = reinterpret_cast<float4*>(pair_rows + (size_t)ppid * HGS_ROW_FLOATS);
-      if (HGS_ABL & 4) { if (k00 == 123.456f) row[0] = zero4; return; }
       row[0] = make_float4(x0 * il, x1 * il, sxx * -0.5f, sxy * -1.0f);
       row[1] = make_float4(syy * -0.5f, k00 * opi, a3[0], a3[1]);
       row[2] = make_float4(a3[2], a3[3], 0.0f, 0.0f);
@@ -223,8 +218,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       row[3] = make_float4(0.f, 0.f, 0.f, 0.f);          // (the whole 64 B granule is written: no read-modify-write at the memory side)
 #endif
     };
-
-    HGS_TACC(0);
     for (uint32_t it0 = 0; it0 < maxcnt; it0 += HGS_RB) {
 #ifdef HGS_TIMELINE
       ++tl_nb;
@@ -241,7 +234,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       c0 = zero4; c1 = zero4; c2 = zero4;
       const uint32_t pid_this = pid_cur;
       pid_cur = le_next.y;
-      if (le_next.x != 0xffffffffu && !(HGS_ABL & 8)) {
+      if (le_next.x != 0xffffffffu) {
         c0 = recs[3 * (size_t)le_next.x]; c1 = recs[3 * (size_t)le_next.x + 1]; c2 = recs[3 * (size_t)le_next.x + 2];
         c2.w = __uint_as_float(le_next.x - tstart1);
       }
@@ -262,7 +255,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // ---- 16 iterations: everything that depends on (pixel, record); T and F are the only carried values
-      if (!(HGS_ABL & 2)) {
       // (the LDS reads of record u + HGS_BWD_AHEAD are in flight while record u is evaluated)
       float4 q0[HGS_BWD_AHEAD], q1[HGS_BWD_AHEAD], q2[HGS_BWD_AHEAD];
 #pragma unroll
@@ -295,14 +287,11 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         stage_k[u * HGS_STAGE_STRIDE + lane] = am * dLda;      // k = dL/dG * G
         stage_w[u * HGS_STAGE_STRIDE + lane] = wgt;
       }
-      }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      HGS_TACC(1);
       // keep the previous batch's accumulators in AGPRs up to here: read any earlier and the wave
       // waits for its MFMA chains before evaluating this batch (no overlap)
       if (pending) { asm volatile("" : "+a"(pa1), "+a"(pa2), "+a"(pa3)); finish(pa1, pa2, pa3, pit); }
-      HGS_TACC(3);
       // operand B: lane 16 kk + n reads (iteration n, pixels of row kk): 16 consecutive floats per stage
       hgs_f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
       {
@@ -316,7 +305,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           const float wx[4] = {bw.x, bw.y, bw.z, bw.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (HGS_ABL & 1) continue;
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * q4 + r], kx[r], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[4 * q4 + r], kx[r], acc2, 0, 0, 0);
             acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[4 * q4 + r], wx[r], acc3, 0, 0, 0);
@@ -325,7 +313,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();                 // the next batch overwrites the stages
-      HGS_TACC(2);
       pa1 = acc1; pa2 = acc2; pa3 = acc3;
       pmx = mxr; pmy = myr; pqa = qar; pqb = qbr; pqc = qcr; pop = opr;
       pit = it0; ppid = pid_this;
@@ -369,11 +356,7 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
   float2 s2 = make_float2(0.f, 0.f);
   // contiguous?  every entry with pairs must sit at (first pair of the wave) + (pairs of the lanes before it)
   const unsigned long long withp = __ballot(cnt != 0u);
-#ifdef HGS_RED_ABL_R
-  if (withp == 0x1234ull) {
-#else
   if (withp != 0ull) {
-#endif
     const int first = __builtin_ctzll(withp);
     const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(ep.y - off), first);
     const bool contiguous = __ballot(cnt != 0u && ep.y - off != base) == 0ull;
@@ -406,11 +389,7 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
       }
     }
   }
-#ifdef HGS_RED_ABL_W
-  if (have && s0.x == 123.456f) {
-#else
   if (have) {
-#endif
     float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
     dst[0] = s0; dst[1] = s1; dst[2] = make_float4(s2.x, s2.y, 0.0f, 0.0f);
 #if HGS_GROW_F4 > 3

@@ -46,3 +46,19 @@ def prune_rows(keep: torch.Tensor, tensors: Sequence[torch.Tensor]):
     """[t[keep] for t in tensors] for (P, ...) fp32 tensors (parameters, exp_avg, exp_avg_sq,
     xyz_gradient_accum, denom, max_radii2D), order preserved."""
     return _lib.load_binding().compact_rows(keep, list(tensors))
+
+
+def append_rows(tensors: Sequence[torch.Tensor], new_rows: Sequence[Optional[torch.Tensor]]):
+    """The clone / split APPEND half of the optimizer surgery (gaussian_model.py:339-357, `cat_tensors_to_optimizer`):
+    [cat(t, n)] per tensor; `None` in `new_rows` appends zeros of the other tensors' row count - what the reference
+    does for the Adam moments (`exp_avg`, `exp_avg_sq`) and for `xyz_gradient_accum` / `denom` / `max_radii2D`
+    (gaussian_model.py:352-357).  Plain `torch.cat` (a copy is the whole operation: nothing to fuse)."""
+    n_new = next((n.shape[0] for n in new_rows if n is not None), 0)
+    out = []
+    for t, n in zip(tensors, new_rows):
+        if n is None:
+            n = torch.zeros((n_new,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if n.shape[1:] != t.shape[1:]:
+            raise ValueError("append_rows: new rows must have the tensor's trailing dimensions")
+        out.append(torch.cat((t, n.to(dtype=t.dtype, device=t.device)), dim=0))
+    return out

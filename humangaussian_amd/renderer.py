@@ -146,6 +146,52 @@ class Renderer:
                 "radii": out["radii"]}
 
 
+class HostCamera:
+    """What `render()` / `render_views()` read from a camera, built WITHOUT device work."""
+
+    def __init__(self, H, W, fovx, fovy, view, full, center):
+        self.image_height, self.image_width = int(H), int(W)
+        self.FoVx, self.FoVy = float(fovx), float(fovy)
+        self.world_view_transform, self.full_proj_transform, self.camera_center = view, full, center
+
+
+def cameras_from_c2w(c2w, fovy, image_height: int, image_width: int, device="cuda", znear: float = 0.01,
+                     zfar: float = 100.0):
+    """The B cameras of a training step from their camera-to-world matrices, computed on the HOST with
+    ONE upload of B x 35 floats.  The reference builds every view's `Camera` on the device
+    (/root/reference/gaussiansplatting/scene/cameras.py:22-53: two `torch.inverse()` launches, a dozen elementwise
+    kernels and a device-to-host `tan` per view; utils/graphics_utils.py:73-99 for the projection); the arithmetic
+    is restated here in float64 numpy (pinned to the reference class by tests/golden/reference_helpers.npz through
+    synth.camera_from_c2w, which shares it).  c2w: (B,4,4) array-like, fovy: radians, scalar or (B,)."""
+    import math
+    import numpy as np
+    c2w = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float64).reshape(-1, 4, 4)
+    B = c2w.shape[0]
+    fov = np.broadcast_to(np.asarray(fovy.detach().cpu() if isinstance(fovy, torch.Tensor) else fovy, dtype=np.float64).reshape(-1), (B,))
+    H, W = int(image_height), int(image_width)
+    pack = np.zeros((B, 35), np.float32)
+    fovs = []
+    for b in range(B):
+        fy = float(fov[b])
+        focal = H / (2.0 * math.tan(fy / 2.0))
+        fx = 2.0 * math.atan(W / (2.0 * focal))                          # cameras.py:22 (fov2focal / focal2fov)
+        w2c = np.linalg.inv(c2w[b])
+        w2c[1:3, :3] *= -1                                               # cameras.py:28-29
+        w2c[:3, 3] *= -1
+        V = w2c.T                                                        # cameras.py:50
+        ty, tx = math.tan(fy / 2.0), math.tan(fx / 2.0)
+        Pm = np.zeros((4, 4))
+        Pm[0, 0], Pm[1, 1], Pm[3, 2] = 1.0 / tx, 1.0 / ty, 1.0           # graphics_utils.py:73-93
+        Pm[2, 2], Pm[2, 3] = zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)
+        pack[b, :16] = V.reshape(-1)
+        pack[b, 16:32] = (V @ Pm.T).reshape(-1)                          # cameras.py:52
+        pack[b, 32:35] = np.linalg.inv(V)[3, :3]                         # cameras.py:53
+        fovs.append((fx, fy))
+    dev = torch.from_numpy(pack).to(device, non_blocking=True)
+    return [HostCamera(H, W, fovs[b][0], fovs[b][1], dev[b, :16].view(4, 4), dev[b, 16:32].view(4, 4), dev[b, 32:35])
+            for b in range(B)]
+
+
 def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
                  override_color=None, fuse_activations=False):
     """All views of one training step in ONE rasterize call - the batched form of the loop
@@ -160,6 +206,9 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_mo
     `pc._rotation`) to the rasterizer, which applies sigmoid / exp / normalize inside its
     per-Gaussian kernels (forward and backward): six elementwise launches fewer per step; results
     then agree with the un-fused path to rounding (expf vs torch.exp), not bit for bit.
+
+    `viewpoint_cameras`: reference `Camera` / `MiniCam` objects, or the `HostCamera`s of `cameras_from_c2w()` (host-side
+    matrices, one upload per step instead of the reference's per-view device inversions).
 
     Returns the reference's dict with a leading view axis:
       render (B,3,H,W), depth_3dgs (B,1,H,W), alpha_3dgs (B,1,H,W), radii (B,P),

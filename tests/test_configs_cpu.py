@@ -95,3 +95,28 @@ def test_load_ply_kiui_axes_fixups_match_gs_renderer(tmp_path):
     for k in ("features_dc", "features_rest", "opacity"):
         assert np.array_equal(fixed[k], plain[k])
     assert not np.array_equal(fixed["xyz"], plain["xyz"])
+
+
+def test_cameras_from_c2w_match_the_per_camera_arithmetic_and_append_rows():
+    """renderer.cameras_from_c2w (host-side matrices of a whole step, one upload) == synth.camera_from_c2w per view
+    (which tests/golden/reference_helpers.npz pins to the reference Camera class); densify.append_rows == the
+    reference's cat_tensors_to_optimizer semantics (gaussian_model.py:339-357)."""
+    import numpy as np
+    import torch
+    from humangaussian_amd import densify, renderer, synth
+    c2ws = np.stack([synth.c2w_orbit(10.0 + 3 * i, 40.0 * i, 1.5 + 0.1 * i) for i in range(5)])
+    fovy = np.radians([40.0, 50.0, 55.0, 60.0, 70.0])
+    cams = renderer.cameras_from_c2w(c2ws, fovy, 96, 128, device="cpu")
+    for i, c in enumerate(cams):
+        ref = synth.camera_from_c2w(c2ws[i], float(fovy[i]), 96, 128)
+        assert abs(c.FoVx - ref.FoVx) < 1e-12 and abs(c.FoVy - ref.FoVy) < 1e-12
+        assert torch.equal(c.world_view_transform, ref.world_view_transform)
+        assert torch.equal(c.full_proj_transform, ref.full_proj_transform)
+        assert torch.equal(c.camera_center, ref.camera_center)
+        assert (c.image_height, c.image_width) == (96, 128)
+    xyz, m1 = torch.arange(12.0).reshape(4, 3), torch.ones(4, 3)
+    acc = torch.arange(4.0).reshape(4, 1)
+    new = torch.full((2, 3), 7.0)
+    a, b, c_ = densify.append_rows([xyz, m1, acc], [new, None, None])
+    assert torch.equal(a, torch.cat((xyz, new))) and torch.equal(b, torch.cat((m1, torch.zeros(2, 3))))
+    assert torch.equal(c_, torch.cat((acc, torch.zeros(2, 1))))

@@ -329,3 +329,42 @@ def test_convert_shs_python_branch_degree3_matches_rasterizer_sh():
         b = render(cam, pc, Pipe(), sc["bg"].to(dev))
     assert float((a["render"] - b["render"]).abs().max()) < 2e-5
     assert torch.equal(a["radii"], b["radii"])
+
+
+def test_reference_render_call_replayed_on_the_hip_rasterizer():
+    """The arguments the reference's OWN render() (gaussian_renderer/__init__.py:18-104, run unchanged against the
+    reference GaussianModel by tests/golden/make_render_call_fixture.py in the build container) hands to
+    GaussianRasterizer.forward, replayed here through the HIP rasterizer and checked against the oracle:
+    forward images <= 1e-4, radii exact, gradients <= 1e-3 max|g| (fp64 oracle)."""
+    import os
+    import numpy as np
+    import oracle
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_render_call.npz"))
+    H, W, tfx, tfy, mod, deg = fx["scalars"].tolist()
+    H, W, deg = int(H), int(W), int(deg)
+    dev = torch.device("cuda")
+    t = lambda k: torch.from_numpy(fx[k].copy())  # noqa: E731
+    rs = GaussianRasterizationSettings(H, W, tfx, tfy, t("bg").to(dev), mod, t("viewmatrix").to(dev), t("projmatrix").to(dev),
+                                       deg, t("campos").to(dev), False, False)
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    ins = {k: t(k).to(dev).requires_grad_(True) for k in names}
+    m2 = torch.zeros_like(ins["means3D"], requires_grad=True)
+    c, r, d, a = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], colors_precomp=None,
+                                        opacities=ins["opacities"], scales=ins["scales"], rotations=ins["rotations"],
+                                        cov3D_precomp=None)
+    g = torch.Generator().manual_seed(4)
+    wc, wd, wa = (torch.randn(s, generator=g) for s in ((3, H, W), (1, H, W), (1, H, W)))
+    ((c * wc.to(dev)).sum() + (d * wd.to(dev)).sum() + (a * wa.to(dev)).sum()).backward()
+    st = oracle.OracleSettings(H, W, tfx, tfy, t("bg"), mod, t("viewmatrix"), t("projmatrix"), deg, t("campos"), False, False)
+    oin = {k: t(k).double().requires_grad_(True) for k in names}
+    om2 = torch.zeros(oin["means3D"].shape, dtype=torch.float64, requires_grad=True)
+    oc, orad, od, oa = oracle.rasterize(oin["means3D"], om2, oin["shs"], None, oin["opacities"], oin["scales"],
+                                        oin["rotations"], None, st, dtype=torch.float64)
+    ((oc * wc).sum() + (od * wd).sum() + (oa * wa).sum()).backward()
+    assert torch.equal(r.cpu(), oracle.rasterize(t("means3D"), None, t("shs"), None, t("opacities"), t("scales"),
+                                                 t("rotations"), None, st)[1])
+    assert int((r > 0).sum()) > 300
+    for got, ref in ((c, oc), (d, od), (a, oa)):
+        assert float((got.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    for got, ref in [(ins[k].grad, oin[k].grad) for k in names] + [(m2.grad, om2.grad)]:
+        assert float((got.cpu().double() - ref).abs().max()) <= 1e-3 * max(float(ref.abs().max()), 1e-12)

@@ -471,3 +471,27 @@ def test_batch_of_sixteen_views_and_global_atomic_bin_path():
         acc = gb if acc is None else {k: acc[k] + gb[k] for k in NAMES}
     for k in NAMES:
         assert torch.equal(got[k], acc[k]), k
+
+
+def test_render_views_with_host_side_cameras():
+    """renderer.cameras_from_c2w (matrices of all views formed on the host, one upload) feeds render_views the same
+    cameras as the reference's per-view device construction: identical images, radii and gradients."""
+    from test_gpu_api_contract import FakeCamera, FakeGaussianModel, Pipe
+    from humangaussian_amd.renderer import cameras_from_c2w
+    import numpy as np
+    B, P, H, W = 3, 800, 64, 80
+    sc = make_scene(P=P, sh_degree=1, seed=61, H=H, W=W, spread=0.3)
+    c2ws = np.stack([synth.c2w_orbit(5.0 * i, 70.0 * i, 1.8) for i in range(B)])
+    fovy = math.radians(50.0)
+    ref_cams = [FakeCamera(synth.camera_from_c2w(c2ws[i], fovy, H, W)) for i in range(B)]
+    host_cams = cameras_from_c2w(c2ws, fovy, H, W, device=DEV)
+    bg = sc["bg"].to(DEV)
+    outs = []
+    for cams in (ref_cams, host_cams):
+        pc = FakeGaussianModel(sc, 1)
+        out = render_views(cams, pc, Pipe(), bg)
+        (out["render"].sum() + out["depth_3dgs"].sum()).backward()
+        outs.append((out["render"].detach(), out["radii"], [p.grad.clone() for p in pc.params()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(x, y)
