@@ -241,6 +241,9 @@ def main():
         if args.collective == "auto":
             collective_mode[0] = min(vp.COLLECTIVE_MODES, key=lambda m: res[m]["collective_and_reduce_us"])
         collective = {"mode_used": collective_mode[0], "requested": args.collective, "timings": res,
+                      # nothing in a one-view-per-rank step can run beside the collective (the per-Gaussian backward
+                      # that produces the gradients is the last kernel of the step): all of it is exposed
+                      "exposed_collective_us": res[collective_mode[0]]["pack_us"] + res[collective_mode[0]]["collective_and_reduce_us"],
                       "bytes_per_rank_pack": int(pack.numel() * 4),
                       "note": "allgather = ONE all_gather_into_tensor of the per-rank gradient packs + rank-ordered local "
                               "reduction; scatter = all_to_all of row shards + the same local reduction + one all-gather of "

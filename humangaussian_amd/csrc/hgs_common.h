@@ -49,7 +49,9 @@
 #define HGS_RB 16              // records a row stages per batch (= lanes of a row)
 #define HGS_ROW_F4 (HGS_RB * 3 + 1)   // float4 per staged row: 16 records of 48 B + 16 B, so that the four rows of a wave
                                // (which read four DIFFERENT records per ds_read_b128) sit on different LDS banks
-#define HGS_SEGLEN 64          // cell-list entries per backward work item; the forward stores the pixel state
+#ifndef HGS_SEGLEN
+#define HGS_SEGLEN 128         // cell-list entries per backward work item; the forward stores the pixel state
+#endif
                                // of a cell at every multiple of this
 #define HGS_PAIRS_PER_ENTRY 16 // capacity of the pair arrays per entry of capacity (worst case: every cell)
 #define HGS_NEAR_Z 0.2f
@@ -115,7 +117,7 @@ struct Counters {
 // shorter).  Four items make a wave (one per row), so items are handed out longest first and in classes of
 // similar length: class 0 = full segments; 1 / 2 / 3 = partial ones with >= 43 / >= 22 / fewer entries.
 __host__ __device__ __forceinline__ uint32_t hgs_item_class(uint32_t cnt) {
-  return cnt >= HGS_SEGLEN ? 0u : (cnt >= 43u ? 1u : (cnt >= 22u ? 2u : 3u));
+  return cnt >= HGS_SEGLEN ? 0u : (cnt >= (2u * HGS_SEGLEN + 2u) / 3u ? 1u : (cnt >= (HGS_SEGLEN + 2u) / 3u ? 2u : 3u));
 }
 
 // Forward work item = one non-empty cell; a wave takes four cells of one class (rows of similar length end

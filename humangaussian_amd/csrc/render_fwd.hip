@@ -141,7 +141,7 @@ __device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L,
 
   for (uint32_t it0 = 0; it0 < len; it0 += 64u) {
     if (__ballot(T != 0.0f) == 0ull) break;          // every pixel has terminated
-    if (STORE && it0 > 0) {                          // pixel state in front of record it0 (a multiple of HGS_SEGLEN = 64)
+    if (STORE && it0 > 0 && (it0 % HGS_SEGLEN) == 0) {      // pixel state in front of record it0 (blocks of 64; HGS_SEGLEN is a multiple)
       const float s0 = hgs_rows_sum(C0, lane), s1 = hgs_rows_sum(C1, lane), s2 = hgs_rows_sum(C2, lane);
       const float sd = hgs_rows_sum(D, lane), sw = hgs_rows_sum(Wt, lane);
       if (r == 0) {
