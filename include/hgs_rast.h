@@ -54,22 +54,27 @@ typedef struct hgs_settings {
 /* Written by hgs_forward into the tail of the geom buffer (device) and, once the stream
  * reaches that point, mirrored to `status_host` (HOST, pinned) when it is non-NULL. */
 typedef struct hgs_status {
-  uint32_t num_rendered;   /* R = sum of tiles touched (upstream's `num_rendered`)      */
+  uint32_t num_rendered;   /* R = entries in the tile lists.  <= upstream's `num_rendered`: a    */
+                           /* (Gaussian, tile) pair gets an entry only if the box of its         */
+                           /* alpha >= 1/255 ellipse touches the tile (results are unchanged)    */
   uint32_t active_tiles;   /* tiles with a non-empty list                              */
   uint32_t num_buckets;    /* unused since ABI v11 (0)                                 */
-  uint32_t bwd_groups;     /* unused since ABI v11 (0): the blend backward runs persistent waves */
+  uint32_t bwd_groups;     /* unused since ABI v11 (0): the blend kernels run persistent waves */
   uint32_t overflow;       /* != 0: outputs are INVALID.  bit0: R exceeded              */
                            /* entry_capacity (retry with >= num_rendered); bit1: a tile */
                            /* list exceeded max_tile_entries_hint (retry with hint 0)   */
   uint32_t reserved[3];    /* [0] = entry_capacity the bin buffer was carved with,      */
-                           /* [1] = longest tile list, [2] = forward segments of long lists */
+                           /* [1] = longest tile list, [2] = 1: "complete" - in the host mirror this */
+                           /* word is stored LAST behind a system-scope fence, so a host that  */
+                           /* cleared it before the call may POLL it instead of using an event */
 } hgs_status;
 
 /* ---- buffer sizing (host-side arithmetic, no device work) --------------------------
  * Replaces the three resize callbacks (geometry / binning / image state) that upstream's
  * rasterize_gaussians() drives through torch.  geom: per-Gaussian + per-tile state;
  * bin: per-(tile,Gaussian) entry state, sized by entry_capacity; img: per-pixel state;
- * bwd_scratch: per-entry gradient rows used only inside hgs_backward. */
+ * bwd_scratch: gradient rows per entry and per (entry, 4x4-pixel cell) pair, used only inside
+ * hgs_backward (17 x 48 B per entry). */
 size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t hgs_bin_bytes(int64_t entry_capacity);
 size_t hgs_img_bytes(int32_t image_height, int32_t image_width);
@@ -91,7 +96,7 @@ size_t hgs_img_bytes_batch(int32_t B, int32_t image_height, int32_t image_width)
  * cov3D_precomp must be non-NULL (HGS_ESHAPE otherwise), matching the fork's Python
  * checks.  shs is (P, M, 3); M = max coefficient count of the tensor.
  * out_color (3,H,W), out_depth (1,H,W), out_alpha (1,H,W), radii (P) int32.
- * store_bwd_state = 0 skips the bucket-state stores (no-grad / inference calls).
+ * store_bwd_state = 0 skips the pixel-state stores the backward needs (no-grad / inference calls).
  * max_tile_entries_hint: 0 = unknown; > 0 = the caller promises no tile list is longer
  * (lets the library skip launching sort classes that cannot occur); a broken promise is
  * detected on the device and reported as overflow bit 1 (value 2) - call again with 0.
