@@ -339,6 +339,7 @@ def test_reference_render_call_replayed_on_the_hip_rasterizer():
     import os
     import numpy as np
     import oracle
+    from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer
     fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_render_call.npz"))
     H, W, tfx, tfy, mod, deg = fx["scalars"].tolist()
     H, W, deg = int(H), int(W), int(deg)
