@@ -1,9 +1,9 @@
 // render_bwd.hip - blend backward (stage B1 of SURVEY.md 2.3(B)), CELL-ROW mapping, and the pair reduction.
 //
 // Upstream walks each pixel's list back-to-front and issues ~10 atomicAdd per (pixel, Gaussian) pair.
-// Here the unit of work is 64 consecutive entries of ONE CELL LIST (a 4x4-pixel cell of a tile, the records
-// that can reach it, depth-ordered; written by the sort kernel): the forward stored the cell's per-pixel
-// running state (T, C, D, W) at every 64th entry, so all items are independent.  A wave64 is FOUR ROWS of
+// Here the unit of work is HGS_SEGLEN (128) consecutive entries of ONE CELL LIST (a 4x4-pixel cell of a tile, the
+// records that can reach it, depth-ordered; written by the sort kernel): the forward stored the cell's per-pixel
+// running state (T, C, D, W) at every HGS_SEGLEN-th entry, so all items are independent.  A wave64 is FOUR ROWS of
 // 16 lanes; each row takes one work item (any cell of any tile), lane = pixel of the row's cell.  Persistent
 // waves take groups of four items round-robin from a longest-first table (full segments, then partial ones by
 // length class).
@@ -19,29 +19,34 @@
 // quantities with per-pixel constants:
 //   k   (= op G dL/dalpha)  against  1, u, v, u^2, uv, v^2     (u, v = pixel - cell centre)
 //   wgt (= alpha T)         against  g_C0, g_C1, g_C2, g_D
-// and run on the matrix cores, v_mfma_f32_16x16x4_f32 (exact fp32), once per batch of 16 iterations:
-//   D[m][n] += sum_kk A[m][kk] B[kk][n],   instruction t = in-cell pixel t of ALL FOUR cells:
-//   K slot kk = row (cell) kk, column n = iteration n of the batch, row m = (cell jj, quantity q);
-//   B[kk][n] = k (or wgt) of row kk's record n at its pixel t: lane 16 kk + n reads it from the LDS stage;
-//   A[(jj, q)][kk] = basis_q(pixel t) if jj == kk else 0 (block diagonal: a row's records only meet
-//   their own cell's pixels).
-// Three chains (A = {1, u, v, u^2} x k; {uv, v^2} x k; {g_C0, g_C1, g_C2, g_D} x wgt), 16 instructions each.
-// The accumulator layout then puts ALL TEN sums of (row kk, record n) into lane 16 kk + n - the lane that
+// and run on the matrix cores, once per batch of 16 iterations, as v_mfma_f32_4x4x1_16b_f32 (exact fp32): SIXTEEN
+// independent 4x4 outer-product blocks per instruction, block = 4 consecutive lanes,
+//   D_b[q][jn] += A_b[q] * B_b[jn],      instruction t = in-cell pixel t of ALL FOUR cells:
+//   block b = (cell b >> 2, records 4 (b & 3) .. + 3 of the batch), q = one of four quantities;
+//   B: lane l = 16 cell + n supplies k (or wgt) of (cell, record n) at pixel t - it reads it from the LDS stage;
+//   A: lane l supplies basis_{l & 3}(pixel t)  (for the gradient chain: g_{l & 3} at pixel t of cell l >> 4).
+// Three chains (A = {1, u, v, u^2} x k; {uv, v^2} x k; {g_C0, g_C1, g_C2, g_D} x wgt), 16 instructions of 8 cycles
+// each.  The accumulator layout puts ALL TEN sums of (cell, record n) into lane 16 cell + n - the lane that
 // gathered that record - so the moment -> gradient conversion and the 48 B pair row need no shuffles.
+// (First version: v_mfma_f32_16x16x4_f32 with a block-diagonal A - K slot = cell - to get the same layout: three
+// quarters of its 32 cycles multiplied zeros, and the matrix pipe was 40 % of the kernel's issue time.)
 //
 // An (entry, cell) pair row lands at the pair's id (entry-major); hgs_k_pair_reduce adds the pair rows of
 // every entry in cell order (fixed order: no atomics, bitwise reproducible) into one 48 B gradient row per
 // entry, which hgs_k_preprocess_bwd sums per Gaussian.
 //
-// Roofline: VALU issue (~35 instructions per row iteration) beside the MFMA pipe (3 x 32 cycles per
+// Roofline: VALU issue (~35 instructions per row iteration) beside the MFMA pipe (3 x 8 cycles per
 // iteration); HBM traffic per (entry, cell) pair: 4 B index + 48 B record gather (L2-served), 48 B pair row
-// out, 24 B/pixel state per 64 pairs in.
+// out, 24 B/pixel state per 128 pairs in.
 //
 // This file is its own translation unit (it compiles in parallel with api.hip; same flags).
 #include "hgs_common.h"
 
 #ifndef HGS_BWD_AHEAD
 #define HGS_BWD_AHEAD 1                // records whose LDS reads run ahead of the evaluation
+#endif
+#ifndef HGS_BWD_SNAKE
+#define HGS_BWD_SNAKE 1                // odd rounds of the persistent waves run through the group table backwards
 #endif
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 
@@ -85,18 +90,15 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all);
   float4* __restrict__ srow = s_rec + j * HGS_ROW_F4;
 
-  // ---- MFMA operand A of the two moment chains: constants of the lane.  Lane l supplies A[m = l & 15][kk = l >> 4];
-  // m = (cell jj = m >> 2, quantity q = m & 3); block diagonal: zero unless jj == kk.  Instruction t: in-cell pixel t.
-  const bool diag = ((lane & 15) >> 2) == (lane >> 4);
+  // ---- MFMA operand A of the two moment chains: constants of the lane.  Lane l supplies A[q = l & 3] of block l >> 2
+  // (its cell: l >> 4); instruction t: in-cell pixel t.
   const int qsel = lane & 3;
   float A1[16], A2[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const float u = (float)(t & 3) - 1.5f, w_ = (float)(t >> 2) - 1.5f;
-    const float f1 = qsel == 0 ? 1.0f : (qsel == 1 ? u : (qsel == 2 ? w_ : u * u));
-    const float f2 = qsel == 0 ? u * w_ : (qsel == 1 ? w_ * w_ : 0.0f);
-    A1[t] = diag ? f1 : 0.0f;
-    A2[t] = diag ? f2 : 0.0f;
+    A1[t] = qsel == 0 ? 1.0f : (qsel == 1 ? u : (qsel == 2 ? w_ : u * u));
+    A2[t] = qsel == 0 ? u * w_ : (qsel == 1 ? w_ * w_ : 0.0f);
   }
 
 #ifdef HGS_TIMELINE
@@ -104,10 +106,14 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   unsigned long long tl_w0 = 0;
   uint32_t tl_nb = 0;
 #endif
-  // Persistent waves, static round-robin over the groups of four items: wave w takes groups w, w + W, ... - the
-  // table is longest first, so every wave gets a similar mix.  (A shared ticket - one device-scope atomic per group on
-  // ONE address - serialised at the memory side of the fabric: ~10 ns each, 110 us for the 10^4 fetches of a view.)
-  for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  // Persistent waves, static SNAKE over the groups of four items: wave w takes group w of round 0, W - 1 - w of
+  // round 1, ... - the table is longest first, so the waves that drew the full segments get the shortest leftovers.
+  // (Plain round-robin: a view has ~1.16 W groups, and the 485 groups of the second round went to the waves that
+  // already held the longest ones - the kernel ran 65 us for 47 us of mean load.  A shared ticket - one device-scope
+  // atomic per group on ONE address - serialised at the memory side of the fabric: ~10 ns each, 110 us per view.)
+  for (uint32_t rnd = 0, grp0 = 0; grp0 < ngroups; ++rnd, grp0 += gridDim.x) {
+    const uint32_t grp = grp0 + ((HGS_BWD_SNAKE && (rnd & 1u)) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+    if (grp >= ngroups) continue;
 #ifdef HGS_TIMELINE
     tl_w0 = wall_clock64(); tl_nb = 0;
 #endif
@@ -161,8 +167,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const float4 a = *reinterpret_cast<const float4*>(ar + 4 * q4);
-        A3[4 * q4 + 0] = diag ? a.x : 0.0f; A3[4 * q4 + 1] = diag ? a.y : 0.0f;
-        A3[4 * q4 + 2] = diag ? a.z : 0.0f; A3[4 * q4 + 3] = diag ? a.w : 0.0f;
+        A3[4 * q4 + 0] = a.x; A3[4 * q4 + 1] = a.y; A3[4 * q4 + 2] = a.z; A3[4 * q4 + 3] = a.w;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -174,16 +179,25 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     maxcnt = max(maxcnt, (uint32_t)__builtin_amdgcn_readlane((int)cnt, 32));
     maxcnt = max(maxcnt, (uint32_t)__builtin_amdgcn_readlane((int)cnt, 48));
 
-    // software pipeline of the record stream: indices two batches ahead, records one batch ahead
-    const uint2 nol = make_uint2(0xffffffffu, 0u);
-    uint2 le_next = ((uint32_t)i < cnt) ? list[i] : nol;
+    // Software pipeline of the record stream: indices two batches ahead, records one batch ahead.  Every load is
+    // UNCONDITIONAL (a lane beyond the item's end re-reads a valid slot and is marked through its list position,
+    // 0xffffffff = never active) and the index load is issued BEFORE the record gather of the same iteration: with
+    // predicated loads the compiler merged the loaded registers into the loop-carried ones right behind the load
+    // (s_waitcnt vmcnt(1) two instructions after the gather: the whole memory latency exposed once per batch), and
+    // with the index load last, the wait for it (vmcnt is in order) also waited for the gather and the row stores.
+    const uint32_t safe_rec = have ? tstart1 + 1u : 0u;  // the tile's first record: always a valid slot
+    auto list_at = [&](uint32_t e) { return list[(e < cnt) ? e : 0u]; };
+    auto gather = [&](const uint2 le, bool valid, float4& r0, float4& r1, float4& r2) {
+      const uint32_t idx = valid ? le.x : safe_rec;
+      r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1];
+      const float4 t2 = recs[3 * (size_t)idx + 2];
+      r2 = make_float4(t2.x, t2.y, t2.z, __uint_as_float(valid ? idx - tstart1 : 0xffffffffu));   // .w: 1-based position in the tile list
+    };
+    uint2 le_next = list_at((uint32_t)i);
     uint32_t pid_cur = le_next.y;                       // pair id of the lane's record of the current batch
-    float4 c0 = zero4, c1 = zero4, c2 = zero4;
-    if (le_next.x != 0xffffffffu) {
-      c0 = recs[3 * (size_t)le_next.x]; c1 = recs[3 * (size_t)le_next.x + 1]; c2 = recs[3 * (size_t)le_next.x + 2];
-      c2.w = __uint_as_float(le_next.x - tstart1);
-    }
-    le_next = (HGS_RB + (uint32_t)i < cnt) ? list[HGS_RB + i] : nol;
+    float4 c0, c1, c2;
+    gather(le_next, (uint32_t)i < cnt, c0, c1, c2);
+    le_next = list_at(HGS_RB + (uint32_t)i);
     {
       // A pixel whose last contributor (n_contrib, a tile-list position) lies before the item's first record
       // finished before this item - its forward row may have stopped without storing the state - and is never active.
@@ -230,16 +244,13 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         __builtin_amdgcn_wave_barrier();               // the previous batch's LDS reads are done
         srow[3 * i + 0] = c0; srow[3 * i + 1] = c1; srow[3 * i + 2] = c2;
       }
-      // next batch's records, the indices after that (also when this batch is skipped)
-      c0 = zero4; c1 = zero4; c2 = zero4;
-      const uint32_t pid_this = pid_cur;
-      pid_cur = le_next.y;
-      if (le_next.x != 0xffffffffu) {
-        c0 = recs[3 * (size_t)le_next.x]; c1 = recs[3 * (size_t)le_next.x + 1]; c2 = recs[3 * (size_t)le_next.x + 2];
-        c2.w = __uint_as_float(le_next.x - tstart1);
-      }
+      // the index of the batch after next, then the next batch's records (also when this batch is skipped)
+      const uint2 le_use = le_next;
       const uint32_t in2 = it0 + 2 * HGS_RB + (uint32_t)i;
-      le_next = (in2 < cnt) ? list[in2] : nol;
+      le_next = list_at(in2);
+      const uint32_t pid_this = pid_cur;
+      pid_cur = le_use.y;
+      gather(le_use, it0 + HGS_RB + (uint32_t)i < cnt, c0, c1, c2);
       if (act == 0ull) {
         // nothing contributes any more (every pixel terminated before): zero pair rows, no evaluation
         if (pending) { asm volatile("" : "+a"(pa1), "+a"(pa2), "+a"(pa3)); finish(pa1, pa2, pa3, pit); pending = false; }
@@ -305,9 +316,9 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           const float wx[4] = {bw.x, bw.y, bw.z, bw.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[4 * q4 + r], kx[r], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[4 * q4 + r], kx[r], acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A3[4 * q4 + r], wx[r], acc3, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1[4 * q4 + r], kx[r], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(A2[4 * q4 + r], kx[r], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(A3[4 * q4 + r], wx[r], acc3, 0, 0, 0);
           }
         }
       }

@@ -126,18 +126,20 @@ __device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L,
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, Wt = 0.f;
   uint32_t last = 0;
 
-  auto load_idx = [&](uint32_t e) { return (e < len) ? list[e].x : 0xffffffffu; };
-  auto gather = [&](uint32_t idx, float4& r0, float4& r1, float4& r2) {
-    r0 = zero4; r1 = zero4; r2 = zero4;
-    if (idx != 0xffffffffu) {
-      r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1]; r2 = recs[3 * (size_t)idx + 2];
-      r2.w = __uint_as_float(idx - tstart1);
-    }
+  // Unconditional loads (a lane beyond the list re-reads a valid slot; its record is neutralised - opacity 0 - when it
+  // is staged, one block later, when the data has arrived anyway), and the index load goes BEFORE the gather of the
+  // same iteration: vmcnt counts in order, so waiting for the youngest load waits for everything before it.
+  auto load_idx = [&](uint32_t e) { return list[(e < len) ? e : 0u].x; };
+  auto gather = [&](uint32_t idx_raw, bool valid, float4& r0, float4& r1, float4& r2) {
+    const uint32_t idx = valid ? idx_raw : tstart1 + 1u;               // (the tile's first record)
+    r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1];
+    const float4 t2 = recs[3 * (size_t)idx + 2];
+    r2 = make_float4(t2.x, t2.y, t2.z, __uint_as_float(valid ? idx - tstart1 : 0xffffffffu));
   };
-  // blocks of 64 records, one per lane; index two blocks ahead, records one block ahead
+  // blocks of 64 records, one per lane; indices two and three blocks ahead, records one block ahead
   float4 c0, c1, c2;
-  gather(load_idx((uint32_t)lane), c0, c1, c2);
-  uint32_t idx_next = load_idx(64u + (uint32_t)lane);
+  gather(load_idx((uint32_t)lane), (uint32_t)lane < len, c0, c1, c2);
+  uint32_t idx_a = load_idx(64u + (uint32_t)lane), idx_b = load_idx(128u + (uint32_t)lane);
 
   for (uint32_t it0 = 0; it0 < len; it0 += 64u) {
     if (__ballot(T != 0.0f) == 0ull) break;          // every pixel has terminated
@@ -150,9 +152,11 @@ __device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L,
       }
     }
     __builtin_amdgcn_wave_barrier();                 // the previous block's LDS reads are done
+    c1.y = (__float_as_uint(c2.w) == 0xffffffffu) ? 0.0f : c1.y;      // pad record: never blends
     s_rec_w[3 * lane + 0] = c0; s_rec_w[3 * lane + 1] = c1; s_rec_w[3 * lane + 2] = c2;
-    gather(idx_next, c0, c1, c2);
-    idx_next = load_idx(it0 + 128u + (uint32_t)lane);
+    const uint32_t idx_n = load_idx(it0 + 192u + (uint32_t)lane);
+    gather(idx_a, it0 + 64u + (uint32_t)lane < len, c0, c1, c2);
+    idx_a = idx_b; idx_b = idx_n;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const float4* __restrict__ myrec = s_rec_w + 3 * r;          // record 4 k + r of the block
@@ -262,18 +266,19 @@ __device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L,
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // Software pipeline of the record stream: the index of batch b + 3 and the 48 B record gather of batch b + 2
   // are issued while batch b is blended.
-  auto load_idx = [&](uint32_t e) { return (e < len) ? list[e].x : 0xffffffffu; };
-  auto gather = [&](uint32_t idx, float4& r0, float4& r1, float4& r2) {
-    r0 = zero4; r1 = zero4; r2 = zero4;
-    if (idx != 0xffffffffu) {
-      r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1]; r2 = recs[3 * (size_t)idx + 2];
-      r2.w = __uint_as_float(idx - tstart1);
-    }
+  // Unconditional loads, index load before the gather of the same iteration (see render_fwd_cell4)
+  const uint32_t safe_rec = have ? tstart1 + 1u : 0u;
+  auto load_idx = [&](uint32_t e) { return list[(e < len) ? e : 0u].x; };
+  auto gather = [&](uint32_t idx_raw, bool valid, float4& r0, float4& r1, float4& r2) {
+    const uint32_t idx = valid ? idx_raw : safe_rec;
+    r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1];
+    const float4 t2 = recs[3 * (size_t)idx + 2];
+    r2 = make_float4(t2.x, t2.y, t2.z, __uint_as_float(valid ? idx - tstart1 : 0xffffffffu));
   };
   float4 c0, c1, c2, d0, d1, d2;                    // records of batch b (c) and b + 1 (d)
-  gather(load_idx((uint32_t)i), c0, c1, c2);
-  gather(load_idx(HGS_RB + (uint32_t)i), d0, d1, d2);
-  uint32_t idx_next = load_idx(2 * HGS_RB + (uint32_t)i);                  // batch b + 2
+  gather(load_idx((uint32_t)i), (uint32_t)i < len, c0, c1, c2);
+  gather(load_idx(HGS_RB + (uint32_t)i), HGS_RB + (uint32_t)i < len, d0, d1, d2);
+  uint32_t idx_a = load_idx(2 * HGS_RB + (uint32_t)i), idx_b = load_idx(3 * HGS_RB + (uint32_t)i);      // batches b + 2, b + 3
 
   for (uint32_t it0 = 0;; it0 += HGS_RB) {
     // rows still at work: list not exhausted and a pixel not finished
@@ -285,10 +290,12 @@ __device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L,
       cs[0 * 16] = s.T; cs[1 * 16] = s.C0; cs[2 * 16] = s.C1; cs[3 * 16] = s.C2; cs[4 * 16] = s.D; cs[5 * 16] = s.Wt;
     }
     __builtin_amdgcn_wave_barrier();                 // the previous batch's LDS reads are done
+    c1.y = (__float_as_uint(c2.w) == 0xffffffffu) ? 0.0f : c1.y;      // pad record: never blends
     srow[3 * i + 0] = c0; srow[3 * i + 1] = c1; srow[3 * i + 2] = c2;
     c0 = d0; c1 = d1; c2 = d2;
-    gather(row_on ? idx_next : 0xffffffffu, d0, d1, d2);
-    idx_next = row_on ? load_idx(it0 + 3 * HGS_RB + (uint32_t)i) : 0xffffffffu;
+    const uint32_t idx_n = load_idx(it0 + 4 * HGS_RB + (uint32_t)i);
+    gather(idx_a, row_on && (it0 + 2 * HGS_RB + (uint32_t)i < len), d0, d1, d2);
+    idx_a = idx_b; idx_b = idx_n;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // groups of HGS_FWD_GROUP records; the LDS reads of group k + 1 are in flight while group k is blended
