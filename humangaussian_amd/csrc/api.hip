@@ -78,7 +78,7 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   c.tile_start = take(TT * 4);
   c.tile_order = take(TT * 4);
   c.cell_info = take(TT * 16 * sizeof(CellInfo));
-  c.items_part = take(2 * 16 * TT * sizeof(uint2));      // last (partial) segment of every cell list, by length class
+  c.items_part = take(2 * 16 * TT * sizeof(uint4));      // last (partial) segment of every cell list, by length class
   c.fwd_cells = take((size_t)HGS_NFC * 16 * TT * 4);       // non-empty cells by length class
   c.hist = take(lds ? (size_t)B * nwg * T * 4 : 0);
   c.tile_gbase = take(lds ? (size_t)HGS_ROW_GROUPS * TT * 4 : 0);
@@ -107,7 +107,7 @@ BinCarve carve_bin(int64_t cap) {
   c.entpair = take(C * 8);
   // a cell list of len entries has ceil(len / 64) - 1 stored states and ceil(len / 64) work items, len / 64 of them full
   c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
-  c.items_full = take((NP / HGS_SEGLEN + 1) * sizeof(uint2));
+  c.items_full = take((NP / HGS_SEGLEN + 1) * sizeof(uint4));
   c.total = off;
   return c;
 }
@@ -123,7 +123,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.tile_start = reinterpret_cast<uint32_t*>(gp + g.tile_start);
   L.tile_order = reinterpret_cast<uint32_t*>(gp + g.tile_order);
   L.cell_info = reinterpret_cast<CellInfo*>(gp + g.cell_info);
-  L.items_part = reinterpret_cast<uint2*>(gp + g.items_part);
+  L.items_part = reinterpret_cast<uint4*>(gp + g.items_part);
   L.fwd_cells = reinterpret_cast<uint32_t*>(gp + g.fwd_cells);
   L.hist = reinterpret_cast<uint32_t*>(gp + g.hist);
   L.tile_gbase = reinterpret_cast<uint32_t*>(gp + g.tile_gbase);
@@ -136,7 +136,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.cell_list = bp ? reinterpret_cast<uint2*>(bp + b.cell_list) : nullptr;
   L.entpair = bp ? reinterpret_cast<uint2*>(bp + b.entpair) : nullptr;
   L.cstate = bp ? reinterpret_cast<float*>(bp + b.cstate) : nullptr;
-  L.items_full = bp ? reinterpret_cast<uint2*>(bp + b.items_full) : nullptr;
+  L.items_full = bp ? reinterpret_cast<uint4*>(bp + b.items_full) : nullptr;
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;
 }
@@ -482,8 +482,8 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   float* pair_rows = rows + (size_t)X * HGS_ROW_FLOATS;
   HGS_STAGE(0);
   if (maybe_entries) {
-    // persistent waves: as many as the chip holds (LDS: 11.8 KB per wave => 12 per CU, 3 per SIMD), each fetches
-    // groups of four work items
+    // persistent workgroups of HGS_BWD_BLOCK_WAVES waves: as many waves as the chip holds (LDS: 11.8 KB per wave =>
+    // 12 per CU, 3 per SIMD); the waves of a workgroup draw its groups of four work items through an LDS ticket
     static int resident = 0;
     if (resident == 0) {
       int dev = 0, cus = 0;
@@ -493,7 +493,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
       if (const char* e = getenv("HGS_BWD_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;     // (experiments)
       resident = per_cu * cus;
     }
-    hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)resident), dim3(64), 0, stream, v, L, status_dev, L.recs, L.cstate,
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)(resident / HGS_BWD_BLOCK_WAVES)), dim3(64 * HGS_BWD_BLOCK_WAVES), 0, stream, v, L, status_dev, L.recs, L.cstate,
                        out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows);
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);

@@ -295,12 +295,14 @@ __device__ __forceinline__ void hgs_alloc_cell_ranges(const View& v, const Layou
       L.cell_info[(size_t)g * 16 + lane] = ci;
       const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
       if (len) L.fwd_cells[(size_t)fcls * 16u * v.TT + fpos] = key;
-      uint2* full = L.items_full + (fb + i_full - nfull);
-      for (uint32_t sgm = 0; sgm < nfull; ++sgm) full[sgm] = make_uint2(key, sgm);
+      // a work item carries all its wave needs to start: (cell, entries, first cell-list slot, state slot in front of it)
+      uint4* full = L.items_full + (fb + i_full - nfull);
+      for (uint32_t sgm = 0; sgm < nfull; ++sgm)
+        full[sgm] = make_uint4(key, HGS_SEGLEN, base + sgm * HGS_SEGLEN, sgm ? ci.sbase + sgm - 1u : 0xffffffffu);
       if (rem) {
         const unsigned long long below = (1ull << lane) - 1ull;
         const size_t ptab = (size_t)16 * v.TT;
-        uint2 it = make_uint2(key, nfull | (rem << 24));
+        const uint4 it = make_uint4(key, rem, base + nfull * HGS_SEGLEN, nfull ? ci.sbase + nfull - 1u : 0xffffffffu);
         if (pcls == 1u) L.items_part[p1 + (uint32_t)__popcll(b1 & below)] = it;
         else if (pcls == 2u) L.items_part[ptab - 1 - (p2 + (uint32_t)__popcll(b2 & below))] = it;
         else L.items_part[ptab + p3 + (uint32_t)__popcll(b3 & below)] = it;

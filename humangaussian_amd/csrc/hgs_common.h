@@ -13,8 +13,8 @@
 //   uint32   tile_start[B*T]     first entry    uint2   cell_list[16C] (record index, pair id), CELL-major per tile
 //   uint32   tile_order[B*T]     heavy first                   pair ids are ENTRY-major: the pairs of an entry are neighbours
 //   CellInfo cell_info[B*T][16]  the 16 cell    float   cstate[C/4][6][16]  pixel state every 64 cell-list entries
-//            lists of a tile                    uint2   items_full[C/4] backward work items (full segments)
-//   uint2    items_part[2][16 B*T] backward work items (last, partial segment of every cell list)
+//            lists of a tile                    uint4   items_full[C/4] backward work items (full segments)
+//   uint4    items_part[2][16 B*T] backward work items (last, partial segment of every cell list)
 //   uint32   fwd_cells[11][16 B*T] forward work items: non-empty cells by length class
 //   uint32   hist[B*nwg][T]      per-binning-workgroup tile histograms (T <= 16384)
 //   uint32   tile_gbase[RG][B*T] absolute base of a row group inside the tile's list
@@ -49,6 +49,9 @@
 #define HGS_RB 16              // records a row stages per batch (= lanes of a row)
 #define HGS_ROW_F4 (HGS_RB * 3 + 1)   // float4 per staged row: 16 records of 48 B + 16 B, so that the four rows of a wave
                                // (which read four DIFFERENT records per ds_read_b128) sit on different LDS banks
+#ifndef HGS_BWD_BLOCK_WAVES
+#define HGS_BWD_BLOCK_WAVES 12 // waves per workgroup of the blend backward: they share one LDS ticket for the workgroup's groups
+#endif
 #ifndef HGS_SEGLEN
 #define HGS_SEGLEN 128         // cell-list entries per backward work item; the forward stores the pixel state
 #endif
@@ -139,14 +142,14 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* chunk_base;       // [B*nblk] first entry id of the chunk (bump-allocated)
   CellInfo* cell_info;        // [B*T][16]
   uint32_t* fwd_cells;        // [HGS_NFC][16 B*T]: cell keys (g * 16 + c) of the non-empty cells, per length class
-  uint2* items_part;          // [2][16 B*T]: table 0 holds class 1 (from the front) and class 2 (from the back), table 1 class 3
+  uint4* items_part;          // [2][16 B*T]: table 0 holds class 1 (from the front) and class 2 (from the back), table 1 class 3
   Counters* ctr;
   unsigned long long* keys;
   SortRec* recs;
   uint2* cell_list;           // [16 C]: (record index, pair id)
   uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first pair id) - what the pair reduction reads
   float* cstate;              // [C/4 + 1][6][16]
-  uint2* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, segment)
+  uint4* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, entries, first cell-list slot, state slot or ~0): all a wave needs to start
   uint32_t* n_contrib;        // [B][H*W]  1 + cell-list rank of the pixel's last contributor
 };
 

@@ -56,32 +56,46 @@ namespace {
 
 // the four work items of group `grp`, one per row: longest first (class 0 = full segments, then 1, 2, 3)
 __device__ __forceinline__ bool fetch_item(const View& v, const Layout& L, uint32_t q, uint32_t n0, uint32_t n1,
-                                           uint32_t n2, uint32_t n3, uint2& item) {
+                                           uint32_t n2, uint32_t n3, uint4& item) {
+  // ONE unconditional load from a selected address (a load per branch made the compiler wait for it on the spot)
   const size_t ptab = (size_t)16 * v.TT;
-  if (q < n0) { item = L.items_full[q]; return true; }
-  q -= n0;
-  if (q < n1) { item = L.items_part[q]; return true; }
-  q -= n1;
-  if (q < n2) { item = L.items_part[ptab - 1 - q]; return true; }
-  q -= n2;
-  if (q < n3) { item = L.items_part[ptab + q]; return true; }
-  return false;
+  const bool ok = q < n0 + n1 + n2 + n3;
+  const uint4* src = L.items_full + q;
+  if (q >= n0) {
+    const uint32_t q1 = q - n0;
+    src = L.items_part + q1;
+    if (q1 >= n1) {
+      const uint32_t q2 = q1 - n1;
+      src = (q2 < n2) ? L.items_part + (ptab - 1 - q2) : L.items_part + (ptab + (q2 - n2));
+    }
+  }
+  if (!ok) src = L.items_part;                          // (any valid slot; the caller masks every use with the result)
+  item = *src;
+  return ok;
 }
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64 * HGS_BWD_BLOCK_WAVES)
 hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const SortRec* __restrict__ recs_all, const float* __restrict__ cstate,
                  const float* __restrict__ out_color,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
                  const float* __restrict__ dL_dalpha, float* __restrict__ pair_rows) {
-  __shared__ float4 s_rec[4 * HGS_ROW_F4];                                         // [row][record][3] (+ pad: rows on different banks)
-  __shared__ __attribute__((aligned(16))) float stage_k[HGS_RB * HGS_STAGE_STRIDE];   // [iteration][pixel lane]
-  __shared__ __attribute__((aligned(16))) float stage_w[HGS_RB * HGS_STAGE_STRIDE];
+  // wave-private LDS slices
+  __shared__ float4 s_rec_all[HGS_BWD_BLOCK_WAVES][4 * HGS_ROW_F4];                 // [row][record][3] (+ pad: rows on different banks)
+  __shared__ __attribute__((aligned(16))) float stage_k_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];   // [iteration][pixel lane]
+  __shared__ __attribute__((aligned(16))) float stage_w_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];
+  __shared__ uint32_t s_ticket;
   if (status->overflow) return;
-  const int lane = (int)threadIdx.x;
+  const int lane = (int)threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  float4* __restrict__ s_rec = s_rec_all[wv];
+  float* __restrict__ stage_k = stage_k_all[wv];
+  float* __restrict__ stage_w = stage_w_all[wv];
+  if (threadIdx.x == 0) s_ticket = HGS_BWD_BLOCK_WAVES;      // tickets 0 .. waves - 1: every wave's first group
+  __syncthreads();
   const int j = lane >> 4, i = lane & 15;
   const uint32_t n0 = (uint32_t)L.ctr->alloc3[1], n1 = (uint32_t)(L.ctr->alloc3[1] >> 32);      // items per class
   const uint32_t n2 = (uint32_t)L.ctr->alloc3[2], n3 = (uint32_t)(L.ctr->alloc3[2] >> 32);
@@ -106,54 +120,83 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   unsigned long long tl_w0 = 0;
   uint32_t tl_nb = 0;
 #endif
-  // Persistent waves, static SNAKE over the groups of four items: wave w takes group w of round 0, W - 1 - w of
-  // round 1, ... - the table is longest first, so the waves that drew the full segments get the shortest leftovers.
-  // (Plain round-robin: a view has ~1.16 W groups, and the 485 groups of the second round went to the waves that
-  // already held the longest ones - the kernel ran 65 us for 47 us of mean load.  A shared ticket - one device-scope
-  // atomic per group on ONE address - serialised at the memory side of the fabric: ~10 ns each, 110 us per view.)
-  for (uint32_t rnd = 0, grp0 = 0; grp0 < ngroups; ++rnd, grp0 += gridDim.x) {
-    const uint32_t grp = grp0 + ((HGS_BWD_SNAKE && (rnd & 1u)) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
-    if (grp >= ngroups) continue;
+  // Persistent workgroups of HGS_BWD_BLOCK_WAVES waves (one per SIMD).  The group table is longest first; workgroup b
+  // owns groups b, 2 G - 1 - b, 2 G + b, ... (G workgroups; odd rounds run backwards, so every workgroup gets a
+  // similar total), and its waves DRAW them in that order through an LDS ticket: the wave that finishes first takes
+  // the next, the SIMDs of the CU end within one short group of each other.  (Static round-robin per wave: a view
+  // has ~1.16 groups per wave, the kernel ran 60 us for 47 us of mean load, a quarter of it with SIMDs running dry.
+  // A device-wide ticket - one device-scope atomic per group on ONE address - serialised at the memory side of the
+  // fabric: ~10 ns each, 110 us per view.)
+  auto group_of = [&](uint32_t tk) {
+    return tk * gridDim.x + ((HGS_BWD_SNAKE && (tk & 1u)) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+  };
+  // the item of the NEXT group is fetched while this one is processed (a group's start is a chain of dependent
+  // loads - item, cell list, records - at ~2 us each, and a view has more than one group per wave)
+  uint32_t grp = group_of((uint32_t)wv);
+  uint4 item;                                            // (cell key, entries, first cell-list slot, state slot or ~0)
+  bool have = fetch_item(v, L, 4u * grp + (uint32_t)j, n0, n1, n2, n3, item);
+  while (grp < ngroups) {                                // (every later ticket of this workgroup lies behind it as well)
+    uint32_t grp_next;
+    {
+      uint32_t t_next = 0;
+      if (lane == 0) t_next = atomicAdd(&s_ticket, 1u);  // (LDS)
+      grp_next = group_of((uint32_t)__builtin_amdgcn_readfirstlane((int)t_next));
+    }
 #ifdef HGS_TIMELINE
     tl_w0 = wall_clock64(); tl_nb = 0;
 #endif
-    uint2 item = make_uint2(0u, 0u);
-    const bool have = fetch_item(v, L, 4u * grp + (uint32_t)j, n0, n1, n2, n3, item);
-    const uint32_t key = item.x, seg = item.y & 0xffffffu;
-    uint32_t cnt = have ? (item.y >> 24) : 0u;
-    if (have && cnt == 0u) cnt = HGS_SEGLEN;
+    const uint32_t key = item.x, cnt = have ? item.y : 0u;
     const int g = (int)(key >> 4), c = (int)(key & 15u);
-    CellInfo ci;
-    ci.base = 0; ci.len = 0; ci.sbase = 0; ci.pbase = 0;
-    if (have) ci = L.cell_info[key];
     const int bview = g / v.T, t_ = g % v.T;
     const int cx0 = (t_ % v.grid_x) * HGS_TILE + (c & 3) * HGS_CELL, cy0 = (t_ / v.grid_x) * HGS_TILE + (c >> 2) * HGS_CELL;
     const int px = cx0 + (i & 3), py = cy0 + (i >> 2);
     const float pxf = (float)px, pyf = (float)py;
     const float cxq = (float)cx0 + 1.5f, cyq = (float)cy0 + 1.5f;      // cell centre
-    const uint32_t e0 = seg * HGS_SEGLEN;                              // cell-list rank of the item's first entry
-    const uint32_t tstart1 = have ? L.tile_start[g] - 1u : 0u;         // record index - tstart1 = 1-based position in the tile list
-    const uint2* __restrict__ list = L.cell_list + ci.base + e0;      // (record index, pair id)
+    const uint32_t tstart1 = L.tile_start[have ? g : 0] - 1u;         // record index - tstart1 = 1-based position in the tile list
+    const uint2* __restrict__ list = L.cell_list + (have ? item.z : 0u);      // (record index, pair id)
 
-    // per-pixel inputs
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f, ga = 0.f, fp = 0.f;
-    uint32_t nc = 0;
-    float T = 1.0f, F = 0.0f;
-    if (have && px < v.W && py < v.H) {
-      const size_t HW = (size_t)v.H * v.W, pix = (size_t)py * v.W + px;
-      const size_t o1 = (size_t)bview * HW, o3 = 3 * o1;
-      if (dL_dcolor) { g0 = dL_dcolor[o3 + pix]; g1 = dL_dcolor[o3 + HW + pix]; g2 = dL_dcolor[o3 + 2 * HW + pix]; }
-      if (dL_ddepth) gd = dL_ddepth[o1 + pix];
-      if (dL_dalpha) ga = dL_dalpha[o1 + pix];
-      fp = out_color[o3 + pix] * g0 + out_color[o3 + HW + pix] * g1 + out_color[o3 + 2 * HW + pix] * g2 +
-           out_depth[o1 + pix] * gd + out_alpha[o1 + pix] * ga;
-      nc = L.n_contrib[o1 + pix];
+    // ---- the group's start: ONE round of independent loads (cell list, per-pixel inputs, stored state - every one
+    // unconditional, from a clamped address, masked afterwards), then the first record gather.  (With the loads inside
+    // `if (inside)` blocks each block waited for its own data before the next one was issued: item -> pixels -> list ->
+    // records, four memory round trips of ~2 us in front of every group.)
+    const uint32_t safe_rec = tstart1 + 1u;              // the tile's first record (tile 0's for a row without item): always a valid slot
+    auto list_at = [&](uint32_t e) { return list[(e < cnt) ? e : 0u]; };
+    auto gather = [&](const uint2 le, bool valid, float4& r0, float4& r1, float4& r2) {
+      const uint32_t idx = valid ? le.x : safe_rec;
+      r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1];
+      const float4 t2 = recs[3 * (size_t)idx + 2];
+      r2 = make_float4(t2.x, t2.y, t2.z, __uint_as_float(valid ? idx - tstart1 : 0xffffffffu));   // .w: 1-based position in the tile list
+    };
+    float4 c0, c1, c2;
+    uint2 le_next = list_at((uint32_t)i);
+    const uint2 le_second = list_at(HGS_RB + (uint32_t)i);
+    const bool inside = have && px < v.W && py < v.H;
+    const bool has_state = inside && item.w != 0xffffffffu;
+    float g0, g1, g2, gd, ga, fp, T, F;
+    uint32_t nc;
+    {
+      const size_t HW = (size_t)v.H * v.W, pix = inside ? (size_t)py * v.W + px : 0;
+      const size_t o1 = inside ? (size_t)bview * HW : 0, o3 = 3 * o1;
+      const float* pc = dL_dcolor ? dL_dcolor : out_color;          // (absent gradient: any readable address, value masked)
+      const float* pd = dL_ddepth ? dL_ddepth : out_depth;
+      const float* pa = dL_dalpha ? dL_dalpha : out_alpha;
+      const float r_g0 = pc[o3 + pix], r_g1 = pc[o3 + HW + pix], r_g2 = pc[o3 + 2 * HW + pix];
+      const float r_gd = pd[o1 + pix], r_ga = pa[o1 + pix];
+      const float r_c0 = out_color[o3 + pix], r_c1 = out_color[o3 + HW + pix], r_c2 = out_color[o3 + 2 * HW + pix];
+      const float r_d = out_depth[o1 + pix], r_a = out_alpha[o1 + pix];
+      const uint32_t r_nc = L.n_contrib[o1 + pix];
       // running state at the item's first entry (used only by pixels that still contribute, see below)
-      if (seg > 0) {
-        const float* cs = cstate + (size_t)(ci.sbase + seg - 1) * HGS_CSTATE_FLOATS + i;
-        T = cs[0 * 16];
-        F = cs[1 * 16] * g0 + cs[2 * 16] * g1 + cs[3 * 16] * g2 + cs[4 * 16] * gd + cs[5 * 16] * ga;
-      }
+      const float* cs = cstate + (size_t)(has_state ? item.w : 0u) * HGS_CSTATE_FLOATS + i;
+      const float r_s0 = cs[0 * 16], r_s1 = cs[1 * 16], r_s2 = cs[2 * 16], r_s3 = cs[3 * 16], r_s4 = cs[4 * 16], r_s5 = cs[5 * 16];
+      // the first records go out before anything above is consumed
+      gather(le_next, (uint32_t)i < cnt, c0, c1, c2);
+      g0 = (inside && dL_dcolor) ? r_g0 : 0.0f; g1 = (inside && dL_dcolor) ? r_g1 : 0.0f; g2 = (inside && dL_dcolor) ? r_g2 : 0.0f;
+      gd = (inside && dL_ddepth) ? r_gd : 0.0f;
+      ga = (inside && dL_dalpha) ? r_ga : 0.0f;
+      fp = inside ? r_c0 * g0 + r_c1 * g1 + r_c2 * g2 + r_d * gd + r_a * ga : 0.0f;
+      nc = inside ? r_nc : 0u;
+      T = has_state ? r_s0 : 1.0f;
+      F = has_state ? r_s1 * g0 + r_s2 * g1 + r_s3 * g2 + r_s4 * gd + r_s5 * ga : 0.0f;
     }
     // ---- operand A of the gradient chain: the row's pixel gradients, transposed through LDS
     // (the k stage is free here: every batch of the previous group has been consumed)
@@ -185,19 +228,12 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     // predicated loads the compiler merged the loaded registers into the loop-carried ones right behind the load
     // (s_waitcnt vmcnt(1) two instructions after the gather: the whole memory latency exposed once per batch), and
     // with the index load last, the wait for it (vmcnt is in order) also waited for the gather and the row stores.
-    const uint32_t safe_rec = have ? tstart1 + 1u : 0u;  // the tile's first record: always a valid slot
-    auto list_at = [&](uint32_t e) { return list[(e < cnt) ? e : 0u]; };
-    auto gather = [&](const uint2 le, bool valid, float4& r0, float4& r1, float4& r2) {
-      const uint32_t idx = valid ? le.x : safe_rec;
-      r0 = recs[3 * (size_t)idx]; r1 = recs[3 * (size_t)idx + 1];
-      const float4 t2 = recs[3 * (size_t)idx + 2];
-      r2 = make_float4(t2.x, t2.y, t2.z, __uint_as_float(valid ? idx - tstart1 : 0xffffffffu));   // .w: 1-based position in the tile list
-    };
-    uint2 le_next = list_at((uint32_t)i);
     uint32_t pid_cur = le_next.y;                       // pair id of the lane's record of the current batch
-    float4 c0, c1, c2;
-    gather(le_next, (uint32_t)i < cnt, c0, c1, c2);
-    le_next = list_at(HGS_RB + (uint32_t)i);
+    le_next = le_second;
+    // (issued behind the first gather: the wait for that gather covers it; at the top of the group it sat in front of
+    // the setup's waits and its latency was exposed)
+    uint4 item_next;
+    const bool have_next = fetch_item(v, L, 4u * grp_next + (uint32_t)j, n0, n1, n2, n3, item_next);
     {
       // A pixel whose last contributor (n_contrib, a tile-list position) lies before the item's first record
       // finished before this item - its forward row may have stopped without storing the state - and is never active.
@@ -336,6 +372,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       o[0] = tl_w0; o[1] = wall_clock64(); o[2] = tl_nb; o[3] = (unsigned long long)(cnt) | 1ull << 63;
     }
 #endif
+    grp = grp_next; item = item_next; have = have_next;
   }
 }
 
