@@ -411,10 +411,34 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
     if (contiguous) {
       const float4* __restrict__ src = reinterpret_cast<const float4*>(pair_rows) + (size_t)base * HGS_GROW_F4;
       float4* __restrict__ sl = s_rows[w];
+      // double buffered through registers: the loads of tile t + 1 are in flight while tile t is summed (a wave has
+      // ~3 tiles; one after the other their load latency was most of the kernel's 20 us)
+      static_assert(HGS_RED_ROWS * HGS_GROW_F4 == 6 * 64, "six float4 per lane and tile");
+      float4 b0, b1, b2, b3, b4, b5;                   // (named registers: an array here went to scratch memory)
+      // (no branch around the loads: behind the last tile every lane re-reads element 0 - one cache line; a
+      // conditional block made the compiler wait for the loads where they are issued)
+#define HGS_RED_ISSUE(T0)                                                                                      \
+  {                                                                                                            \
+    const uint32_t t0n__ = (T0);                                                                               \
+    const bool any__ = t0n__ < total;                                                                          \
+    const uint32_t last__ = any__ ? min((uint32_t)HGS_RED_ROWS, total - t0n__) * HGS_GROW_F4 - 1u : 0u;        \
+    const float4* p__ = src + (any__ ? (size_t)t0n__ * HGS_GROW_F4 : 0);                                       \
+    b0 = p__[min((uint32_t)lane, last__)];        b1 = p__[min((uint32_t)lane + 64u, last__)];                 \
+    b2 = p__[min((uint32_t)lane + 128u, last__)]; b3 = p__[min((uint32_t)lane + 192u, last__)];                \
+    b4 = p__[min((uint32_t)lane + 256u, last__)]; b5 = p__[min((uint32_t)lane + 320u, last__)];                \
+  }
+      HGS_RED_ISSUE(0u);
       for (uint32_t t0 = 0; t0 < total; t0 += HGS_RED_ROWS) {
         const uint32_t nrow = min((uint32_t)HGS_RED_ROWS, total - t0);
+        const uint32_t nfl = nrow * HGS_GROW_F4;
         __builtin_amdgcn_wave_barrier();               // the previous tile's LDS reads are done
-        for (uint32_t f = (uint32_t)lane; f < nrow * HGS_GROW_F4; f += 64u) sl[f] = src[(size_t)t0 * HGS_GROW_F4 + f];
+        if ((uint32_t)lane < nfl) sl[lane] = b0;
+        if ((uint32_t)lane + 64u < nfl) sl[lane + 64] = b1;
+        if ((uint32_t)lane + 128u < nfl) sl[lane + 128] = b2;
+        if ((uint32_t)lane + 192u < nfl) sl[lane + 192] = b3;
+        if ((uint32_t)lane + 256u < nfl) sl[lane + 256] = b4;
+        if ((uint32_t)lane + 320u < nfl) sl[lane + 320] = b5;
+        HGS_RED_ISSUE(t0 + HGS_RED_ROWS);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t r_begin = max(off, t0), r_end = min(off + cnt, t0 + nrow);
