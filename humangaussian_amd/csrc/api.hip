@@ -279,7 +279,7 @@ size_t hgs_img_bytes_batch(int32_t B, int32_t H, int32_t W) {
 size_t hgs_img_bytes(int32_t H, int32_t W) { return hgs_img_bytes_batch(1, H, W); }
 // one gradient row per entry + one per (entry, cell) pair
 size_t hgs_bwd_scratch_bytes(int64_t R) {
-  return hgs_align_up((size_t)(R > 0 ? R : 0) * (1 + HGS_PAIRS_PER_ENTRY) * HGS_ROW_FLOATS * sizeof(float), ALIGN);
+  return hgs_align_up((size_t)(R > 0 ? R : 0) * (HGS_ROW_FLOATS + HGS_PAIRS_PER_ENTRY * HGS_PROW_FLOATS) * sizeof(float), ALIGN);
 }
 
 int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
@@ -476,7 +476,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
                                const_cast<void*>(img), B, P, v.H, v.W, cap);
   const hgs_status* status_dev = reinterpret_cast<const hgs_status*>(
       static_cast<const char*>(geom) + carve_geom(B, P, v.H, v.W).status);
-  // gradient rows: [X entries][12] then the pair rows [16 X][12], X = what the caller sized the scratch by
+  // gradient rows: [X entries][12] then the pair rows [16 X][10], X = what the caller sized the scratch by
   const int64_t X = status ? (int64_t)status->num_rendered : cap;
   float* rows = static_cast<float*>(bwd_scratch);
   float* pair_rows = rows + (size_t)X * HGS_ROW_FLOATS;

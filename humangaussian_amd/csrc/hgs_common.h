@@ -21,7 +21,7 @@
 //   uint32   chunk_sums/base[B*P/256]  entry-id ranges of the 256-Gaussian chunks
 //   Counters ctr                 bump allocators, class histogram, tickets
 //   hgs_status                                  img buffer:  uint32 n_contrib[B][H*W]
-//                                               bwd scratch: float grad_rows[R][12], pair_rows[16R][12]
+//                                               bwd scratch: float grad_rows[R][12], pair_rows[16R][10]
 //
 // A 16x16 tile is cut into 16 CELLS of 4x4 pixels.  The sort kernel gives every entry a 16-bit cell
 // mask (cellmask.h: the exact ellipse-vs-rectangle test of alpha >= 1/255) and writes, per tile, 16
@@ -66,6 +66,8 @@
 #define HGS_ROW_FLOATS 12                       // gradient row per entry / per (entry, cell) pair (10 used); 64 B rows
 #endif                                          // (whole ECC granules per scattered store) measured slower: the rows are bandwidth
 #define HGS_GROW_F4 (HGS_ROW_FLOATS / 4)          // float4 per gradient row
+#define HGS_PROW_FLOATS 10                      // (entry, cell) pair row: the ten sums, packed (40 B: a sixth less pair traffic than 48 B)
+#define HGS_PROW_F2 (HGS_PROW_FLOATS / 2)         // float2 per pair row
 #define HGS_NCLS 33                             // tile classes by log2(list length); class 0 = empty
 #define HGS_NFC 11                              // length classes of the non-empty cells (forward work items)
 

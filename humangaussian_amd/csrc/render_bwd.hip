@@ -27,16 +27,16 @@
 //   A: lane l supplies basis_{l & 3}(pixel t)  (for the gradient chain: g_{l & 3} at pixel t of cell l >> 4).
 // Three chains (A = {1, u, v, u^2} x k; {uv, v^2} x k; {g_C0, g_C1, g_C2, g_D} x wgt), 16 instructions of 8 cycles
 // each.  The accumulator layout puts ALL TEN sums of (cell, record n) into lane 16 cell + n - the lane that
-// gathered that record - so the moment -> gradient conversion and the 48 B pair row need no shuffles.
+// gathered that record - so the moment -> gradient conversion and the 40 B pair row need no shuffles.
 // (First version: v_mfma_f32_16x16x4_f32 with a block-diagonal A - K slot = cell - to get the same layout: three
 // quarters of its 32 cycles multiplied zeros, and the matrix pipe was 40 % of the kernel's issue time.)
 //
 // An (entry, cell) pair row lands at the pair's id (entry-major); hgs_k_pair_reduce adds the pair rows of
 // every entry in cell order (fixed order: no atomics, bitwise reproducible) into one 48 B gradient row per
-// entry, which hgs_k_preprocess_bwd sums per Gaussian.
+// entry, which hgs_k_preprocess_bwd sums per Gaussian.  Pair rows are 40 B (the ten sums, packed).
 //
 // Roofline: VALU issue (~35 instructions per row iteration) beside the MFMA pipe (3 x 8 cycles per
-// iteration); HBM traffic per (entry, cell) pair: 4 B index + 48 B record gather (L2-served), 48 B pair row
+// iteration); HBM traffic per (entry, cell) pair: 4 B index + 48 B record gather (L2-served), 40 B pair row
 // out, 24 B/pixel state per 128 pairs in.
 //
 // This file is its own translation unit (it compiles in parallel with api.hip; same flags).
@@ -260,13 +260,12 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float x1 = __builtin_fmaf(pqb, sdx, (pqc + pqc) * sdy);
       const float il = 1.0f / HGS_LOG2E;
       const float opi = (pop != 0.0f) ? 1.0f / pop : 0.0f;
-      float4* row = reinterpret_cast<float4*>(pair_rows + (size_t)ppid * HGS_ROW_FLOATS);
-      row[0] = make_float4(x0 * il, x1 * il, sxx * -0.5f, sxy * -1.0f);
-      row[1] = make_float4(syy * -0.5f, k00 * opi, a3[0], a3[1]);
-      row[2] = make_float4(a3[2], a3[3], 0.0f, 0.0f);
-#if HGS_GROW_F4 > 3
-      row[3] = make_float4(0.f, 0.f, 0.f, 0.f);          // (the whole 64 B granule is written: no read-modify-write at the memory side)
-#endif
+      float2* row = reinterpret_cast<float2*>(pair_rows + (size_t)ppid * HGS_PROW_FLOATS);      // (40 B rows: 8 B aligned)
+      row[0] = make_float2(x0 * il, x1 * il);
+      row[1] = make_float2(sxx * -0.5f, sxy * -1.0f);
+      row[2] = make_float2(syy * -0.5f, k00 * opi);
+      row[3] = make_float2(a3[0], a3[1]);
+      row[4] = make_float2(a3[2], a3[3]);
     };
     for (uint32_t it0 = 0; it0 < maxcnt; it0 += HGS_RB) {
 #ifdef HGS_TIMELINE
@@ -291,11 +290,9 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         // nothing contributes any more (every pixel terminated before): zero pair rows, no evaluation
         if (pending) { asm volatile("" : "+a"(pa1), "+a"(pa2), "+a"(pa3)); finish(pa1, pa2, pa3, pit); pending = false; }
         if (it0 + (uint32_t)i < cnt) {
-          float4* row = reinterpret_cast<float4*>(pair_rows + (size_t)pid_this * HGS_ROW_FLOATS);
-          row[0] = zero4; row[1] = zero4; row[2] = zero4;
-#if HGS_GROW_F4 > 3
-          row[3] = zero4;
-#endif
+          float2* row = reinterpret_cast<float2*>(pair_rows + (size_t)pid_this * HGS_PROW_FLOATS);
+          const float2 zero2 = make_float2(0.f, 0.f);
+          row[0] = zero2; row[1] = zero2; row[2] = zero2; row[3] = zero2; row[4] = zero2;
         }
         continue;
       }
@@ -379,7 +376,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 // ------------------------------------------------------------------------------ pair reduction
 // One gradient row per tile entry = the sum of the entry's (entry, cell) pair rows, cells in ascending order
 // (deterministic).  A wave64 takes 64 consecutive entries; pair ids are entry-major, so their pair rows are ONE
-// contiguous range (inside a tile): the wave streams it through LDS with fully coalesced 16 B loads, 128 rows at a
+// contiguous range (inside a tile): the wave streams it through LDS with fully coalesced 8 B loads, 128 rows at a
 // time, and every lane (= entry) then adds its own rows from LDS in order.  (Per-thread row loads - 48 B at a
 // stride of ~170 B per lane - reached 3 TB/s; at 8 views the 456 MB of pair rows made this the second-largest
 // kernel of the step.)  A wave whose entries straddle two tiles (pair ranges apart) takes the per-thread path.
@@ -387,7 +384,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
                   const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
-  __shared__ float4 s_rows[4][HGS_RED_ROWS * HGS_GROW_F4];
+  __shared__ float2 s_rows[4][HGS_RED_ROWS * HGS_PROW_F2];
   if (status->overflow) return;
   const uint32_t R = status->num_rendered;
   const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
@@ -399,9 +396,7 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
   const uint32_t entry = ep.x & 0x7ffffffu, cnt = ep.x >> 27;
   const uint32_t incl = hgs_wave_incl_scan(cnt), off = incl - cnt;
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 s0 = zero4, s1 = zero4;
-  float2 s2 = make_float2(0.f, 0.f);
+  float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
   // contiguous?  every entry with pairs must sit at (first pair of the wave) + (pairs of the lanes before it)
   const unsigned long long withp = __ballot(cnt != 0u);
   if (withp != 0ull) {
@@ -409,28 +404,30 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
     const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(ep.y - off), first);
     const bool contiguous = __ballot(cnt != 0u && ep.y - off != base) == 0ull;
     if (contiguous) {
-      const float4* __restrict__ src = reinterpret_cast<const float4*>(pair_rows) + (size_t)base * HGS_GROW_F4;
-      float4* __restrict__ sl = s_rows[w];
+      const float2* __restrict__ src = reinterpret_cast<const float2*>(pair_rows) + (size_t)base * HGS_PROW_F2;
+      float2* __restrict__ sl = s_rows[w];
       // double buffered through registers: the loads of tile t + 1 are in flight while tile t is summed (a wave has
       // ~3 tiles; one after the other their load latency was most of the kernel's 20 us)
-      static_assert(HGS_RED_ROWS * HGS_GROW_F4 == 6 * 64, "six float4 per lane and tile");
-      float4 b0, b1, b2, b3, b4, b5;                   // (named registers: an array here went to scratch memory)
+      static_assert(HGS_RED_ROWS * HGS_PROW_F2 == 10 * 64, "ten float2 per lane and tile");
+      float2 b0, b1, b2, b3, b4, b5, b6, b7, b8, b9;   // (named registers: an array here went to scratch memory)
       // (no branch around the loads: behind the last tile every lane re-reads element 0 - one cache line; a
       // conditional block made the compiler wait for the loads where they are issued)
 #define HGS_RED_ISSUE(T0)                                                                                      \
   {                                                                                                            \
     const uint32_t t0n__ = (T0);                                                                               \
     const bool any__ = t0n__ < total;                                                                          \
-    const uint32_t last__ = any__ ? min((uint32_t)HGS_RED_ROWS, total - t0n__) * HGS_GROW_F4 - 1u : 0u;        \
-    const float4* p__ = src + (any__ ? (size_t)t0n__ * HGS_GROW_F4 : 0);                                       \
+    const uint32_t last__ = any__ ? min((uint32_t)HGS_RED_ROWS, total - t0n__) * HGS_PROW_F2 - 1u : 0u;        \
+    const float2* p__ = src + (any__ ? (size_t)t0n__ * HGS_PROW_F2 : 0);                                       \
     b0 = p__[min((uint32_t)lane, last__)];        b1 = p__[min((uint32_t)lane + 64u, last__)];                 \
     b2 = p__[min((uint32_t)lane + 128u, last__)]; b3 = p__[min((uint32_t)lane + 192u, last__)];                \
     b4 = p__[min((uint32_t)lane + 256u, last__)]; b5 = p__[min((uint32_t)lane + 320u, last__)];                \
+    b6 = p__[min((uint32_t)lane + 384u, last__)]; b7 = p__[min((uint32_t)lane + 448u, last__)];                \
+    b8 = p__[min((uint32_t)lane + 512u, last__)]; b9 = p__[min((uint32_t)lane + 576u, last__)];                \
   }
       HGS_RED_ISSUE(0u);
       for (uint32_t t0 = 0; t0 < total; t0 += HGS_RED_ROWS) {
         const uint32_t nrow = min((uint32_t)HGS_RED_ROWS, total - t0);
-        const uint32_t nfl = nrow * HGS_GROW_F4;
+        const uint32_t nfl = nrow * HGS_PROW_F2;
         __builtin_amdgcn_wave_barrier();               // the previous tile's LDS reads are done
         if ((uint32_t)lane < nfl) sl[lane] = b0;
         if ((uint32_t)lane + 64u < nfl) sl[lane + 64] = b1;
@@ -438,34 +435,37 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
         if ((uint32_t)lane + 192u < nfl) sl[lane + 192] = b3;
         if ((uint32_t)lane + 256u < nfl) sl[lane + 256] = b4;
         if ((uint32_t)lane + 320u < nfl) sl[lane + 320] = b5;
+        if ((uint32_t)lane + 384u < nfl) sl[lane + 384] = b6;
+        if ((uint32_t)lane + 448u < nfl) sl[lane + 448] = b7;
+        if ((uint32_t)lane + 512u < nfl) sl[lane + 512] = b8;
+        if ((uint32_t)lane + 576u < nfl) sl[lane + 576] = b9;
         HGS_RED_ISSUE(t0 + HGS_RED_ROWS);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t r_begin = max(off, t0), r_end = min(off + cnt, t0 + nrow);
         for (uint32_t r = r_begin; r < r_end; ++r) {
-          const float4 a = sl[HGS_GROW_F4 * (r - t0) + 0], b = sl[HGS_GROW_F4 * (r - t0) + 1];
-          const float2 c = *reinterpret_cast<const float2*>(&sl[HGS_GROW_F4 * (r - t0) + 2]);
-          s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-          s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-          s2.x += c.x; s2.y += c.y;
+          const float2* q = sl + HGS_PROW_F2 * (r - t0);
+          const float2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+          s0.x += a0.x; s0.y += a0.y; s1.x += a1.x; s1.y += a1.y; s2.x += a2.x; s2.y += a2.y;
+          s3.x += a3.x; s3.y += a3.y; s4.x += a4.x; s4.y += a4.y;
         }
       }
     } else {
-      const float4* __restrict__ rows = reinterpret_cast<const float4*>(pair_rows) + (size_t)ep.y * HGS_GROW_F4;
+      const float2* __restrict__ rows = reinterpret_cast<const float2*>(pair_rows) + (size_t)ep.y * HGS_PROW_F2;
       for (uint32_t r = 0; r < cnt; ++r) {
-        const float4 a = rows[HGS_GROW_F4 * r], b = rows[HGS_GROW_F4 * r + 1];
-        const float2 c = *reinterpret_cast<const float2*>(&rows[HGS_GROW_F4 * r + 2]);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-        s2.x += c.x; s2.y += c.y;
+        const float2* q = rows + HGS_PROW_F2 * r;
+        const float2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+        s0.x += a0.x; s0.y += a0.y; s1.x += a1.x; s1.y += a1.y; s2.x += a2.x; s2.y += a2.y;
+        s3.x += a3.x; s3.y += a3.y; s4.x += a4.x; s4.y += a4.y;
       }
     }
   }
   if (have) {
     float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
-    dst[0] = s0; dst[1] = s1; dst[2] = make_float4(s2.x, s2.y, 0.0f, 0.0f);
+    dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
+    dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
 #if HGS_GROW_F4 > 3
-    dst[3] = zero4;
+    dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
   }
 }
