@@ -120,7 +120,8 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   unsigned long long tl_w0 = 0;
   uint32_t tl_nb = 0;
 #endif
-  // Persistent workgroups of HGS_BWD_BLOCK_WAVES waves (one per SIMD).  The group table is longest first; workgroup b
+  // Persistent workgroups of HGS_BWD_BLOCK_WAVES waves (12: one workgroup per CU, three waves per SIMD).  The group
+  // table is longest first; workgroup b
   // owns groups b, 2 G - 1 - b, 2 G + b, ... (G workgroups; odd rounds run backwards, so every workgroup gets a
   // similar total), and its waves DRAW them in that order through an LDS ticket: the wave that finishes first takes
   // the next, the SIMDs of the CU end within one short group of each other.  (Static round-robin per wave: a view

@@ -261,7 +261,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     // three such byte tensors for its backward); a capacity retry re-allocates only the last two
     const int64_t g_sz = al256(hgs_geom_bytes_batch((int32_t)B, (int32_t)P, (int32_t)H, (int32_t)W));
     const int64_t i_sz = al256(hgs_img_bytes_batch((int32_t)B, (int32_t)H, (int32_t)W));
-    // (the backward's pair rows - 16 x 48 B per entry - are allocated by backward() for its own duration: they would
+    // (the backward's pair rows - 16 x 40 B per entry - are allocated by backward() for its own duration: they would
     // otherwise be held by every view of a step until its backward runs)
     int64_t b_sz = al256(hgs_bin_bytes(cap));
     const int64_t s_sz = 0;

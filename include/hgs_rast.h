@@ -74,7 +74,7 @@ typedef struct hgs_status {
  * rasterize_gaussians() drives through torch.  geom: per-Gaussian + per-tile state;
  * bin: per-(tile,Gaussian) entry state, sized by entry_capacity; img: per-pixel state;
  * bwd_scratch: gradient rows per entry and per (entry, 4x4-pixel cell) pair, used only inside
- * hgs_backward (17 x 48 B per entry). */
+ * hgs_backward (48 + 16 x 40 B per entry). */
 size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t hgs_bin_bytes(int64_t entry_capacity);
 size_t hgs_img_bytes(int32_t image_height, int32_t image_width);
