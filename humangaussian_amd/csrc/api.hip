@@ -105,7 +105,7 @@ BinCarve carve_bin(int64_t cap) {
   c.recs = take(C * sizeof(SortRec));
   c.cell_list = take(NP * 8);
   c.entpair = take(C * 8);
-  // a cell list of len entries has ceil(len / 64) - 1 stored states and ceil(len / 64) work items, len / 64 of them full
+  // a cell list of len entries has ceil(len / HGS_SEGLEN) - 1 stored states and ceil(len / HGS_SEGLEN) work items, len / HGS_SEGLEN of them full
   c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
   c.items_full = take((NP / HGS_SEGLEN + 1) * sizeof(uint4));
   c.total = off;
