@@ -48,7 +48,9 @@ def test_buffer_sizing(lib):
     b1, b2 = lib.hgs_bin_bytes(1 << 20), lib.hgs_bin_bytes(1 << 21)
     assert b1 >= (1 << 20) * (8 + 48 + 96) and abs(b2 - 2 * b1) <= 65536
     assert lib.hgs_bin_bytes(0) <= 65536          # only the fixed part of the segment planes
-    assert lib.hgs_bwd_scratch_bytes(1000) >= 48000
+    # backward scratch (include/hgs_rast.h): one 48 B gradient row per entry + 16 (entry, cell) pair rows of 40 B
+    assert lib.hgs_bwd_scratch_bytes(1000) == -(-1000 * (48 + 16 * 40) // 256) * 256
+    assert lib.hgs_bwd_scratch_bytes(0) == 0 and lib.hgs_bwd_scratch_bytes(-5) == 0
 
 
 def test_argument_validation_without_gpu(lib):
@@ -101,3 +103,28 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_backward_group_schedule_visits_every_group_once():
+    """Host-side restatement of render_bwd.hip's group_of(): workgroup b of G draws tickets 0, 1, 2, ... and ticket t
+    maps to group t * G + (b, or G - 1 - b on odd t).  Every group of the table must be owned by exactly one
+    (workgroup, ticket), a workgroup's groups must ascend with the ticket (so it may stop at the first one beyond the
+    table), and the snake must give every workgroup the same number of groups +- 1."""
+    for G, ngroups in ((1, 7), (4, 4), (256, 3557), (256, 28000), (12, 5), (64, 0)):
+        seen, per_wg = set(), []
+        for b in range(G):
+            mine, t = [], 0
+            while True:
+                grp = t * G + ((G - 1 - b) if (t & 1) else b)
+                if grp >= ngroups:
+                    # nothing later may fall inside the table
+                    assert all(tt * G + ((G - 1 - b) if (tt & 1) else b) >= ngroups for tt in range(t + 1, t + 4))
+                    break
+                mine.append(grp)
+                t += 1
+            assert mine == sorted(mine)
+            assert not (seen & set(mine))
+            seen |= set(mine)
+            per_wg.append(len(mine))
+        assert seen == set(range(ngroups))
+        assert max(per_wg) - min(per_wg) <= 1
