@@ -367,7 +367,10 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #ifdef HGS_TIMELINE
     if (lane == 0) {
       unsigned long long* o = L.keys + (size_t)grp * 4;
-      o[0] = tl_w0; o[1] = wall_clock64(); o[2] = tl_nb; o[3] = (unsigned long long)(cnt) | 1ull << 63;
+      // (physical SIMD: XCC id and the SE / SH / CU / SIMD fields of HW_ID, for the per-SIMD balance in tools/timeline.py)
+      const unsigned long long simd_key = ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) << 16) |
+                                          (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff30u);
+      o[0] = tl_w0; o[1] = wall_clock64(); o[2] = tl_nb; o[3] = (unsigned long long)(cnt) | (simd_key << 8) | 1ull << 63;
     }
 #endif
     grp = grp_next; item = item_next; have = have_next;

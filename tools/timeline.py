@@ -48,6 +48,19 @@ assert rc.forward() == 0
 torch.cuda.synchronize()
 
 
+def simd_balance(key, dur, en, what):
+    """Per PHYSICAL SIMD (XCC id + SE / SH / CU / SIMD fields of HW_ID): how many waves / groups it ran, their summed
+    time and when its last one ended - the placement the work tables assume (heavy + light mix per SIMD) made visible."""
+    uniq, inv = np.unique(key, return_inverse=True)
+    cnt = np.bincount(inv)
+    load = np.bincount(inv, weights=dur)
+    last = np.zeros(len(uniq))
+    np.maximum.at(last, inv, en)
+    pc = lambda x: " / ".join("%.1f" % np.percentile(x, q) for q in (0, 10, 50, 90, 100))
+    print(f"  physical SIMDs seen: {len(uniq)}; {what} per SIMD min/p10/p50/p90/max: {pc(cnt)}; summed time per SIMD (us): {pc(load)}; "
+          f"last end per SIMD (us): {pc(last)}")
+
+
 def waves(kid, name):
     tm = read(kid)
     slot = np.nonzero(tm[:, 0])[0]
@@ -63,6 +76,7 @@ def waves(kid, name):
     edges = np.linspace(0, span, nb + 1)
     occ = [float(np.clip(np.minimum(en, b) - np.maximum(st, a), 0, None).sum() / (b - a) / 1024) for a, b in zip(edges[:-1], edges[1:])]
     print("resident waves per SIMD over time (%d bins of %.1f us):" % (nb, span / nb), " ".join("%.2f" % o for o in occ))
+    simd_balance(((tm[:, 2] >> 32) & 0xf) << 16 | (tm[:, 2] & 0xff30), dur, en, "waves")
     order = np.argsort(-en)[:8]
     print("last waves to finish (slot, start, dur, tag):", [(int(slot[i]), round(float(st[i]), 1), round(float(dur[i]), 1), int(tag[i])) for i in order])
     for lo, hi in ((0, 1), (1, 64), (64, 256), (256, 512), (512, 1024), (1024, 1 << 31)):
@@ -109,6 +123,7 @@ span = en.max()
 edges = np.linspace(0, span, 17)
 occ = [float(np.clip(np.minimum(en, b) - np.maximum(st, a), 0, None).sum() / (b - a) / 1024) for a, b in zip(edges[:-1], edges[1:])]
 print("groups in flight per SIMD over time:", " ".join("%.2f" % o for o in occ))
+simd_balance((tm[:, 3] >> 8) & 0xfffff, dur, en, "groups")
 for k in (4, 3, 2, 1):
     m = nb == k
     if m.any():
