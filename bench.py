@@ -256,15 +256,21 @@ def main():
     # ---------------- host/GPU balance (outside the timed region): time the host spends blocked
     # in the one event wait per forward.  wait ~ 0 means the loop is host-bound.
     nhost = 50
-    w0 = _rast._state(dev).wait_ns
+    st0 = _rast._state(dev)
+    w0 = st0.wait_ns
     th = time.perf_counter()
     for _ in range(nhost):
         main_wl.step()
     torch.cuda.synchronize()
     th = time.perf_counter() - th
     st_now = _rast._state(dev)
+    hb = {k: round((st_now.host_ns[k] - st0.host_ns[k]) / nhost * 1e-3, 1) for k in st_now.host_ns}
     host_info = {"step_us": round(th / nhost * 1e6, 1),
                  "event_wait_us": round((st_now.wait_ns - w0) / nhost * 1e-3, 1),
+                 # inside the binding (us per step): forward = pre (checks, allocations) + launch (hgs_forward: 5 kernel
+                 # launches) + shadow (autograd state, gradient tensors) + wait (status poll) + rest; backward likewise;
+                 # step_us - fwd_total - bwd_total = Python, the autograd engine and its thread hand-off
+                 "binding_us": hb,
                  "forward_retries_total": int(st_now.retries), "forward_calls_total": int(st_now.calls)}
 
     # ---------------- host/GPU balance etc. follow below

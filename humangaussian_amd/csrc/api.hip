@@ -1,5 +1,6 @@
 // api.hip - host side of the C ABI declared in include/hgs_rast.h: buffer carving and the
-// launch sequences.  No allocation, no host synchronisation, no global state.
+// launch sequences.  No allocation, no host synchronisation; the only process-wide state is a per-device cache of
+// the CU count (read-only after its first use, filled under a mutex).
 //
 // Forward launch chain (one stream, no host round trip), for all B views of a call at once:
 //   preprocess_fwd -> tiles -> fill (+ tile order) [status published] -> sort_{huge,large,lds} (+ cell lists,
@@ -8,6 +9,8 @@
 #include "hgs_common.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 
 // The forward kernels and the per-Gaussian backward are included here (one translation
 // unit, SLP vectorisation on: the forward blend is latency-bound and profits from v_pk_*).
@@ -28,10 +31,29 @@ extern "C" __global__ void hgs_k_pair_reduce(View, Layout, const hgs_status*, co
 
 namespace {
 
-#ifndef HGS_SORT_256_MIN_VIEWS
-#define HGS_SORT_256_MIN_VIEWS 3   // calls with at least this many views use the throughput-shaped kernel variants:
-                                   // 256-thread sort workgroups (binning.hip), blend unroll 2 (render_fwd.hip)
+// Experiment knobs (tools/abenv.sh) exist only in -DHGS_KNOBS builds; the product library never reads the environment.
+#ifdef HGS_KNOBS
+inline int hgs_knob(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
+#else
+inline int hgs_knob(const char*, int dflt) { return dflt; }
 #endif
+
+// CUs of the device `stream` belongs to (persistent grids are sized by it).  Cached per device; the stream's device,
+// not the thread's current one.
+inline int cu_count(hipStream_t stream) {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipStreamGetDevice(stream, &dev) != hipSuccess) {
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+  }
+  if (dev < 0 || dev >= 64) return 256;
+  int c = cache[dev].load(std::memory_order_relaxed);
+  if (c > 0) return c;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
 #ifndef HGS_PRE_BWD_VPAR_MIN_VIEWS
 #define HGS_PRE_BWD_VPAR_MIN_VIEWS 2   // calls with at least this many views run the per-Gaussian backward with one thread per
 #endif                                 // (Gaussian, view); fewer: one thread per Gaussian
@@ -47,7 +69,7 @@ constexpr int HGS_MAX_BIN_WGS_PER_VIEW = HGS_BIN_WGS_PER_VIEW_MAX;
 constexpr int HGS_BIN_WGS_TOTAL = HGS_BIN_WGS_TOTAL_MAX;      // binning workgroups of a batch (all views)
 
 struct GeomCarve {
-  size_t geom, tile_n, tile_start, tile_order, cell_info, items_part, fwd_cells,
+  size_t geom, tile_n, tile_start, tile_order, tile_rec, cell_info, items_part, fwd_cells,
       hist, tile_gbase, tile_count, chunk_sums, chunk_base, ctr, status, total;
 };
 
@@ -77,6 +99,7 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   c.tile_n = take(TT * 4);
   c.tile_start = take(TT * 4);
   c.tile_order = take(TT * 4);
+  c.tile_rec = take(TT * 16);
   c.cell_info = take(TT * 16 * sizeof(CellInfo));
   c.items_part = take(2 * 16 * TT * sizeof(uint4));      // last (partial) segment of every cell list, by length class
   c.fwd_cells = take((size_t)HGS_NFC * 16 * TT * 4);       // non-empty cells by length class
@@ -122,6 +145,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.tile_n = reinterpret_cast<uint32_t*>(gp + g.tile_n);
   L.tile_start = reinterpret_cast<uint32_t*>(gp + g.tile_start);
   L.tile_order = reinterpret_cast<uint32_t*>(gp + g.tile_order);
+  L.tile_rec = reinterpret_cast<uint4*>(gp + g.tile_rec);
   L.cell_info = reinterpret_cast<CellInfo*>(gp + g.cell_info);
   L.items_part = reinterpret_cast<uint4*>(gp + g.items_part);
   L.fwd_cells = reinterpret_cast<uint32_t*>(gp + g.fwd_cells);
@@ -304,7 +328,10 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     if (entry_capacity > 0 && !bin) return HGS_EINVAL;
     if ((int64_t)B * P >= (1ll << 31) || P >= (1 << 28)) return HGS_EINVAL;
   }
+  // entry ids travel in 27 bits (entpair.x = entry | pairs << 27): a larger list cannot be addressed
+  if (entry_capacity > HGS_MAX_ENTRY_CAPACITY) return HGS_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int ncu = cu_count(stream);
   const View v = make_view(s, B, P, M, entry_capacity, max_tile_entries_hint > 0 ? max_tile_entries_hint : 0,
                            activation_flags);
   const Layout L = make_layout(geom, bin, img, B, P, v.H, v.W, entry_capacity);
@@ -379,11 +406,9 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
       hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
       HGS_LAUNCH_CHECK();
     }
-    static const int sort_force = getenv("HGS_SORT_SHAPE") ? atoi(getenv("HGS_SORT_SHAPE")) : 0;     // (experiments: 256 / 512)
-    if (sort_force == 256 || (sort_force != 512 && v.B >= HGS_SORT_256_MIN_VIEWS))
-      hipLaunchKernelGGL(hgs_k_sort_lds_256, dim3(class_grid(1)), dim3(256), 0, stream, v, L, status_dev);
-    else
-      hipLaunchKernelGGL(hgs_k_sort_lds, dim3(class_grid(1)), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
+    // persistent workgroups (53 KB of LDS: three per CU), tiles heavy first round-robin
+    const unsigned sort_wgs = std::min<unsigned>(class_grid(1), (unsigned)(hgs_knob("HGS_SORT_WGS_PER_CU", 3) * ncu));
+    hipLaunchKernelGGL(hgs_k_sort_lds, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
   } else {
     HGS_STAGE(3);
@@ -394,16 +419,9 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
   {
     // persistent cell waves: enough to fill the chip (4 waves per block; 4 blocks per CU), never more than the cells
     const int64_t cells = std::min<int64_t>((int64_t)16 * v.TT, (int64_t)HGS_PAIRS_PER_ENTRY * entry_capacity);
-    static int fwd_blocks = 0;
-    if (fwd_blocks == 0) {
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-        cus = 256;
-      int per_cu = 4;
-      if (const char* e = getenv("HGS_FWD_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;     // (experiments)
-      fwd_blocks = per_cu * cus;
-    }
-    const unsigned cell_blocks = (unsigned)std::min<int64_t>(fwd_blocks, (cells + 3) / 4);
+    // (the snake schedule of hgs_k_render_fwd visits every item only when the block count is a multiple of 4)
+    const int64_t fwd_blocks = (int64_t)hgs_knob("HGS_FWD_BLOCKS_PER_CU", 4) * ncu;
+    const unsigned cell_blocks = (unsigned)std::max<int64_t>(4, std::min<int64_t>(fwd_blocks, (cells + 3) / 4) & ~int64_t(3));
     if (store_bwd_state)
       hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(cell_blocks + v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
                          status_dev, L.recs, L.cstate, out_color, out_depth, out_alpha);
@@ -458,7 +476,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   (void)radii;
   if (activation_flags & ~7) return HGS_EINVAL;
   if ((activation_flags & HGS_ACT_OPACITY_SIGMOID) && P > 0 && !opacities) return HGS_EINVAL;
-  if (!batch_ok(s, B) || P < 0 || !geom || !img || entry_capacity < 0) return HGS_EINVAL;
+  if (!batch_ok(s, B) || P < 0 || !geom || !img || entry_capacity < 0 || entry_capacity > HGS_MAX_ENTRY_CAPACITY) return HGS_EINVAL;
   if (status && status->overflow) return HGS_EINVAL;
   if (status && (int64_t)status->reserved[0] != entry_capacity) return HGS_EINVAL;
   if (P == 0) return HGS_OK;
@@ -484,16 +502,8 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   if (maybe_entries) {
     // persistent workgroups of HGS_BWD_BLOCK_WAVES waves: as many waves as the chip holds (LDS: 11.8 KB per wave =>
     // 12 per CU, 3 per SIMD); the waves of a workgroup draw its groups of four work items through an LDS ticket
-    static int resident = 0;
-    if (resident == 0) {
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-        cus = 256;
-      int per_cu = 12;
-      if (const char* e = getenv("HGS_BWD_WAVES_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;     // (experiments)
-      resident = per_cu * cus;
-    }
-    hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)(resident / HGS_BWD_BLOCK_WAVES)), dim3(64 * HGS_BWD_BLOCK_WAVES), 0, stream, v, L, status_dev, L.recs, L.cstate,
+    const int resident = hgs_knob("HGS_BWD_WAVES_PER_CU", 12) * cu_count(stream);
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)std::max(1, resident / HGS_BWD_BLOCK_WAVES)), dim3(64 * HGS_BWD_BLOCK_WAVES), 0, stream, v, L, status_dev, L.recs, L.cstate,
                        out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows);
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);

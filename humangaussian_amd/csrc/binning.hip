@@ -184,6 +184,7 @@ __device__ __forceinline__ void place_tiles(const View& v, const Layout& L, int 
     pos = cls_base[c] + atomicAdd(&L.ctr->cls_cur[c], 1u);
   }
   L.tile_order[pos] = (uint32_t)g;
+  L.tile_rec[pos] = make_uint4((uint32_t)g, n, L.tile_start[g], 0u);      // what a sort workgroup needs to start, in one load
 }
 
 extern "C" __global__ void __launch_bounds__(HGS_BLOCK)
@@ -245,70 +246,90 @@ hgs_k_fill_ga(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __r
 namespace {
 
 // Ranges of one tile, from the lengths of its 16 cell lists: pairs (= cell-list slots), cell states, work items.
-// Wave 0 of the workgroup, lane c = cell c.  Writes cell_info, the items, cell_base[] and pair_base (LDS).
+// Wave 0 of the workgroup, lane c = cell c.  Two halves: `issue` sends the bump allocation (ONE atomic instruction,
+// lanes 0..2 + one per forward class on 64-bit counters: a device-scope atomic is a ~2 us trip to the memory side of
+// the fabric, five of them in a row were 13 us of every tile's chain), `finish` consumes its result and writes
+// cell_info, the work items, cell_base[] and pair_base (LDS) - the caller may put independent work between the two.
+struct CellAlloc {
+  uint32_t len, nfull, rem, nst, i_len, i_st, i_full, pcls, fcls, frank;
+  unsigned long long b1, b2, b3, got;
+};
+
+__device__ __forceinline__ void hgs_alloc_cell_ranges_issue(const Layout& L, uint32_t len_of_lane, CellAlloc& a) {
+  const int lane = (int)threadIdx.x & 63;
+  const bool cl = lane < 16;
+  a.len = cl ? len_of_lane : 0u;
+  a.nfull = a.len / HGS_SEGLEN; a.rem = a.len % HGS_SEGLEN;
+  const uint32_t nseg = a.nfull + (a.rem ? 1u : 0u);
+  a.nst = nseg ? nseg - 1u : 0u;
+  a.i_len = hgs_wave_incl_scan(a.len); a.i_st = hgs_wave_incl_scan(a.nst); a.i_full = hgs_wave_incl_scan(a.nfull);
+  a.pcls = a.rem ? hgs_item_class(a.rem) : 0u;            // 1..3 for a partial last segment
+  a.b1 = __ballot(a.pcls == 1u); a.b2 = __ballot(a.pcls == 2u); a.b3 = __ballot(a.pcls == 3u);
+  const uint32_t t_len = (uint32_t)__builtin_amdgcn_readlane((int)a.i_len, 63);
+  const uint32_t t_st = (uint32_t)__builtin_amdgcn_readlane((int)a.i_st, 63);
+  const uint32_t t_full = (uint32_t)__builtin_amdgcn_readlane((int)a.i_full, 63);
+  // forward work items: every non-empty cell goes into the table of its length class; lane 3 + c allocates for class c
+  a.fcls = hgs_cell_class(a.len);
+  unsigned long long fb_ = 0;                          // cells of this tile in "my" class (lanes 3 .. 3 + HGS_NFC - 1)
+  a.frank = 0;                                         // rank of this lane's cell inside its class, within the tile
+#pragma unroll
+  for (int c = 0; c < HGS_NFC; ++c) {
+    const unsigned long long bc = __ballot(cl && a.len && a.fcls == (uint32_t)c);
+    if (lane == 3 + c) fb_ = bc;
+    if (a.fcls == (uint32_t)c) a.frank = (uint32_t)__popcll(bc & ((1ull << lane) - 1ull));
+  }
+  const unsigned long long add = lane == 0 ? ((unsigned long long)t_len | ((unsigned long long)t_st << 32))
+                               : lane == 1 ? ((unsigned long long)t_full | ((unsigned long long)__popcll(a.b1) << 32))
+                               : lane == 2 ? ((unsigned long long)__popcll(a.b2) | ((unsigned long long)__popcll(a.b3) << 32))
+                                           : (unsigned long long)__popcll(fb_);
+  a.got = 0;
+  if (lane < 3 + HGS_NFC && add) a.got = atomicAdd(&L.ctr->alloc3[lane], add);
+}
+
+__device__ __forceinline__ void hgs_alloc_cell_ranges_finish(const View& v, const Layout& L, int g, const CellAlloc& a,
+                                                             uint32_t* cell_base, uint32_t& pair_base_out) {
+  int lane = (int)threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));       // (keeps lane-dependent store addresses from being hoisted out of a persistent tile loop
+  const bool cl = lane < 16;           //  and held - spilled - across it)
+  const uint32_t fpos = (uint32_t)__shfl((int)(uint32_t)a.got, 3 + (int)a.fcls, 64) + a.frank;
+  const uint32_t got_lo = (uint32_t)a.got, got_hi = (uint32_t)(a.got >> 32);
+  const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 0);
+  const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 0);
+  const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 1);
+  const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 1);
+  const uint32_t p2 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 2);
+  const uint32_t p3 = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 2);
+  if (cl) {
+    const uint32_t len = a.len, nfull = a.nfull, rem = a.rem;
+    const uint32_t base = pb + a.i_len - len;
+    cell_base[lane] = base;
+    CellInfo ci;
+    ci.base = base; ci.len = len; ci.sbase = sb + a.i_st - a.nst; ci.pbase = pb;
+    L.cell_info[(size_t)g * 16 + lane] = ci;
+    const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
+    if (len) L.fwd_cells[(size_t)a.fcls * 16u * v.TT + fpos] = key;
+    // a work item carries all its wave needs to start: (cell, entries, first cell-list slot, state slot in front of it)
+    uint4* full = L.items_full + (fb + a.i_full - nfull);
+    for (uint32_t sgm = 0; sgm < nfull; ++sgm)
+      full[sgm] = make_uint4(key, HGS_SEGLEN, base + sgm * HGS_SEGLEN, sgm ? ci.sbase + sgm - 1u : 0xffffffffu);
+    if (rem) {
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const size_t ptab = (size_t)16 * v.TT;
+      const uint4 it = make_uint4(key, rem, base + nfull * HGS_SEGLEN, nfull ? ci.sbase + nfull - 1u : 0xffffffffu);
+      if (a.pcls == 1u) L.items_part[p1 + (uint32_t)__popcll(a.b1 & below)] = it;
+      else if (a.pcls == 2u) L.items_part[ptab - 1 - (p2 + (uint32_t)__popcll(a.b2 & below))] = it;
+      else L.items_part[ptab + p3 + (uint32_t)__popcll(a.b3 & below)] = it;
+    }
+  }
+  if (lane == 0) pair_base_out = pb;
+}
+
 __device__ __forceinline__ void hgs_alloc_cell_ranges(const View& v, const Layout& L, int g, const uint32_t* cell_tot,
                                                       uint32_t* cell_base, uint32_t& pair_base_out) {
-  const int tid = (int)threadIdx.x, lane = tid & 63;
-  if (tid < 64) {
-    const bool cl = lane < 16;
-    const uint32_t len = cl ? cell_tot[lane] : 0u;
-    const uint32_t nfull = len / HGS_SEGLEN, rem = len % HGS_SEGLEN;
-    const uint32_t nseg = nfull + (rem ? 1u : 0u);
-    const uint32_t nst = nseg ? nseg - 1u : 0u;
-    const uint32_t i_len = hgs_wave_incl_scan(len), i_st = hgs_wave_incl_scan(nst), i_full = hgs_wave_incl_scan(nfull);
-    const uint32_t pcls = rem ? hgs_item_class(rem) : 0u;            // 1..3 for a partial last segment
-    const unsigned long long b1 = __ballot(pcls == 1u), b2 = __ballot(pcls == 2u), b3 = __ballot(pcls == 3u);
-    // the bump allocations travel together: ONE atomic instruction, lanes 0..2 on three 64-bit counters (a device-scope
-    // atomic is a trip to the memory side of the fabric: five of them in a row were 13 us of every tile's chain)
-    const uint32_t t_len = (uint32_t)__builtin_amdgcn_readlane((int)i_len, 63);
-    const uint32_t t_st = (uint32_t)__builtin_amdgcn_readlane((int)i_st, 63);
-    const uint32_t t_full = (uint32_t)__builtin_amdgcn_readlane((int)i_full, 63);
-    // forward work items: every non-empty cell goes into the table of its length class; lane 3 + c allocates for class c
-    const uint32_t fcls = hgs_cell_class(len);
-    unsigned long long fb_ = 0;                        // cells of this tile in "my" class (lanes 3 .. 3 + HGS_NFC - 1)
-    uint32_t frank = 0;                                // rank of this lane's cell inside its class, within the tile
-#pragma unroll
-    for (int c = 0; c < HGS_NFC; ++c) {
-      const unsigned long long bc = __ballot(cl && len && fcls == (uint32_t)c);
-      if (lane == 3 + c) fb_ = bc;
-      if (fcls == (uint32_t)c) frank = (uint32_t)__popcll(bc & ((1ull << lane) - 1ull));
-    }
-    const unsigned long long add = lane == 0 ? ((unsigned long long)t_len | ((unsigned long long)t_st << 32))
-                                 : lane == 1 ? ((unsigned long long)t_full | ((unsigned long long)__popcll(b1) << 32))
-                                 : lane == 2 ? ((unsigned long long)__popcll(b2) | ((unsigned long long)__popcll(b3) << 32))
-                                             : (unsigned long long)__popcll(fb_);
-    unsigned long long got = 0;
-    if (lane < 3 + HGS_NFC && add) got = atomicAdd(&L.ctr->alloc3[lane], add);
-    const uint32_t fpos = (uint32_t)__shfl((int)(uint32_t)got, 3 + (int)fcls, 64) + frank;
-    const uint32_t got_lo = (uint32_t)got, got_hi = (uint32_t)(got >> 32);
-    const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 0);
-    const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 0);
-    const uint32_t fb = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 1);
-    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 1);
-    const uint32_t p2 = (uint32_t)__builtin_amdgcn_readlane((int)got_lo, 2);
-    const uint32_t p3 = (uint32_t)__builtin_amdgcn_readlane((int)got_hi, 2);
-    if (cl) {
-      const uint32_t base = pb + i_len - len;
-      cell_base[lane] = base;
-      CellInfo ci;
-      ci.base = base; ci.len = len; ci.sbase = sb + i_st - nst; ci.pbase = pb;
-      L.cell_info[(size_t)g * 16 + lane] = ci;
-      const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
-      if (len) L.fwd_cells[(size_t)fcls * 16u * v.TT + fpos] = key;
-      // a work item carries all its wave needs to start: (cell, entries, first cell-list slot, state slot in front of it)
-      uint4* full = L.items_full + (fb + i_full - nfull);
-      for (uint32_t sgm = 0; sgm < nfull; ++sgm)
-        full[sgm] = make_uint4(key, HGS_SEGLEN, base + sgm * HGS_SEGLEN, sgm ? ci.sbase + sgm - 1u : 0xffffffffu);
-      if (rem) {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const size_t ptab = (size_t)16 * v.TT;
-        const uint4 it = make_uint4(key, rem, base + nfull * HGS_SEGLEN, nfull ? ci.sbase + nfull - 1u : 0xffffffffu);
-        if (pcls == 1u) L.items_part[p1 + (uint32_t)__popcll(b1 & below)] = it;
-        else if (pcls == 2u) L.items_part[ptab - 1 - (p2 + (uint32_t)__popcll(b2 & below))] = it;
-        else L.items_part[ptab + p3 + (uint32_t)__popcll(b3 & below)] = it;
-      }
-    }
-    if (lane == 0) pair_base_out = pb;
+  if (threadIdx.x < 64) {
+    CellAlloc a;
+    hgs_alloc_cell_ranges_issue(L, (threadIdx.x & 63) < 16 ? cell_tot[threadIdx.x & 63] : 0u, a);
+    hgs_alloc_cell_ranges_finish(v, L, g, a, cell_base, pair_base_out);
   }
 }
 
@@ -850,93 +871,575 @@ __device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad
   }
 }
 
-// One tile, n <= NT*E keys: load, sort in registers/LDS, gather the records.
-template <int E, int NT>
-__device__ __forceinline__ void sort_one_tile(const View& v, const Layout& L, int t,
-                                              uint32_t start, uint32_t n, u64* keys, GatherLds<64>& S) {
-  uint32_t npad = E;
-  while (npad < n) npad <<= 1;
-  // Waves whose key slots all lie beyond npad would hold +inf padding only: they leave NOW (a
-  // workgroup barrier only waits for the waves that are still alive), which frees their wave slots
-  // for other tiles - most tiles are far shorter than NT * E keys (762 tiles, mean 436 entries at
-  // config 2).  Measured with 8 views in flight: sort 176 -> ~120 us; a single view is unchanged.
-  const uint32_t live = min((uint32_t)NT, max(64u, (npad / E + 63u) & ~63u));     // threads that stay (wave-uniform)
-  if (threadIdx.x >= live) return;
-  u64 k[E];
-  const uint32_t base = threadIdx.x * E;
-#ifdef HGS_TIMELINE
-  const unsigned long long tp0 = wall_clock64();
-#endif
-#pragma unroll
-  for (int e = 0; e < E; ++e) k[e] = (base + e < n) ? L.keys[start + base + e] : ~0ull;
-#ifdef HGS_TIMELINE
-  asm volatile("s_waitcnt vmcnt(0)");
-  const unsigned long long tp1 = wall_clock64();
-#endif
-  hybrid_sort<E, NT>(k, keys, npad);
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < E; ++e) keys[base + e] = k[e];
-  __syncthreads();
-#ifdef HGS_TIMELINE
-  const unsigned long long tp2 = wall_clock64();
-#endif
-  gather_records_single<64>(v, L, t, start, n, keys, (int)live, S);
-#ifdef HGS_TIMELINE
-  if (threadIdx.x == 0 && blockIdx.x < HGS_TL_SLOTS) {     // phases of this tile's sort (wave 0): kernel id 5
-    hgs_tl[5][blockIdx.x][0] = tp1 - tp0;
-    hgs_tl[5][blockIdx.x][1] = tp2 - tp1;
-    hgs_tl[5][blockIdx.x][2] = wall_clock64() - tp2;
-    hgs_tl[5][blockIdx.x][3] = ((unsigned long long)E << 32) | n;
-  }
-#endif
-}
-
 }  // namespace
 
-// All tiles with 1..4096 entries in ONE launch: each sort is latency-bound on its own stage chain,
-// so the few long lists overlap with the many short ones instead of running in a second kernel
-// after them.  Two workgroup shapes: 512 threads (2, 4 or 8 keys per thread by list length) gives
-// the heaviest tile the shortest chain - what a single view waits for (34 vs 37.5 us); 256 threads
-// (4, 8, 16 keys) keeps twice as many tiles resident per CU - what counts with several views in
-// flight (8 views: 120 vs 158 us).  The host picks by the number of views of the call.
+// ---------------------------------------------------------------------------- 3b. rank sort (lists of 1..4096 entries)
+// The bitonic network above costs log2(n) (log2(n) + 1) / 2 DEPENDENT stages (45 for a typical 436-entry tile, ~220 ns
+// each) and the record gather behind it was a second chain of dependent round trips: a tile took 22 us, the heaviest
+// 33 us, and the kernel was the latency of its heaviest tile.  Here a key never moves: the thread that LOADED a key
+// computes the key's final RANK and writes the record straight to its slot.
+//   1. keys -> registers (coalesced); the 64 B geometry gathers of the thread's first keys go out NOW and fly under
+//      the whole sort (the thread knows its Gaussians from the start: nothing waits for the order);
+//   2. depth range of the tile (wave reductions + two LDS atomics), NB ~ 2 n buckets (a power of two <= 2048),
+//      bucket = floor((depth - dmin) * NB / range): a MONOTONE map (fp subtraction, multiplication by a positive
+//      constant, truncation and the clamp are all non-decreasing), so keys of a smaller bucket sort first;
+//   3. LDS histogram (one atomic per key; its return value = arrival position inside the bucket), exclusive scan;
+//   4. keys scattered into bucket order (LDS); rank = bucket base + number of SMALLER 64-bit keys inside the bucket
+//      (unique keys: depth bits, then Gaussian index - upstream's stable order); buckets hold ~1-3 keys, the probes of
+//      all keys of a thread run interleaved;
+//   5. record + cell mask at the rank (HBM), mask at the rank (LDS), per-cell totals on the way -> the bump
+//      allocation of the tile's ranges is ISSUED, the cell tables are built while it travels, then the cell lists:
+//      a branch-free emit (16 uniform iterations, list bases through v_readlane) instead of a per-lane loop.
+// Degenerate depth distributions (a bucket of more than HGS_RANK_BUCKET_MAX keys: hundreds of exactly equal depths, one
+// far outlier that stretches the range) take the plain bitonic network in LDS for step 4 - same results, the old speed.
+// Workgroups are PERSISTENT (a capacity-sized grid spent its last third launching ~3000 workgroups that found no tile).
+// Steps 1-4 exist in a register form for lists of up to 2 / 4 keys per thread and in a streaming form for longer ones;
+// step 5 is ONE loop for all (it reads (Gaussian, rank) pairs back from LDS), which keeps the kernel's code within the
+// instruction cache.
+#define HGS_RANK_BUCKET_MAX 192        // (< 256: bucket lengths travel in 8 bits)
+#define HGS_RANK_NB_MAX 2048
+// 256 threads: three workgroups per CU by LDS (45 KB each) are three waves per SIMD, which leaves a wave 168 VGPRs for
+// up to 16 keys + their ranks + the gathers in flight.  A typical tile (~440 entries) is two keys per thread.
+#define HGS_SORT_NT 256
+#ifndef HGS_RANK_PRIO
+#define HGS_RANK_PRIO 0
+#endif
+#ifndef HGS_RANK_GU
+#define HGS_RANK_GU 2                  // geometry gathers per thread and round (16 registers each); two rounds are in flight
+#endif
+
 namespace {
+
+// workgroup barrier that orders LDS traffic only (no global load / atomic is waited for: gathers and the bump
+// allocation stay in flight across it).  Every cross-wave hand-off in this kernel goes through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct RankLds {
+  uint32_t hist[HGS_RANK_NB_MAX + 1];   // bucket counts -> exclusive bases (+ sentinel); from step 5 on: the 16-bit masks in list order
+  uint32_t wtot[8];                      // block scan
+  uint32_t tot16[8];                     // cell-list lengths of the tile, two 16-bit fields per word (word 2 q + (c & 1), field (c >> 1) & 1, q = c >> 2)
+  uint32_t dmin, dmax, maxcnt, pad;
+};
+static_assert(sizeof(uint32_t) * (HGS_RANK_NB_MAX + 1) >= sizeof(uint16_t) * 4096, "the masks of the longest list fit into the histogram");
+
+// Cell tables + cell lists of one tile from the masks of its records in list order (what gather_records_single does
+// behind its sweep 1).  All NT threads of the workgroup take part; wave 0 has ISSUED the range allocation (`ca`).
 template <int NT>
-__device__ __forceinline__ void sort_lds_body(const View& v, const Layout& L, const hgs_status* __restrict__ status,
-                                              unsigned long long* keys, GatherLds<64>& S) {
+__device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layout& L, uint32_t order_pos, uint32_t start, uint32_t n,
+                                                      const uint16_t* __restrict__ masks, GatherLds<64>& S, const CellAlloc& ca,
+                                                      unsigned long long* tp) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int nwaves = NT / 64;
+  const uint32_t nch = (n + 63u) / 64u;                 // <= 64
+  // (1) per 64-record chunk: packed per-cell counts (tab[ch][0..3]) and the chunk's pairs (tab[ch][16])
+  for (uint32_t ch = wv; ch < nch; ch += nwaves) {
+    const uint32_t k = ch * 64u + lane;
+    const uint32_t mask = (k < n) ? (uint32_t)masks[k] : 0u;
+    uint32_t tot[4];
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) tot[wd] = hgs_wave_incl_scan(hgs_spread4((mask >> (4 * wd)) & 0xfu));
+    if (lane == 63) {
+      S.tab[ch][0] = tot[0]; S.tab[ch][1] = tot[1]; S.tab[ch][2] = tot[2]; S.tab[ch][3] = tot[3];
+      S.tab[ch][16] = hgs_bytesum(tot[0]) + hgs_bytesum(tot[1]) + hgs_bytesum(tot[2]) + hgs_bytesum(tot[3]);
+    }
+  }
+  lds_barrier();
+  // (2) exclusive prefix over the chunks for the 16 cells (unpacked to 32 bits in place, after every wave has read
+  // its packed words) and for the pairs
+  {
+    uint32_t pk[4];
+    const uint32_t ch = (uint32_t)lane;
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) pk[wd] = (ch < nch) ? S.tab[ch][wd] : 0u;
+    lds_barrier();
+    for (int col = wv; col < 5; col += nwaves) {
+      if (col < 4) {
+        const uint32_t word = col == 0 ? pk[0] : col == 1 ? pk[1] : col == 2 ? pk[2] : pk[3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const uint32_t x = (word >> (8 * b)) & 0xffu;
+          const uint32_t inc = hgs_wave_incl_scan(x);
+          if (ch < nch) S.tab[ch][4 * col + b] = inc - x;
+        }
+      } else {
+        const uint32_t x = ch < nch ? S.tab[ch][16] : 0u;
+        const uint32_t inc = hgs_wave_incl_scan(x);
+        if (ch < nch) S.tab[ch][16] = inc - x;
+      }
+    }
+  }
+#ifdef HGS_TIMELINE
+  tp[2] = wall_clock64();
+#endif
+  // (3) the ranges have arrived: cell_info, work items, list bases
+  if (tid < 64) hgs_alloc_cell_ranges_finish(v, L, (int)L.tile_rec[order_pos].x, ca, S.cell_base, S.pair_base);   // (the tile id re-read: one register less across the kernel)
+  lds_barrier();
+#ifdef HGS_TIMELINE
+  tp[3] = wall_clock64();
+#endif
+  // (4) cell lists and pair slots: 16 uniform iterations, the list bases of the chunk travel through v_readlane
+  const uint32_t pair_base = S.pair_base;
+  for (uint32_t ch = wv; ch < nch; ch += nwaves) {
+    const uint32_t k = ch * 64u + lane;
+    const bool in = k < n;
+    const uint32_t mask = in ? (uint32_t)masks[k] : 0u;
+    uint32_t ex[4], before = 0;                          // records of this chunk before this lane, per cell (bytes)
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+      const uint32_t mine = hgs_spread4((mask >> (4 * wd)) & 0xfu);
+      ex[wd] = hgs_wave_incl_scan(mine) - mine;
+      before += hgs_bytesum(ex[wd]);
+    }
+    const uint32_t rel = pair_base + S.tab[ch][16] + before;      // first pair id of this entry (entry-major)
+    if (in) L.entpair[start + k].y = rel;
+    const uint32_t cb = lane < 16 ? S.cell_base[lane] + S.tab[ch][lane] : 0u;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const uint32_t cbase = (uint32_t)__builtin_amdgcn_readlane((int)cb, c);
+      if ((mask >> c) & 1u) {
+        const uint32_t slot = cbase + ((ex[c >> 2] >> (8 * (c & 3))) & 0xffu);
+        L.cell_list[slot] = make_uint2(start + k, rel + (uint32_t)__popc(mask & ((1u << c) - 1u)));
+      }
+    }
+  }
+}
+
+// Steps 1-4 for one tile of n <= E * NT keys: leaves (Gaussian index | rank << 32) of source position k in pairs[k]
+// (k = e * NT + thread: every thread reads back only what it wrote).  keyp = the thread's first keys, already loaded.
+// Returns true when the depth distribution was degenerate and the ranks came from the bitonic network (then the pair of
+// source position k belongs to LIST position k and the caller's prefetched gathers are stale).
+template <int E, int NT>
+__device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint32_t n, uint32_t NB, const u64 (&keyp)[HGS_RANK_GU],
+                                          unsigned long long* pairs, RankLds& R) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  u64 key[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (e < HGS_RANK_GU) key[e] = keyp[e];
+    else {                                               // (unconditional load from a clamped slot: a load inside a branch is
+      const uint32_t k = (uint32_t)e * NT + (uint32_t)tid;      // waited for on the spot, one key at a time)
+      const u64 kv = L.keys[start + min(k, n - 1u)];
+      key[e] = (k < n) ? kv : ~0ull;
+    }
+  }
+  // ---- 2. depth range
+  {
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t d = (uint32_t)(key[e] >> 32);
+      lo = min(lo, d);                                   // (padding: 0xffffffff never lowers the minimum)
+      hi = max(hi, key[e] != ~0ull ? d : 0u);
+    }
+    hi = hgs_wave_max_u32(hi);
+    lo = ~hgs_wave_max_u32(~lo);
+    lds_barrier();                                       // the zeroed histogram / range words are in place
+    if (lane == 0) { atomicMin(&R.dmin, lo); atomicMax(&R.dmax, hi); }
+  }
+  lds_barrier();
+  // ---- 3. histogram
+  const float flo = __uint_as_float(R.dmin);
+  const float range = __uint_as_float(R.dmax) - flo;
+  const float scale = range > 1e-30f ? (float)NB / range : 0.0f;
+  uint32_t bp[E];                                          // bucket | arrival position << 12, later the rank
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    bp[e] = 0u;
+    if (key[e] != ~0ull) {
+      const float x = (__uint_as_float((uint32_t)(key[e] >> 32)) - flo) * scale;
+      const uint32_t bkt = (uint32_t)fminf(x, (float)(NB - 1u));
+      bp[e] = bkt | (atomicAdd(&R.hist[bkt], 1u) << 12);
+    }
+  }
+  lds_barrier();
+  // exclusive scan of the NB counts in place (thread = PER consecutive buckets), largest bucket on the way
+  {
+    const uint32_t PER = NB >= (uint32_t)NT ? NB / NT : 1u;         // a power of two <= NB_MAX / NT
+    const uint32_t b0 = (uint32_t)tid * PER;
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t i = 0; i < PER; ++i) {
+      const uint32_t c = (b0 + i < NB) ? R.hist[b0 + i] : 0u;
+      sum += c; mx = max(mx, c);
+    }
+    const uint32_t inc = hgs_wave_incl_scan(sum);
+    mx = hgs_wave_max_u32(mx);
+    if (lane == 63) R.wtot[wv] = inc;
+    if (lane == 0 && mx) atomicMax(&R.maxcnt, mx);
+    lds_barrier();
+    uint32_t base = inc - sum;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) base += (w < wv) ? R.wtot[w] : 0u;
+    for (uint32_t i = 0; i < PER; ++i) {
+      if (b0 + i < NB) { const uint32_t c = R.hist[b0 + i]; R.hist[b0 + i] = base; base += c; }
+    }
+    if (tid == 0) R.hist[NB] = n;
+  }
+  lds_barrier();
+  const bool degenerate = R.maxcnt > (uint32_t)HGS_RANK_BUCKET_MAX;      // (workgroup-uniform)
+  if (!degenerate) {
+    // ---- 4. bucket order, then the rank inside the bucket
+    constexpr int EG = E < 8 ? E : 8;                      // keys probed together (more: registers)
+    uint32_t lmax[E / EG];
+#pragma unroll
+    for (int h = 0; h < E / EG; ++h) lmax[h] = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (key[e] != ~0ull) {
+        const uint32_t j0 = R.hist[bp[e] & 0xfffu], j1 = R.hist[(bp[e] & 0xfffu) + 1u];
+        pairs[j0 + (bp[e] >> 12)] = key[e];
+        bp[e] = j0 | ((j1 - j0) << 12);                    // bucket start | bucket length << 12 | (smaller keys << 20)
+        lmax[e / EG] = max(lmax[e / EG], j1 - j0);
+      }                                                    // (padding keeps 0: no probe)
+    }
+    lds_barrier();
+    // the probes of the thread's keys interleaved: EG independent LDS reads per step (one key after the other, each
+    // with its own data-dependent loop, was 5 us of a 1400-entry tile)
+#pragma unroll
+    for (int h = 0; h < E / EG; ++h) {
+      for (uint32_t sidx = 0; sidx < lmax[h]; ++sidx) {
+        u64 other[EG];
+#pragma unroll
+        for (int e = 0; e < EG; ++e) {
+          const uint32_t w = bp[h * EG + e];
+          const bool on = sidx < ((w >> 12) & 0xffu);
+          other[e] = pairs[on ? (w & 0xfffu) + sidx : 0u];        // (unconditional read from a valid slot)
+        }
+#pragma unroll
+        for (int e = 0; e < EG; ++e) {
+          const uint32_t w = bp[h * EG + e];
+          const bool on = sidx < ((w >> 12) & 0xffu);
+          bp[h * EG + e] = w + ((on && other[e] < key[h * EG + e]) ? (1u << 20) : 0u);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) bp[e] = (bp[e] & 0xfffu) + (bp[e] >> 20);
+  } else {
+    // hundreds of keys in one bucket (exactly equal depths, or a range stretched by an outlier): the bitonic network
+    // on the keys in LDS; afterwards the thread adopts the keys at ITS list positions
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t k = (uint32_t)e * NT + (uint32_t)tid;
+      if (k < n) pairs[k] = key[e];
+    }
+    __syncthreads();
+    bitonic_sort<NT>(pairs, n);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t k = (uint32_t)e * NT + (uint32_t)tid;
+      key[e] = (k < n) ? pairs[k] : ~0ull;
+      bp[e] = k;
+    }
+  }
+  lds_barrier();                                           // every rank is known: `pairs` and the histogram are free
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t k = (uint32_t)e * NT + (uint32_t)tid;
+    if (k < n) pairs[k] = (key[e] & 0xffffffffull) | ((u64)bp[e] << 32);
+  }
+  return degenerate;
+}
+
+// The same steps for LONG lists (more than four keys per thread) without per-key register state: every phase re-reads
+// the keys from the tile's key segment (coalesced, L2-resident) and only the ranks stay in registers (16 keys and
+// their bucket words per thread did not fit beside everything else: scratch spills).  The scatter takes its slot from a
+// second LDS atomic on the scanned histogram (hist[b] then ends bucket b), so no arrival position has to be kept.
+template <int NT>
+__device__ __forceinline__ bool rank_keys_stream(const Layout& L, uint32_t start, uint32_t n, uint32_t NB,
+                                                 unsigned long long* pairs, RankLds& R) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned long long* __restrict__ keys = L.keys + start;
+  const uint32_t last = n - 1u;
+  // ---- 2. depth range
+  {
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll 4
+    for (uint32_t k = tid; k < n; k += NT) {
+      const uint32_t d = (uint32_t)(keys[k] >> 32);
+      lo = min(lo, d); hi = max(hi, d);
+    }
+    hi = hgs_wave_max_u32(hi);
+    lo = ~hgs_wave_max_u32(~lo);
+    lds_barrier();                                       // the zeroed histogram / range words are in place
+    if (lane == 0) { atomicMin(&R.dmin, lo); atomicMax(&R.dmax, hi); }
+  }
+  lds_barrier();
+  const float flo = __uint_as_float(R.dmin);
+  const float range = __uint_as_float(R.dmax) - flo;
+  const float scale = range > 1e-30f ? (float)NB / range : 0.0f;
+  const float bmax = (float)(NB - 1u);
+  auto bucket_of = [&](u64 key) { return (uint32_t)fminf((__uint_as_float((uint32_t)(key >> 32)) - flo) * scale, bmax); };
+  // ---- 3. histogram, scan
+#pragma unroll 4
+  for (uint32_t k = tid; k < n; k += NT) atomicAdd(&R.hist[bucket_of(keys[k])], 1u);
+  lds_barrier();
+  {
+    const uint32_t PER = NB >= (uint32_t)NT ? NB / NT : 1u;
+    const uint32_t b0 = (uint32_t)tid * PER;
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t i = 0; i < PER; ++i) {
+      const uint32_t c = (b0 + i < NB) ? R.hist[b0 + i] : 0u;
+      sum += c; mx = max(mx, c);
+    }
+    const uint32_t inc = hgs_wave_incl_scan(sum);
+    mx = hgs_wave_max_u32(mx);
+    if (lane == 63) R.wtot[wv] = inc;
+    if (lane == 0 && mx) atomicMax(&R.maxcnt, mx);
+    lds_barrier();
+    uint32_t base = inc - sum;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) base += (w < wv) ? R.wtot[w] : 0u;
+    for (uint32_t i = 0; i < PER; ++i) {
+      if (b0 + i < NB) { const uint32_t c = R.hist[b0 + i]; R.hist[b0 + i] = base; base += c; }
+    }
+  }
+  lds_barrier();
+  const bool degenerate = R.maxcnt > (uint32_t)HGS_RANK_BUCKET_MAX;      // (workgroup-uniform)
+  uint32_t rk[16];
+  if (!degenerate) {
+    // ---- 4. bucket order (slot = the bucket's cursor), then the rank inside the bucket, four keys probed together
+#pragma unroll 4
+    for (uint32_t k = tid; k < n; k += NT) {
+      const u64 key = keys[k];
+      pairs[atomicAdd(&R.hist[bucket_of(key)], 1u)] = key;
+    }
+    lds_barrier();                                         // hist[b] = end of bucket b = start of bucket b + 1
+#pragma unroll
+    for (int e0 = 0; e0 < 16; e0 += 4) {
+      if ((uint32_t)e0 * NT >= n) break;                   // (workgroup-uniform)
+      u64 key[4];
+      uint32_t w[4], lmax = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t k = (uint32_t)(e0 + e) * NT + (uint32_t)tid;
+        key[e] = keys[min(k, last)];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t k = (uint32_t)(e0 + e) * NT + (uint32_t)tid;
+        const uint32_t b = bucket_of(key[e]);
+        const uint32_t j1 = R.hist[b], j0 = b ? R.hist[b - 1u] : 0u;
+        const uint32_t len = k < n ? j1 - j0 : 0u;
+        w[e] = j0 | (len << 12);                           // bucket start | bucket length << 12 | (smaller keys << 20)
+        lmax = max(lmax, len);
+      }
+      for (uint32_t sidx = 0; sidx < lmax; ++sidx) {
+        u64 other[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool on = sidx < ((w[e] >> 12) & 0xffu);
+          other[e] = pairs[on ? (w[e] & 0xfffu) + sidx : 0u];     // (unconditional read from a valid slot)
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool on = sidx < ((w[e] >> 12) & 0xffu);
+          w[e] += (on && other[e] < key[e]) ? (1u << 20) : 0u;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rk[e0 + e] = (w[e] & 0xfffu) + (w[e] >> 20);
+    }
+    lds_barrier();                                         // every probe is done: `pairs` is free
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const uint32_t k = (uint32_t)e * NT + (uint32_t)tid;
+      if (k < n) pairs[k] = (keys[k] & 0xffffffffull) | ((u64)rk[e] << 32);
+    }
+  } else {
+    // degenerate depths: the bitonic network on the keys in LDS; list position k then holds (Gaussian, rank = k)
+    for (uint32_t k = tid; k < n; k += NT) pairs[k] = keys[k];
+    __syncthreads();
+    bitonic_sort<NT>(pairs, n);
+    for (uint32_t k = tid; k < n; k += NT) pairs[k] = (pairs[k] & 0xffffffffull) | ((u64)k << 32);
+    lds_barrier();
+  }
+  return degenerate;
+}
+
+template <int NT>
+__device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, uint32_t order_pos, int g, uint32_t start, uint32_t n,
+                                               unsigned long long* pairs, RankLds& R, GatherLds<64>& S, bool& degenerate_out,
+                                               unsigned long long* tp) {
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  constexpr int GU = HGS_RANK_GU;
+  const int t = g % v.T;
+  const GeomRec* __restrict__ geom = L.geom + (size_t)(g / v.T) * v.P;
+  const uint32_t* __restrict__ cbase = L.chunk_base + (size_t)(g / v.T) * v.nblk;
+  const int tx = t % v.grid_x, ty = t / v.grid_x;
+  const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
+  uint32_t NB = 256u;
+  while (NB < 2u * n && NB < (uint32_t)HGS_RANK_NB_MAX) NB <<= 1;      // (wave-uniform)
+  for (uint32_t i = tid; i <= NB; i += NT) R.hist[i] = 0u;
+  if (tid < 8) R.tot16[tid] = 0u;
+  if (tid == 0) { R.dmin = 0xffffffffu; R.dmax = 0u; R.maxcnt = 0u; }
+  // ---- 1. the thread's first keys; their gathers leave at once (unconditional: padding re-reads record 0)
+  u64 keyp[GU];
+#pragma unroll
+  for (int u = 0; u < GU; ++u) {
+    const uint32_t k = (uint32_t)u * NT + (uint32_t)tid;
+    const u64 kv = L.keys[start + min(k, n - 1u)];          // (unconditional, clamped)
+    keyp[u] = (k < n) ? kv : ~0ull;
+  }
+  // two rounds of gathers in flight: A and B, plain register arrays (a struct handed to a lambda stayed in scratch memory)
+  uint4 Aa[GU], Ab[GU], Ac[GU], Ba[GU], Bb[GU], Bc[GU];     // GeomRec words 0-11
+  uint32_t Aoff[GU], Acb[GU], Boff[GU], Bcb[GU];            // entry-id offset inside the chunk, the chunk's base
+  u64 Apr[GU], Bpr[GU];                                     // Gaussian | rank << 32, ~0 = none
+#define HGS_RANK_ISSUE(X, u, PR)                                                              \
+  {                                                                                           \
+    const u64 pr__ = (PR);                                                                    \
+    const uint32_t idx__ = pr__ == ~0ull ? 0u : (uint32_t)pr__;                               \
+    const uint4* gp__ = reinterpret_cast<const uint4*>(&geom[idx__]);                         \
+    X##a[u] = gp__[0]; X##b[u] = gp__[1]; X##c[u] = gp__[2]; X##off[u] = gp__[3].x;           \
+    X##cb[u] = cbase[idx__ >> 8];                                                             \
+    X##pr[u] = pr__;                                                                          \
+  }
+  // ---- 2-4. ranks.  Lists of up to 4 keys per thread keep keys and bucket words in registers and send their first
+  // gathers out BEFORE the sort; longer ones stream the keys per phase and start the gathers behind the sort: their
+  // many rounds amortise one exposed round trip.
+  bool degenerate;
+#ifndef HGS_RANK_REG_MAXE
+#define HGS_RANK_REG_MAXE 8
+#endif
+  const bool early = n <= (uint32_t)HGS_RANK_REG_MAXE * NT;
+  if (early) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) HGS_RANK_ISSUE(A, u, keyp[u]);
+    if (n <= 2u * NT) degenerate = rank_keys<2, NT>(L, start, n, NB, keyp, pairs, R);
+    else if (n <= 4u * NT || HGS_RANK_REG_MAXE < 8) degenerate = rank_keys<4, NT>(L, start, n, NB, keyp, pairs, R);
+    else degenerate = rank_keys<8, NT>(L, start, n, NB, keyp, pairs, R);
+  } else {
+    degenerate = rank_keys_stream<NT>(L, start, n, NB, pairs, R);
+  }
+  degenerate_out = degenerate;
+#ifdef HGS_TIMELINE
+  tp[0] = wall_clock64();
+#endif
+  // ---- 5. records + masks at the rank: rounds of GU keys per thread, two rounds in flight (A / B), the (Gaussian,
+  // rank) pairs read back from LDS; per-cell totals of the thread's masks on the way (bytes: <= 16 keys per thread)
+  uint16_t* __restrict__ masks = reinterpret_cast<uint16_t*>(R.hist);
+  uint32_t acc[4] = {0u, 0u, 0u, 0u};
+#define HGS_RANK_ROUND(X, r)       /* the pairs of round r and their gathers */                \
+  _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                            \
+    const uint32_t k__ = ((r) * (uint32_t)GU + (uint32_t)u) * NT + (uint32_t)tid;             \
+    HGS_RANK_ISSUE(X, u, (k__ < n) ? pairs[k__] : ~0ull);                                     \
+  }
+#define HGS_RANK_CONSUME(X)                                                                   \
+  _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                            \
+    if (X##pr[u] != ~0ull) {                                                                  \
+      const uint32_t k = (uint32_t)(X##pr[u] >> 32);                                          \
+      const uint4 g0 = X##a[u], g1 = X##b[u], g2 = X##c[u];                                   \
+      /* g0: mx my ca cb | g1: cc op r g | g2: b depth rect_lo rect_hi */                     \
+      const int minx = g2.z & 0xffffu, miny = g2.z >> 16, maxx = g2.w & 0xffffu;              \
+      const uint32_t entry = X##cb[u] + X##off[u] + (uint32_t)((ty - miny) * (maxx - minx) + (tx - minx)); \
+      const float mx = __uint_as_float(g0.x), my = __uint_as_float(g0.y);                     \
+      const float ca = __uint_as_float(g0.z), cb = __uint_as_float(g0.w), cc = __uint_as_float(g1.x); \
+      const uint32_t mask = hgs_cell_mask(mx, my, ca, cb, cc, __uint_as_float(g1.y), x0, y0); \
+      uint4* dst = reinterpret_cast<uint4*>(&L.recs[start + k]);                              \
+      const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E; \
+      dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));              \
+      dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);                             \
+      dst[2] = make_uint4(g2.x, g2.y, entry, 0u);                                             \
+      L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);   /* (.y, the first pair id, follows with the lists) */ \
+      masks[k] = (uint16_t)mask;                                                              \
+      _Pragma("unroll") for (int wd = 0; wd < 4; ++wd) acc[wd] += hgs_spread4((mask >> (4 * wd)) & 0xfu); \
+    }                                                                                         \
+  }
+  if (degenerate || !early) {                              // (degenerate: the thread now owns other Gaussians - gather again)
+    HGS_RANK_ROUND(A, 0u)
+  } else {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const uint32_t k = (uint32_t)u * NT + (uint32_t)tid;
+      Apr[u] = (k < n) ? pairs[k] : ~0ull;
+    }
+  }
+  const uint32_t per_round = (uint32_t)GU * NT;
+  for (uint32_t r = 0; r * per_round < n; r += 2u) {       // (workgroup-uniform trip count)
+    const bool hb = (r + 1u) * per_round < n, ha = (r + 2u) * per_round < n;
+    if (hb) { HGS_RANK_ROUND(B, r + 1u) }
+    HGS_RANK_CONSUME(A)
+    if (ha) { HGS_RANK_ROUND(A, r + 2u) }
+    if (hb) { HGS_RANK_CONSUME(B) }
+  }
+#undef HGS_RANK_ISSUE
+#undef HGS_RANK_ROUND
+#undef HGS_RANK_CONSUME
+  // per-cell totals of the wave -> the tile's (two 16-bit fields per word: <= 1024 per wave, <= 4096 per tile)
+  {
+    uint32_t w16[8];
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) { w16[2 * wd] = acc[wd] & 0x00ff00ffu; w16[2 * wd + 1] = (acc[wd] >> 8) & 0x00ff00ffu; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w16[i] = hgs_wave_incl_scan(w16[i]);
+    if (lane == 63) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (w16[i]) atomicAdd(&R.tot16[i], w16[i]);
+    }
+  }
+  lds_barrier();
+#ifdef HGS_TIMELINE
+  tp[1] = wall_clock64();
+#endif
+  // the bump allocation of the tile's ranges leaves now; the cell tables are built while it travels
+  CellAlloc ca;
+  if (tid < 64) {
+    const int c = lane & 15;
+    const uint32_t word = R.tot16[2 * (c >> 2) + (c & 1)];
+    hgs_alloc_cell_ranges_issue(L, (word >> (16 * ((c >> 1) & 1))) & 0xffffu, ca);
+  }
+  cell_lists_from_masks<NT>(v, L, order_pos, start, n, masks, S, ca, tp);
+}
+
+template <int NT>
+__device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, const hgs_status* __restrict__ status,
+                                               unsigned long long* pairs, RankLds& R, GatherLds<64>& S) {
   if (status->overflow) return;
-  const uint32_t b = blockIdx.x;
-  if (b >= status->active_tiles) return;
-  const int t = (int)L.tile_order[b];
-  const uint32_t start = L.tile_start[t];
-  const uint32_t n = L.tile_n[t];
-  if (n == 0 || n > 4096u) return;
-  constexpr int E0 = 1024 / NT;
-  // (4 keys per thread for every list <= 2048 at 512 threads, i.e. half the waves for lists <= 1024,
-  // was measured: single view 34 -> 39 us, 8 views 158 -> 150 us; not kept)
-  if (n <= 1024u) sort_one_tile<E0, NT>(v, L, t, start, n, keys, S);
-  else if (n <= 2048u) sort_one_tile<2 * E0, NT>(v, L, t, start, n, keys, S);
-  else sort_one_tile<4 * E0, NT>(v, L, t, start, n, keys, S);
+  const uint32_t active = status->active_tiles;
+  for (uint32_t b = blockIdx.x; b < active; b += gridDim.x) {
+    const uint4 tr = L.tile_rec[b];                      // (tile, entries, first entry): one load
+    const int g = (int)tr.x;
+    const uint32_t n = tr.y, start = tr.z;
+    if (n == 0 || n > 4096u) continue;                   // (longer lists: hgs_k_sort_large / _huge)
+#ifdef HGS_TIMELINE
+    const unsigned long long tp0 = wall_clock64();
+#endif
+    bool degenerate;
+    unsigned long long tp[4] = {0, 0, 0, 0};
+#if HGS_RANK_PRIO
+    // the kernel ends with its longest list: those workgroups win the issue arbitration against their co-residents
+    if (n > (uint32_t)HGS_RANK_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
+    rank_sort_tile<NT>(v, L, b, g, start, n, pairs, R, S, degenerate, tp);
+#if HGS_RANK_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef HGS_TIMELINE
+    if (threadIdx.x == 0 && b < HGS_TL_SLOTS) {          // per tile (position in tile_order), wave 0: kernel ids 5 and 2
+      const unsigned long long tpe = wall_clock64();
+      auto cl = [](unsigned long long d) { return d > 0xffffull ? 0xffffull : d; };
+      hgs_tl[5][b][0] = tp0;                             // absolute start / end (10 ns ticks)
+      hgs_tl[5][b][1] = tpe;
+      hgs_tl[5][b][2] = degenerate ? 1 : 0;
+      hgs_tl[5][b][3] = ((unsigned long long)1 << 32) | n;
+      // phases: ranks | records | tables | allocation (its exposed rest)   and   cell lists
+      hgs_tl[2][b][0] = cl(tp[0] - tp0) | (cl(tp[1] - tp[0]) << 16) | (cl(tp[2] - tp[1]) << 32) | (cl(tp[3] - tp[2]) << 48);
+      hgs_tl[2][b][1] = cl(tpe - tp[3]);
+    }
+#endif
+    lds_barrier();                                       // the LDS tables are reused by the next tile
+  }
 }
 }  // namespace
 
-#ifndef HGS_SORT_NT
-#define HGS_SORT_NT 512
-#endif
-extern "C" __global__ void __launch_bounds__(HGS_SORT_NT)
+static_assert(16 * HGS_SORT_NT >= 4096, "the rank sort takes every list of the LDS class");
+extern "C" __global__ void __launch_bounds__(HGS_SORT_NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
 hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
-  __shared__ unsigned long long keys[4096];
+  __shared__ unsigned long long pairs[4096];
   __shared__ GatherLds<64> S;
+  __shared__ RankLds R;
   HGS_TL_BEGIN();
-  sort_lds_body<HGS_SORT_NT>(v, L, status, keys, S);
-  HGS_TL_END(3, blockIdx.x < status->active_tiles ? L.tile_n[L.tile_order[blockIdx.x]] : 0u);
-}
-
-extern "C" __global__ void __launch_bounds__(256)
-hgs_k_sort_lds_256(View v, Layout L, const hgs_status* __restrict__ status) {
-  __shared__ unsigned long long keys[4096];
-  __shared__ GatherLds<64> S;
-  sort_lds_body<256>(v, L, status, keys, S);
+  sort_rank_body<HGS_SORT_NT>(v, L, status, pairs, R, S);
+  HGS_TL_END(3, 0u);
 }
 
 extern "C" __global__ void __launch_bounds__(1024)

@@ -11,9 +11,10 @@
 //   GeomRec  geom[B*P]           64 B each      uint64  keys[C]        (depth_bits<<32 | idx)
 //   uint32   tile_n[B*T]         list length    SortRec recs[C]        48 B, depth-sorted per tile
 //   uint32   tile_start[B*T]     first entry    uint2   cell_list[16C] (record index, pair id), CELL-major per tile
-//   uint32   tile_order[B*T]     heavy first                   pair ids are ENTRY-major: the pairs of an entry are neighbours
-//   CellInfo cell_info[B*T][16]  the 16 cell    float   cstate[C/4][6][16]  pixel state every 64 cell-list entries
-//            lists of a tile                    uint4   items_full[C/4] backward work items (full segments)
+//   uint32   tile_order[B*T]     heavy first (+ uint4 tile_rec[B*T]: tile, entries, first entry)
+//                                                   pair ids are ENTRY-major: the pairs of an entry are neighbours
+//   CellInfo cell_info[B*T][16]  the 16 cell    float   cstate[16C/SEGLEN][6][16]  pixel state every HGS_SEGLEN (128) cell-list entries
+//            lists of a tile                    uint4   items_full[16C/SEGLEN] backward work items (full segments)
 //   uint4    items_part[2][16 B*T] backward work items (last, partial segment of every cell list)
 //   uint32   fwd_cells[11][16 B*T] forward work items: non-empty cells by length class
 //   uint32   hist[B*nwg][T]      per-binning-workgroup tile histograms (T <= 16384)
@@ -90,16 +91,15 @@ struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian
   float mx, my;         // pixel-space mean
   float qa, qb, qc;     // conic folded for exp2: qa=-0.5*ca*log2e, qb=-cb*log2e, qc=-0.5*cc*log2e
   float op, r, g, b, depth;
-  uint32_t entry;       // low 27 bits: entry id = geom.offset + position of the tile in the rect;
-                        // high 5 bits: number of (entry, cell) pairs = cells the entry can reach (0..16)
-  uint32_t pairs;       // (unused: the pair table of the reduction is `entpair`)
+  uint32_t entry;       // entry id = chunk base + geom.offset + position of the tile in the rect (< 2^27: HGS_MAX_ENTRY_CAPACITY)
+  uint32_t pad;
 };
 #define HGS_LOG2E 1.4426950408889634f
 
 struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a tile
   uint32_t base;        // first slot of the list in cell_list (absolute)
   uint32_t len;         // records in the list
-  uint32_t sbase;       // first pixel-state slot (cstate): slot sbase + s - 1 holds the state before entry 64 s
+  uint32_t sbase;       // first pixel-state slot (cstate): slot sbase + s - 1 holds the state before entry HGS_SEGLEN * s
   uint32_t pbase;       // the TILE's first pair id
 };
 
@@ -137,6 +137,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* tile_n;
   uint32_t* tile_start;
   uint32_t* tile_order;
+  uint4* tile_rec;            // [B*T] by position in tile_order: (tile, entries, first entry, 0)
   uint32_t* hist;             // [B*nwg][T] per-workgroup tile histograms -> exclusive bases inside a row group
   uint32_t* tile_gbase;       // [HGS_ROW_GROUPS][B*T] absolute base of each row group in the tile's list
   uint32_t* tile_count;       // [B*T] global-atomic path only (T > 16384): counts, then fill cursor
@@ -152,7 +153,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first pair id) - what the pair reduction reads
   float* cstate;              // [C/4 + 1][6][16]
   uint4* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, entries, first cell-list slot, state slot or ~0): all a wave needs to start
-  uint32_t* n_contrib;        // [B][H*W]  1 + cell-list rank of the pixel's last contributor
+  uint32_t* n_contrib;        // [B][H*W]  1-based TILE-list position of the pixel's last contributor (upstream's meaning)
 };
 
 struct Cam {             // per-view constants (device pointers stay with the caller)

@@ -23,8 +23,8 @@
 //
 // Roofline: VALU issue (about 22 instructions per row iteration); a record is evaluated only in the cells
 // it can reach: 57 lane slots per tile entry instead of 256 (tools/cell_stats.py).  HBM traffic per tile
-// entry: 4 B index + 48 B gather per cell reached (L2-served), 24 B/pixel out, 24 B/pixel per 64 cell-list
-// entries of state.
+// entry: 4 B index + 48 B gather per cell reached (L2-served), 24 B/pixel out, 24 B/pixel per HGS_SEGLEN (128)
+// cell-list entries of state.
 #include "hgs_common.h"
 
 namespace {

@@ -74,6 +74,9 @@ struct DevState {
   int64_t calls = 0;
   int64_t retries = 0;        // forwards that had to be re-run (capacity or hint exceeded)
   int64_t wait_ns = 0;        // host time blocked in the per-forward status wait (diagnostic)
+  // host time per phase (diagnostic, bench.py): forward: checks + allocations | hgs_forward (launches) | autograd state
+  // in the shadow of the wait | the wait | after it; backward: before | hgs_backward (launches) | after
+  std::atomic<int64_t> host_ns[8] = {};
   std::mutex mu;
 };
 
@@ -203,6 +206,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                                double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
                                bool want_grad, int64_t batch, int64_t act) {
     (void)means2D;
+    const auto th0 = std::chrono::steady_clock::now();
     const c10::Device dev = means3D.device();
     if (!dev.is_cuda())
       throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device (torch device type 'cuda'); "
@@ -284,6 +288,8 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       volatile uint32_t* ready = &st.ring[slot].reserved[2];
       *ready = 0u;
       std::atomic_thread_fence(std::memory_order_seq_cst);
+      const auto th1 = std::chrono::steady_clock::now();
+      if (attempt == 0) st.host_ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(th1 - th0).count();
       const int rc = hgs_forward_batch_act(plan->settings.s.data(), (int32_t)B, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_),
                                            fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth),
                                            fptr_mut(alpha), P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom,
@@ -291,6 +297,8 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                                            /*status_event=*/nullptr, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(),
                                            (int32_t)act, stream);
       check_rc(rc, "hgs_forward_batch");
+      const auto th2 = std::chrono::steady_clock::now();
+      st.host_ns[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(th2 - th1).count();
       // `debug=True` is upstream's switch for surfacing device errors at the call that caused
       // them (std::runtime_error): synchronise and report
       if (debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer forward (debug=True)");
@@ -317,6 +325,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       // One host wait per forward, like upstream's blocking read of num_rendered - but only for the status: sort and
       // blend are already enqueued and keep the GPU busy while the host goes on to autograd and the backward launch.
       const auto tw = std::chrono::steady_clock::now();
+      st.host_ns[2] += std::chrono::duration_cast<std::chrono::nanoseconds>(tw - th2).count();
       for (uint64_t spins = 0; *ready == 0u; ++spins) {
         if ((spins & 0x3ff) == 0x3ff) {
           if (std::chrono::steady_clock::now() - tw > std::chrono::seconds(2)) {       // (a device error: surface it)
@@ -328,7 +337,9 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         }
       }
       std::atomic_thread_fence(std::memory_order_seq_cst);
-      st.wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw).count();
+      const int64_t waited = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw).count();
+      st.wait_ns += waited;
+      st.host_ns[3] += waited;
       h = st.ring[slot];
       if (!h.overflow) break;
       st.retries += 1;
@@ -361,10 +372,12 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       ctx->saved_data["plan"] = c10::IValue::make_capsule(plan);
     }
     ctx->mark_non_differentiable({radii});
+    st.host_ns[4] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - th0).count();   // whole forward()
     return {color, radii, depth, alpha};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto tb0 = std::chrono::steady_clock::now();
     auto it = ctx->saved_data.find("plan");
     if (it == ctx->saved_data.end() || it->second.isNone())
       throw std::runtime_error("humangaussian_amd: the rasterizer's backward state is gone (the forward ran without "
@@ -393,6 +406,7 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     Tensor scratch = at::empty({al256(hgs_bwd_scratch_bytes((int64_t)plan->status.num_rendered))},
                                at::TensorOptions().dtype(at::kByte).device(dev));
     plan->rows = static_cast<char*>(scratch.data_ptr());
+    const auto tb1 = std::chrono::steady_clock::now();
     const int rc = hgs_backward_batch_act(
         plan->settings.s.data(), plan->B, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_), fptr(ro_),
         fptr(cv_), plan->P > 0 ? radii.data_ptr<int32_t>() : nullptr, fptr(color), fptr(depth), fptr(alpha), fptr(gc),
@@ -400,10 +414,17 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
         fptr_mut(d_means2D), fptr_mut(d_sh), fptr_mut(d_cp), fptr_mut(d_opac), fptr_mut(d_sc), fptr_mut(d_ro),
         fptr_mut(d_cv), g_stage_bwd.empty() ? nullptr : g_stage_bwd.data(), plan->act, stream);
     check_rc(rc, "hgs_backward_batch");
+    const auto tb2 = std::chrono::steady_clock::now();
     if (plan->settings.s[0].debug) hip_ok(hipStreamSynchronize(stream), "device error in the rasterizer backward (debug=True)");
     variable_list out(22);
     out[0] = d_means3D; out[1] = d_means2D; out[2] = d_sh; out[3] = d_cp;
     out[4] = d_opac; out[5] = d_sc; out[6] = d_ro; out[7] = d_cv;
+    {
+      DevState& st = state_for(dev.index());
+      st.host_ns[5] += std::chrono::duration_cast<std::chrono::nanoseconds>(tb1 - tb0).count();
+      st.host_ns[6] += std::chrono::duration_cast<std::chrono::nanoseconds>(tb2 - tb1).count();
+      st.host_ns[7] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb0).count();   // whole backward()
+    }
     return out;
   }
 };
@@ -684,6 +705,12 @@ py::dict device_state(int64_t dev) {
   d["calls"] = st.calls;
   d["retries"] = st.retries;
   d["wait_ns"] = st.wait_ns;
+  {
+    static const char* names[8] = {"fwd_pre", "fwd_launch", "fwd_shadow", "fwd_wait", "fwd_total", "bwd_pre", "bwd_launch", "bwd_total"};
+    py::dict hn;
+    for (int i = 0; i < 8; ++i) hn[names[i]] = st.host_ns[i].load();
+    d["host_ns"] = hn;
+  }
   py::dict e;
   for (const auto& kv : st.est)
     e[py::make_tuple(std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first))] =

@@ -27,6 +27,8 @@ extern "C" {
 #endif
 
 #define HGS_MAX_VIEWS 16  /* views (cameras) one batched call can take */
+#define HGS_MAX_ENTRY_CAPACITY (1ll << 27)  /* entry ids travel in 27 bits: hgs_forward* / hgs_backward* return HGS_EINVAL for a larger
+                                               entry_capacity (134 M tile-list entries = ~45 GB of bin buffer per call) */
 
 #define HGS_OK 0
 #define HGS_EINVAL (-1)   /* bad argument (null pointer, negative size, ...) */

@@ -226,6 +226,37 @@ def test_long_tile_lists_sort_classes_and_early_termination(n):
     assert np.array_equal(ncon, aux["n_contrib"].numpy().astype(np.uint32))
 
 
+@pytest.mark.parametrize("case", ["equal_depths", "outlier"])
+def test_sort_with_degenerate_depth_distributions(case):
+    """The rank sort buckets a tile's keys by depth; a bucket of more than HGS_RANK_BUCKET_MAX (192) keys sends the tile
+    through the bitonic network instead.  `equal_depths`: 6 distinct positions x 250 copies (exact ties, broken by the
+    Gaussian index like upstream's stable radix sort); `outlier`: one far Gaussian stretches the depth range so that
+    the body of the list shares a few buckets.  Order-sensitive outputs (n_contrib exact, images) against the oracle."""
+    n = 1500
+    g = torch.Generator().manual_seed(17)
+    sc = make_scene(P=n, seed=123, H=32, W=48, spread=0.02, scale=0.01, dist=2.0)
+    if case == "equal_depths":
+        sc["means3D"] = sc["means3D"][torch.arange(n) % 6].clone()
+    else:
+        # one Gaussian far behind the cloud, on the camera axis (still inside the frustum, large enough to reach every tile)
+        cam_c = torch.as_tensor(sc["cam"].camera_center, dtype=torch.float32)
+        sc["means3D"][7] = cam_c + (sc["means3D"].mean(0) - cam_c) * 600.0
+        sc["scales"][7] = 30.0
+    sc["opacities"] = 0.02 + 0.3 * torch.rand(n, 1, generator=g)
+    rc = RawCall(sc, capacity=max(8 * n, 1 << 16))
+    assert rc.forward() == 0 and not rc.status[4]
+    oc, orad, od, oa, aux, _ = oracle_forward(sc)
+    assert torch.equal(rc.radii.cpu(), orad)
+    assert rc.status[6] > 700                                          # a list long enough to overflow a bucket
+    check_images(rc, oc, od, oa)
+    ncon = np.frombuffer(rc.img[: rc.H * rc.W * 4].cpu().numpy().tobytes(), dtype=np.uint32).reshape(rc.H, rc.W)
+    assert np.array_equal(ncon, aux["n_contrib"].numpy().astype(np.uint32))
+    grads = rand_grads(32, 48, seed=5)
+    got = rc.backward(*grads)
+    *_, ref = oracle_forward(sc, dtype=torch.float64, grads=grads)
+    check_grads(got, ref)
+
+
 @pytest.mark.parametrize("side", [1936, 2048, 2080])
 def test_very_large_images_bin_paths(side):
     """Tile-count regimes of the binning stage: T = 121^2 = 14641 (LDS histograms, scan without the
@@ -334,10 +365,9 @@ def test_sort_class_hint_violation_is_reported_and_valid_hint_is_exact():
 
 
 def test_long_list_paths_agree_bitwise():
-    """Long lists are blended in segments.  With no hint the segment transmittances come from the
-    hgs_k_fwd_segT pre-pass; with a hint <= 12 segments every segment recomputes its
-    predecessors itself.  Same arithmetic => same bits, forward and backward, and both match
-    the oracle."""
+    """The same deep lists (> 1024 entries: several pixel-state segments per cell list, four-records-per-iteration
+    forward for the long cells) with and without the caller's longest-list hint: the hint only decides which sort-class
+    kernels are launched, so outputs and gradients must agree bit for bit, and both match the oracle."""
     sc = make_scene(P=2600, seed=77, H=32, W=32, spread=0.02, scale=0.01, dist=2.0)
     g = torch.Generator().manual_seed(5)
     sc["opacities"] = 0.01 + 0.05 * torch.rand(2600, 1, generator=g)      # deep lists, late termination

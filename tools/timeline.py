@@ -1,7 +1,7 @@
 """Device timelines of the cell-row kernels.  Needs a -DHGS_TIMELINE build of the library:
   bash tools/mkvariant.sh timeline "-DHGS_TIMELINE"
   HGS_LIB=variants/timeline/libhgs_rast.so LD_PRELOAD=variants/timeline/libhgs_rast.so python tools/timeline.py   (GPU box)
-sort: phases per tile (keys | network | gather: records+masks | chunk scan | range allocation | cell lists);
+sort: phases per tile (ranks | records + masks | cell tables | range allocation | cell lists);
 forward: per wave start / end; backward: per group of four work items: wall start / end and cycles per phase."""
 import ctypes
 import faulthandler
@@ -91,14 +91,17 @@ ph = read(5)
 gp = read(2)
 ok = ph[:, 3] != 0
 n = ph[:, 3] & 0xffffffff
-print("\n== sort phases per tile (us): load keys | network | gather total || records+masks | chunk scan | allocation | cell lists")
+t0s = ph[ok, 0].min()
+print("\n== rank sort per tile (us; wave 0 of the tile's workgroup): total || ranks | records | tables | allocation | cell lists; "
+      "start after the first tile; tiles that took the network fallback")
 for lo, hi in ((1, 64), (64, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 4097)):
     m = ok & (n >= lo) & (n < hi)
     if m.any():
+        tot = (ph[m, 1] - ph[m, 0]) * TICK_US
         g = gp[m, 0]
-        sub = [((g >> (16 * i)) & 0xffff).mean() * TICK_US for i in range(4)]
-        print(f"  n in [{lo},{hi}): {int(m.sum())} tiles: load {ph[m, 0].mean() * TICK_US:.2f} | network {ph[m, 1].mean() * TICK_US:.2f} (max {ph[m, 1].max() * TICK_US:.2f}) | "
-              f"gather {ph[m, 2].mean() * TICK_US:.2f} (max {ph[m, 2].max() * TICK_US:.2f}) || " + " | ".join("%.2f" % x for x in sub))
+        sub = [((g >> (16 * i)) & 0xffff).mean() * TICK_US for i in range(4)] + [(gp[m, 1] & 0xffff).mean() * TICK_US]
+        print(f"  n in [{lo},{hi}): {int(m.sum())} tiles: total {tot.mean():.2f} (max {tot.max():.2f}) || " + " | ".join("%.2f" % x for x in sub)
+              + f" ; start p50 {np.percentile((ph[m, 0] - t0s) * TICK_US, 50):.1f} max {((ph[m, 0] - t0s) * TICK_US).max():.1f}; end max {((ph[m, 1] - t0s) * TICK_US).max():.1f}; fallback {int(ph[m, 2].sum())}")
 
 # ---- backward
 print('backward ...', flush=True)
