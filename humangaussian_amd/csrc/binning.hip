@@ -900,7 +900,12 @@ __device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad
 #define HGS_RANK_NB_MAX 2048
 // 256 threads: three workgroups per CU by LDS (45 KB each) are three waves per SIMD, which leaves a wave 168 VGPRs for
 // up to 16 keys + their ranks + the gathers in flight.  A typical tile (~440 entries) is two keys per thread.
+#ifndef HGS_SORT_NT
 #define HGS_SORT_NT 256
+#endif
+#ifndef HGS_SORT_WAVES_PER_EU
+#define HGS_SORT_WAVES_PER_EU 3
+#endif
 #ifndef HGS_RANK_PRIO
 #define HGS_RANK_PRIO 0
 #endif
@@ -1432,7 +1437,7 @@ __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, c
 }  // namespace
 
 static_assert(16 * HGS_SORT_NT >= 4096, "the rank sort takes every list of the LDS class");
-extern "C" __global__ void __launch_bounds__(HGS_SORT_NT) __attribute__((amdgpu_waves_per_eu(3, 3)))
+extern "C" __global__ void __launch_bounds__(HGS_SORT_NT) __attribute__((amdgpu_waves_per_eu(HGS_SORT_WAVES_PER_EU, HGS_SORT_WAVES_PER_EU)))
 hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
   __shared__ unsigned long long pairs[4096];
   __shared__ GatherLds<64> S;
