@@ -6,11 +6,15 @@
   `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`
   (one rank per GPU over RCCL); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
-A "step" = one pass of the hot path per rank: forward + backward of ONE 1024^2 view of the
-100k-Gaussian SMPL-X-like cloud through the reference-compatible API
-(GaussianRasterizer -> libhgs_rast.so), inputs resident in HBM, plus - for N>1 - the single
-all-gather of the per-rank gradient packs (view-parallel, weak scaling: one view per rank).
-value = P * N * K / t, t = max over ranks of the barrier-bracketed wall time of K steps.
+A "step" = one pass of the hot path per rank: forward + backward of V (--views-per-rank, default 1) 1024^2
+views of the 100k-Gaussian SMPL-X-like cloud, one after the other through the reference-compatible API
+(GaussianRasterizer -> libhgs_rast.so: the reference's loop, GaussianDreamer.py:244-266), inputs resident in
+HBM, plus - for N>1 - the all-gather of the per-rank gradient packs, one per ROUND of views (view-parallel, weak
+scaling), each overlapped with the render of the next round (view_parallel.py); with V = 1 there is one collective
+and nothing to hide it behind.
+value = P * V * N * K / t, t = max over ranks of the barrier-bracketed wall time of K steps.
+HGS_DIST_BACKEND=gloo + HGS_BENCH_SHARE_DEVICE=1 run the N > 1 branch with all ranks on ONE device (gloo stages the
+packs through the host): the configuration of tests/test_gpu_multirank_one_gpu.py, not a measurement.
 
 Extra objects on the JSON line:
   roofline      dominant kernel, timed live with HIP events recorded by the library on its launch stream
@@ -39,6 +43,17 @@ INIT_STEPS = 100               # un-timed first-use steps before the W warm-up s
 
 FWD_STAGES = ["preprocess_fwd", "tiles", "fill", "sort", "render_fwd"]
 BWD_STAGES = ["render_bwd", "pair_reduce", "preprocess_bwd"]
+# upstream's stages: B1 = the blend backward = render_bwd + pair_reduce here
+ROOFLINE_STAGES = {"preprocess_fwd": ["preprocess_fwd"], "tiles": ["tiles"], "fill": ["fill"], "sort": ["sort"],
+                   "render_fwd": ["render_fwd"], "blend_bwd(render_bwd+pair_reduce)": ["render_bwd", "pair_reduce"],
+                   "preprocess_bwd": ["preprocess_bwd"]}
+
+
+def path_bytes_survey(P, M, R, npix, T, B=1, forward_only=False):
+    """SURVEY.md 8(d) / BASELINE.md 3: algorithmic bytes of the whole path per view."""
+    if forward_only:
+        return B * (P * (120 + 12 * M) + 24 * npix + 8 * T) + 80 * R
+    return B * (P * (292 + 36 * M) + 52 * npix + 8 * T) + 164 * R
 
 
 def algorithmic_bytes(stage, P, M, R, npix, T, B=1):
@@ -81,6 +96,10 @@ def main():
     ap.add_argument("--variant", default="mid", choices=["mid", "init"])
     ap.add_argument("--views", type=int, default=1,
                     help="views per rank per step rendered by ONE batched call (extra measurement when > 1)")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="views per rank per step rendered ONE AFTER THE OTHER (the reference's loop); with N > 1 the "
+                         "collective of round k runs under the render of round k + 1")
+    ap.add_argument("--init-steps", type=int, default=INIT_STEPS, help="un-timed first-use steps before the warm-up")
     ap.add_argument("--collective", default="auto", choices=["auto", "allgather", "scatter"],
                     help="N > 1: how the per-rank gradient packs are reduced (view_parallel.allgather_reduce); auto times "
                          "both outside the timed region and uses the faster one")
@@ -102,12 +121,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("HGS_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("HGS_BENCH_SHARE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    VPR = max(1, args.views_per_rank)
+    assert not (VPR > 1 and args.views > 1), "--views (batched call) and --views-per-rank (sequential calls) exclude each other"
+
+    def max_over_ranks(values):
+        t = torch.tensor(values, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
 
     def camera(i):
         return synth.orbit_camera(10.0, 30.0 + 45.0 * i, 1.75, 55.0, RES, RES)
@@ -120,12 +151,15 @@ def main():
     class Workload:
         """One rank's step: `views` views of a `P`-Gaussian cloud, fwd (+bwd), single or batched call."""
 
-        def __init__(self, P, sh_degree, variant, views, forward_only, first_view):
+        def __init__(self, P, sh_degree, variant, views, forward_only, first_view, seq_views=1, collectives=True):
             self.P, self.sh_degree, self.views, self.forward_only = P, sh_degree, views, forward_only
+            self.seq_views, self.collectives = seq_views, collectives
             cloud = synth.init_cloud(P, sh_degree, variant, seed=0)
             self.cloud = cloud
             self.M = cloud.shs.shape[1]
-            self.cams = [camera(first_view + i) for i in range(views)]
+            # sequential mode: round j of the step = global views j * world + rank (view_parallel's round-robin)
+            self.cams = [camera(first_view + i) for i in range(views)] if seq_views == 1 else \
+                [camera(j * world + rank) for j in range(seq_views)]
             self.leaves = {k: getattr(cloud, k).to(dev).requires_grad_(True)
                            for k in ("means3D", "shs", "opacities", "scales", "rotations")}
             bg = torch.zeros(3, device=dev)
@@ -133,6 +167,7 @@ def main():
                 RES, RES, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), bg, 1.0, c.world_view_transform.to(dev),
                 c.full_proj_transform.to(dev), sh_degree, c.camera_center.to(dev), False, False) for c in self.cams]
             self.rast = GaussianRasterizer(self.rs[0])
+            self.rasts = [GaussianRasterizer(r) for r in self.rs]
             g = torch.Generator().manual_seed(1 + first_view)
             shp = (views,) if views > 1 else ()
             self.gc = (torch.randn(shp + (3, RES, RES), generator=g) * 1e-3).to(dev)
@@ -148,6 +183,8 @@ def main():
                                                          L["scales"], L["rotations"], None, self.rs)[0]
                     return self.rast(means3D=L["means3D"], means2D=L["means3D"], shs=L["shs"], opacities=L["opacities"],
                                      scales=L["scales"], rotations=L["rotations"])[0]
+            if self.seq_views > 1 or (world > 1 and self.views == 1):
+                return self.step_rounds()
             for t in L.values():
                 t.grad = None
             if self.views > 1:
@@ -155,7 +192,7 @@ def main():
                 color, radii, depth, alpha = rasterize_gaussians_batch(
                     L["means3D"], means2D, L["shs"], None, L["opacities"], L["scales"], L["rotations"], None, self.rs)
             else:
-                means2D = torch.zeros_like(L["means3D"], requires_grad=True)
+                means2D = torch.empty_like(L["means3D"]).requires_grad_(True)      # (never read by the kernels: no fill launch)
                 color, radii, depth, alpha = self.rast(
                     means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
                     rotations=L["rotations"])
@@ -167,7 +204,34 @@ def main():
                 return vp.allgather_reduce(vp.pack_contribution(grads, rad), mode=collective_mode[0])
             return means2D.grad
 
-        def timed(self, steps, warmup, init_steps=INIT_STEPS):
+        def step_rounds(self):
+            """The reference's loop over the rank's views; N > 1: one all-gather per round, in flight under the next round."""
+            L = self.leaves
+            total, pending = None, None
+            for j in range(self.seq_views):
+                for t in L.values():
+                    t.grad = None
+                means2D = torch.empty_like(L["means3D"]).requires_grad_(True)
+                color, radii, depth, alpha = self.rasts[j](
+                    means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
+                    rotations=L["rotations"])
+                torch.autograd.backward([color, depth, alpha], [self.gc, self.gd, self.ga])
+                if world > 1 and self.collectives:
+                    grads = {k: L[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+                    grads["means2D"] = means2D.grad
+                    pack = vp.pack_contribution(grads, radii)
+                    if self.seq_views == 1:
+                        return vp.allgather_reduce(pack, mode=collective_mode[0])
+                    started = vp.PackGather(pack, async_op=True)
+                    if pending is not None:
+                        total = vp.reduce_gathered(pending.result(), total)
+                    pending = started
+            if pending is not None:
+                total = vp.reduce_gathered(pending.result(), total)
+            return total if total is not None else means2D.grad
+
+        def timed(self, steps, warmup, init_steps=None):
+            init_steps = args.init_steps if init_steps is None else init_steps
             # first-use initialisation, not part of W: the rasterizer's decaying capacity / longest-list
             # estimates settle over the first calls (retries, buffer growth), the GPU leaves its idle clocks
             for _ in range(init_steps):
@@ -182,9 +246,7 @@ def main():
             fence()
             elapsed = time.perf_counter() - t0
             if world > 1:
-                tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                elapsed = float(tt.item())
+                elapsed = max_over_ranks([elapsed])[0]
             return elapsed
 
         def stage_times(self, nprof=20):
@@ -209,7 +271,7 @@ def main():
 
     P, sh_degree = args.points, args.sh_degree
     collective_mode = [args.collective if args.collective != "auto" else "allgather"]
-    main_wl = Workload(P, sh_degree, args.variant, args.views, args.forward_only, first_view=rank * args.views)
+    main_wl = Workload(P, sh_degree, args.variant, args.views, args.forward_only, first_view=rank * args.views, seq_views=VPR)
 
     # ---------------- N > 1: what the collective of a step costs, per mode (OUTSIDE the timed region);
     # --collective auto then runs the timed steps with the faster mode (every rank takes the same decision)
@@ -235,15 +297,23 @@ def main():
                 if it >= 5:
                     acc[0] += ev[0].elapsed_time(ev[1])
                     acc[1] += ev[1].elapsed_time(ev[2])
-            tt = torch.tensor(acc, dtype=torch.float64, device=dev) / nrep * 1e3
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            res[mode] = {"pack_us": float(tt[0]), "collective_and_reduce_us": float(tt[1])}
+            tt = max_over_ranks([a / nrep * 1e3 for a in acc])
+            res[mode] = {"pack_us": tt[0], "collective_and_reduce_us": tt[1]}
         if args.collective == "auto":
             collective_mode[0] = min(vp.COLLECTIVE_MODES, key=lambda m: res[m]["collective_and_reduce_us"])
-        collective = {"mode_used": collective_mode[0], "requested": args.collective, "timings": res,
-                      # nothing in a one-view-per-rank step can run beside the collective (the per-Gaussian backward
-                      # that produces the gradients is the last kernel of the step): all of it is exposed
-                      "exposed_collective_us": res[collective_mode[0]]["pack_us"] + res[collective_mode[0]]["collective_and_reduce_us"],
+        # what the collectives ADD to a step, measured: the same step with and without them (outside the timed region),
+        # for one view per rank (nothing to overlap: the per-Gaussian backward that produces the gradients is the last
+        # kernel of the step) and for two (round 0's all-gather runs under round 1's render)
+        exposed = {}
+        ksteps = max(10, args.steps // 10)
+        for vpr in (1, 2):
+            t_with = Workload(P, sh_degree, args.variant, 1, False, 0, seq_views=vpr).timed(ksteps, 3, init_steps=min(args.init_steps, 20))
+            t_wo = Workload(P, sh_degree, args.variant, 1, False, 0, seq_views=vpr, collectives=False).timed(ksteps, 3, init_steps=min(args.init_steps, 20))
+            exposed[f"views_per_rank_{vpr}"] = {"step_us_with": t_with / ksteps * 1e6, "step_us_without": t_wo / ksteps * 1e6,
+                                                "exposed_collective_us": (t_with - t_wo) / ksteps * 1e6}
+        collective = {"mode_used": collective_mode[0] if VPR == 1 else "allgather per round, pipelined", "requested": args.collective,
+                      "backend": backend, "views_per_rank": VPR, "timings": res, "exposed": exposed,
+                      "exposed_collective_us": exposed[f"views_per_rank_{min(VPR, 2)}"]["exposed_collective_us"],
                       "bytes_per_rank_pack": int(pack.numel() * 4),
                       "note": "allgather = ONE all_gather_into_tensor of the per-rank gradient packs + rank-ordered local "
                               "reduction; scatter = all_to_all of row shards + the same local reduction + one all-gather of "
@@ -251,6 +321,7 @@ def main():
                               "world-1); timed outside the step loop, max over ranks"}
 
     elapsed = main_wl.timed(args.steps, args.warmup)
+    ms = elapsed / args.steps * 1e3
     M = main_wl.M
 
     # ---------------- host/GPU balance (outside the timed region): time the host spends blocked
@@ -279,22 +350,35 @@ def main():
     R = int(_rast._state(dev).max_R)
     npix, T = RES * RES, (RES // 16) ** 2
     B = args.views
-    dom = max(stage_us, key=stage_us.get)
-    dom_bytes = algorithmic_bytes(dom, P, M, R, npix, T, B)
-    achieved = dom_bytes / (stage_us[dom] * 1e-6) / 1e9
+    # upstream's stages: the blend backward (B1) is render_bwd + pair_reduce here, priced together
+    merged_us = {name: sum(stage_us[k] for k in parts) for name, parts in ROOFLINE_STAGES.items()
+                 if not (args.forward_only and any(k in BWD_STAGES for k in parts))}
+    merged_bytes = {name: sum(algorithmic_bytes(k, P, M, R, npix, T, B) for k in ROOFLINE_STAGES[name]) for name in merged_us}
+    merged_bytes["blend_bwd(render_bwd+pair_reduce)"] = 84 * R + 28 * npix * B       # (B1 = 84 R + 28 N_pix)
+    dom = max(merged_us, key=merged_us.get)
+    dom_bytes = merged_bytes[dom]
+    achieved = dom_bytes / (merged_us[dom] * 1e-6) / 1e9
     # HBM-side bytes of the dominant kernel from the committed PMC passes (tools/profile_round.sh), with the commit
     # they were taken at: the two must be read together (the counters cannot be collected inside this process)
     traffic, traffic_commit = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    counters = None
     if os.path.exists(tpath) and B == 1:
         try:
             tj = json.load(open(tpath))
-            traffic, traffic_commit = tj.get(dom), tj.get("_commit")
+            parts = [tj.get(k) for k in ROOFLINE_STAGES[dom]]
+            traffic, traffic_commit = (sum(parts) if all(x is not None for x in parts) else None), tj.get("_commit")
         except Exception:
             traffic = None
-    path_bytes = sum(algorithmic_bytes(k, P, M, R, npix, T, B) for k in stage_us if not (args.forward_only and k in BWD_STAGES))
+    cpath = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if os.path.exists(cpath) and B == 1:
+        try:
+            counters = json.load(open(cpath))         # committed SQ-counter passes (tools/sq_pass.sh) -> VALU busy per blend kernel
+        except Exception:
+            counters = None
+    path_bytes = path_bytes_survey(P, M, R, npix, T, B, args.forward_only)
     gpu_us = sum(stage_us.values())
-    blend_us = stage_us["render_fwd"] + (0.0 if args.forward_only else stage_us.get("render_bwd", 0.0))
+    blend_us = stage_us["render_fwd"] + (0.0 if args.forward_only else stage_us.get("render_bwd", 0.0) + stage_us.get("pair_reduce", 0.0))
 
     # ---------------- extra measurements of the same path (rank 0, N=1 only; same timing rules)
     extra = None
@@ -356,41 +440,46 @@ def main():
                          f"torch {torch.__version__}"}
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
         flops_pair = 25 if args.forward_only else 105
         line = {
             "metric": "rasterize fwd+bwd Gaussians/sec @1024^2, 100k pts" if not args.forward_only
             else "rasterize fwd-only Gaussians/sec @1024^2 (extra measurement)",
-            "value": P * args.views * world * args.steps / elapsed,
+            "value": P * args.views * VPR * world * args.steps / elapsed,
             "unit": "Gaussians/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": INIT_STEPS,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": args.init_steps,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {P} SMPL-X-like Gaussians ({args.variant}-training state, SH degree "
                                    f"{sh_degree}; a capsule humanoid with SMPL-X extents, NOT load/shapes/human.obj - "
-                                   f"R lies inside SURVEY App. B's range), {args.views} 1024x1024 orbit view(s) per GPU per step"
+                                   f"R lies inside SURVEY App. B's range), {args.views * VPR} 1024x1024 orbit view(s) per GPU per step"
                                    + (" in ONE batched call" if args.views > 1 else "")
+                                   + (" one after the other (the reference's loop)" if VPR > 1 else "")
                                    + " (elev 10, azim 30+45*view, dist 1.75, fovy 55), "
                                    + ("fwd only" if args.forward_only else "fwd+bwd"),
-                       "views_per_step": world * args.views, "num_rendered_R": int(R),
+                       "views_per_step": world * args.views * VPR, "views_per_rank_sequential": VPR, "num_rendered_R": int(R),
                        "host_mode": "sync (one host wait per forward for the device-side status, as upstream)",
                        "parallelism": f"view-parallel x{world}" + (f", collective {collective_mode[0]}" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": {"file": "profiles/pmc_traffic.json", "commit": traffic_commit},
-                         "algorithmic_bytes": dom_bytes, "avg_us": stage_us[dom],
-                         "note": "blend kernels are VALU / LDS / MFMA-issue-bound (the backward's pixel sums run on fp32 MFMA); "
-                                 "HBM fraction reported as BASELINE.json asks",
-                         "path": {"algorithmic_bytes": path_bytes, "gpu_us_sum": gpu_us,
-                                  "achieved": path_bytes / (gpu_us * 1e-6) / 1e9,
-                                  "frac": path_bytes / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                         # secondary roofline: 256 R pixel-Gaussian pairs, ~25 flop
-                         # forward + ~80 flop backward per pair, against the fp32 vector/MFMA peak
-                         "fp32": {"algorithmic_flops": 256.0 * R * flops_pair,
-                                  "achieved_tflops": 256.0 * R * flops_pair / (blend_us * 1e-6) / 1e12,
-                                  "peak_tflops": 157.3,
-                                  "frac": 256.0 * R * flops_pair / (blend_us * 1e-6) / 1e12 / 157.3,
-                                  "kernels": "render_fwd + render_bwd"}},
+                         "algorithmic_bytes": dom_bytes, "avg_us": merged_us[dom],
+                         "note": "stage = upstream's stage (B1 = render_bwd + pair_reduce); blend kernels are VALU / LDS / "
+                                 "MFMA-issue-bound (the backward's pixel sums run on fp32 MFMA); HBM fraction reported as "
+                                 "BASELINE.json asks",
+                         # the whole path: SURVEY.md 8(d)'s byte formula over the WALL time of a step (not the event sum)
+                         "path": {"algorithmic_bytes": path_bytes, "ms_per_step": ms, "stage_event_us_sum": gpu_us,
+                                  "achieved": path_bytes / (ms * 1e-3) / 1e9 / max(1, VPR),
+                                  "frac": path_bytes / (ms * 1e-3) / 1e9 / max(1, VPR) / HBM_PEAK_GBS},
+                         # how much faster than UPSTREAM'S BRUTE FORCE (256 pixel-Gaussian pairs per entry, ~25 flop forward
+                         # + ~80 backward) the blend stages run, expressed against the fp32 vector peak.  NOT a utilisation:
+                         # the kernels evaluate ~57 lane slots per entry, not 256 (see valu_busy for what the pipes do)
+                         "brute_force_equivalent": {"flops": 256.0 * R * flops_pair,
+                                                    "tflops": 256.0 * R * flops_pair / (blend_us * 1e-6) / 1e12,
+                                                    "of_fp32_vector_peak_157.3": 256.0 * R * flops_pair / (blend_us * 1e-6) / 1e12 / 157.3,
+                                                    "kernels": "render_fwd + render_bwd + pair_reduce"},
+                         # counter-derived (committed profiles/sq_counters.json: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x
+                         # 2.4 GHz x kernel time)); live lanes: 34 contributing pixels per 57 evaluated lane slots per entry
+                         "valu_busy": (counters or {}).get("valu_busy"), "live_lane_fraction": 34.0 / 57.0},
             "stage_us": stage_us,
             "host": host_info,
             "collective": collective,

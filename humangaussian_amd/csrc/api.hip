@@ -260,17 +260,22 @@ int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
   return HGS_OK;
 }
 
-int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gathered, float* out,
-                          void* stream_) {
+int hgs_reduce_view_packs_acc(int32_t world, int64_t P, int32_t F, const float* gathered, const float* acc_in,
+                              float* out, void* stream_) {
   if (world < 1 || P < 0 || F < 1) return HGS_EINVAL;
   if (P == 0) return HGS_OK;
   if (!gathered || !out) return HGS_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const long long n = (long long)P * F;
   hipLaunchKernelGGL(hgs_k_reduce_view_packs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                     (int)world, n, (int)F, gathered, out);
+                     (int)world, n, (int)F, gathered, acc_in, out);
   HGS_LAUNCH_CHECK();
   return HGS_OK;
+}
+
+int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gathered, float* out,
+                          void* stream_) {
+  return hgs_reduce_view_packs_acc(world, P, F, gathered, nullptr, out, stream_);
 }
 
 int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, const float* g_means2D,
@@ -288,7 +293,7 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 11; }
+int hgs_abi_version(void) { return 12; }
 
 size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t H, int32_t W) {
   if (B < 1 || B > HGS_MAX_VIEWS || P < 0 || H <= 0 || W <= 0) return 0;

@@ -15,6 +15,11 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#ifndef __HIPCC__
+#include <algorithm>
+using std::max;
+using std::min;
+#endif
 
 #ifndef HGS_HD
 #ifdef __HIPCC__
@@ -27,11 +32,24 @@
 #define HGS_CELL 4              // pixels per cell edge
 #define HGS_CELLS_PER_TILE 16
 
+// ca cc - cb^2 with ONE rounding error (Kahan's difference of products): for a very elongated Gaussian the plain fp32
+// expression cancels - at an anisotropy of 1e-3 it lost every digit, the ellipse's extents came out too small and cleared
+// bits hid live pixels (found by brute force at sigma_major ~ 1000 px).
+HGS_HD float hgs_conic_det(float ca, float cb, float cc) {
+  const float w = cb * cb;
+  const float e = fmaf(-cb, cb, w);                     // w - cb^2, exactly
+  return fmaf(ca, cc, -w) + e;
+}
+// what the compensated determinant cannot repair (|det| within a few ulp of ca cc: anisotropy beyond ~3e-4): never cull
+HGS_HD bool hgs_conic_cullable(float ca, float cc, float det) {
+  return det > 0.0f && ca > 0.0f && cc > 0.0f && det > 1e-6f * (ca * cc);
+}
+
 HGS_HD uint32_t hgs_cell_mask(float mx, float my, float ca, float cb, float cc, float op, float x0, float y0) {
   const float a255 = 255.0f * op;
   if (!(a255 >= 0.999f)) return 0u;                     // alpha <= op < 1/255 everywhere
-  const float det = ca * cc - cb * cb;
-  if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return 0xffffu;   // degenerate conic: never cull
+  const float det = hgs_conic_det(ca, cb, cc);
+  if (!hgs_conic_cullable(ca, cc, det)) return 0xffffu; // degenerate / extremely elongated conic: never cull
   const float tau = 2.0f * logf(fmaxf(a255, 1.0f)) * 1.002f + 0.03f;
   const float idet = 1.0f / det;
   const float ex = sqrtf(tau * cc * idet), ey = sqrtf(tau * ca * idet);   // half extents of the ellipse
@@ -57,39 +75,26 @@ HGS_HD uint32_t hgs_cell_mask(float mx, float my, float ca, float cb, float cc, 
   return mask;
 }
 
-// Tile-level version of the same test: can the Gaussian reach alpha >= 1/255 anywhere on the tile's 16 x 16 pixel
-// centres?  Exact minimum of q over the rectangle (the minimum of a convex quadratic over a box is 0 if the centre is
-// inside, else it lies on an edge, where the free coordinate's optimum is the clamped 1-D minimiser), with the same
-// inflated tau as hgs_cell_mask and the rectangle grown by the same eps: a SUPERSET of "hgs_cell_mask != 0".
-// The binning stage drops (Gaussian, tile) pairs that fail it (22 % of upstream's entries on an avatar): they
-// cannot change any pixel.  Evaluated from the GeomRec fields by preprocess_fwd (count), fill (scatter) and
-// preprocess_bwd (which rows exist): the same inputs, the same decision.
-HGS_HD bool hgs_tile_hit(float mx, float my, float ca, float cb, float cc, float op, float x0, float y0) {
+// The tile rect that gets list entries: upstream's rect (a 3-sigma circle of the larger eigenvalue, [tmin, tmax) in tile
+// units, passed in) cut down to the tiles that the axis-aligned box of the ellipse  q(d) <= tau  can touch - only inside
+// that ellipse can a pixel reach alpha >= 1/255, so the dropped (Gaussian, tile) pairs cannot change any pixel (19-22 %
+// of upstream's entries on an avatar: flat and faint Gaussians).  Same margins and the same determinant as the cell
+// mask; used by hgs_k_preprocess_fwd and, compiled for the host, by tests/test_cellmask_cpu.py.
+HGS_HD void hgs_alpha_rect(float mx, float my, float ca, float cb, float cc, float op, int& tminx, int& tminy, int& tmaxx,
+                           int& tmaxy) {
   const float a255 = 255.0f * op;
-  if (!(a255 >= 0.999f)) return false;
-  const float det = ca * cc - cb * cb;
-  if (!(det > 0.0f && ca > 0.0f && cc > 0.0f)) return true;
-  const float tau = 2.0f * logf(fmaxf(a255, 1.0f)) * 1.002f + 0.03f;
-  const float eps = 4e-3f;
-  const float xa = x0 - eps, xb = x0 + 15.0f + eps, ya = y0 - eps, yb = y0 + 15.0f + eps;
-  const float bc = cb / cc, ba = cb / ca;
-  float best;
-  {
-    const float dx = fminf(fmaxf(mx, xa), xb) - mx, dy = fminf(fmaxf(my, ya), yb) - my;      // 0 when the centre is inside
-    best = ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy;
+  const float qdet = hgs_conic_det(ca, cb, cc);
+  if (!(a255 >= 0.999f)) {
+    tmaxx = tminx; tmaxy = tminy;                        // alpha <= op < 1/255 everywhere
+  } else if (hgs_conic_cullable(ca, cc, qdet)) {
+    const float tau = 2.0f * logf(fmaxf(a255, 1.0f)) * 1.002f + 0.03f;
+    const float ex = sqrtf(tau * cc / qdet) * 1.0005f + 4e-3f, ey = sqrtf(tau * ca / qdet) * 1.0005f + 4e-3f;
+    // tile t holds the pixel centres 16 t .. 16 t + 15
+    tminx = max(tminx, (int)ceilf((mx - ex - 15.0f) * 0.0625f));
+    tminy = max(tminy, (int)ceilf((my - ey - 15.0f) * 0.0625f));
+    tmaxx = min(tmaxx, (int)floorf((mx + ex) * 0.0625f) + 1);
+    tmaxy = min(tmaxy, (int)floorf((my + ey) * 0.0625f) + 1);
+    if (tmaxx < tminx) tmaxx = tminx;
+    if (tmaxy < tminy) tmaxy = tminy;
   }
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    {  // vertical edges x = xa / xb
-      const float dx = (e ? xb : xa) - mx;
-      const float dy = fminf(fmaxf(my - bc * dx, ya), yb) - my;
-      best = fminf(best, ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy);
-    }
-    {  // horizontal edges y = ya / yb
-      const float dy = (e ? yb : ya) - my;
-      const float dx = fminf(fmaxf(mx - ba * dy, xa), xb) - mx;
-      best = fminf(best, ca * dx * dx + 2.0f * cb * dx * dy + cc * dy * dy);
-    }
-  }
-  return best <= tau * 1.0005f + 1e-3f * best;
 }

@@ -56,12 +56,13 @@ hgs_k_knn3(int P, const float* __restrict__ pts, float* __restrict__ out) {
 // kernels launched from a Python loop (host-bound: ~25 us per rank).
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_reduce_view_packs(int world, long long n, int F, const float* __restrict__ gathered,
-                        float* __restrict__ out) {
+                        const float* __restrict__ acc_in, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const bool is_max = (int)(i % F) == F - 1;
-  float acc = gathered[i];
-  for (int r = 1; r < world; ++r) {
+  // one left-to-right chain: (running total of the earlier collectives of the step) + rank 0 + rank 1 + ...
+  float acc = acc_in ? acc_in[i] : gathered[i];
+  for (int r = acc_in ? 0 : 1; r < world; ++r) {
     const float x = gathered[(long long)r * n + i];
     acc = is_max ? fmaxf(acc, x) : acc + x;
   }

@@ -236,28 +236,10 @@ __device__ __forceinline__ uint32_t preprocess_one(
   rec.ca = pj.c * det_inv; rec.cb = -pj.b * det_inv; rec.cc = pj.a * det_inv;
   rec.op = act_opacity(opacities[i], v.act);
   rec.depth = pj.tz;
-  // The tile rect that gets list entries: upstream's rect (a 3-sigma circle of the larger eigenvalue) cut down to the
-  // tiles that the axis-aligned box of the ellipse  q(d) <= tau = 2 ln(255 op)  can touch - only inside that ellipse can
-  // a pixel reach alpha >= 1/255, so the dropped (Gaussian, tile) pairs cannot change any pixel (19-22 % of upstream's
-  // entries on an avatar: flat and faint Gaussians).  Margins as in cellmask.h; radii / visibility stay upstream's.
+  // The tile rect that gets list entries: upstream's rect cut down to the box of the alpha >= 1/255 ellipse (cellmask.h);
+  // radii / visibility stay upstream's.
   int tminx = rminx, tminy = rminy, tmaxx = rmaxx, tmaxy = rmaxy;
-  {
-    const float a255 = 255.0f * rec.op;
-    const float qa = rec.ca, qb = rec.cb, qc = rec.cc, qdet = qa * qc - qb * qb;
-    if (!(a255 >= 0.999f)) {
-      tmaxx = tminx; tmaxy = tminy;                    // alpha <= op < 1/255 everywhere
-    } else if (qdet > 0.0f && qa > 0.0f && qc > 0.0f) {
-      const float tau = 2.0f * logf(fmaxf(a255, 1.0f)) * 1.002f + 0.03f;
-      const float ex = sqrtf(tau * qc / qdet) * 1.0005f + 4e-3f, ey = sqrtf(tau * qa / qdet) * 1.0005f + 4e-3f;
-      // tile t holds the pixel centres 16 t .. 16 t + 15
-      tminx = max(tminx, (int)ceilf((mx - ex - 15.0f) * 0.0625f));
-      tminy = max(tminy, (int)ceilf((my - ey - 15.0f) * 0.0625f));
-      tmaxx = min(tmaxx, (int)floorf((mx + ex) * 0.0625f) + 1);
-      tmaxy = min(tmaxy, (int)floorf((my + ey) * 0.0625f) + 1);
-      if (tmaxx < tminx) tmaxx = tminx;
-      if (tmaxy < tminy) tmaxy = tminy;
-    }
-  }
+  hgs_alpha_rect(mx, my, rec.ca, rec.cb, rec.cc, rec.op, tminx, tminy, tmaxx, tmaxy);
   rec.rect_lo = (uint32_t)tminx | ((uint32_t)tminy << 16);
   rec.rect_hi = (uint32_t)tmaxx | ((uint32_t)tmaxy << 16);
   rec.radius = (int)radf;

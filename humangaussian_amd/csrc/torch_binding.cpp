@@ -539,18 +539,25 @@ Tensor pack_view_contribution(const Tensor& g_means3D, const Tensor& g_means2D, 
   return out;
 }
 
-// view-parallel reduction of the all-gathered packs: (world, P, F) -> (P, F)
-Tensor reduce_view_packs(const Tensor& gathered) {
+// view-parallel reduction of the all-gathered packs: (world, P, F) [+ the running total (P, F) of the step's earlier
+// collectives] -> (P, F), one left-to-right chain
+Tensor reduce_view_packs(const Tensor& gathered, const c10::optional<Tensor>& acc_in) {
   at::NoGradGuard ng;
   const c10::Device dev = gathered.device();
   if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
   if (gathered.dim() != 3) throw std::runtime_error("gathered packs must have dimensions (world, num_points, F)");
   DeviceSwitch guard(dev.index());
   const Tensor g = f32c(gathered, dev, "gathered");
+  Tensor a;
+  if (acc_in.has_value() && acc_in->defined()) {
+    a = f32c(*acc_in, dev, "running total");
+    if (a.numel() != g.size(1) * g.size(2)) throw std::runtime_error("running total must have dimensions (num_points, F)");
+  }
   Tensor out = at::empty({g.size(1), g.size(2)}, g.options());
-  const int rc = hgs_reduce_view_packs((int32_t)g.size(0), g.size(1), (int32_t)g.size(2), g.data_ptr<float>(),
-                                       out.data_ptr<float>(), c10::hip::getCurrentHIPStream(dev.index()).stream());
-  check_rc(rc, "hgs_reduce_view_packs");
+  const int rc = hgs_reduce_view_packs_acc((int32_t)g.size(0), g.size(1), (int32_t)g.size(2), g.data_ptr<float>(),
+                                           a.defined() ? a.data_ptr<float>() : nullptr, out.data_ptr<float>(),
+                                           c10::hip::getCurrentHIPStream(dev.index()).stream());
+  check_rc(rc, "hgs_reduce_view_packs_acc");
   return out;
 }
 
@@ -727,7 +734,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize_batch", &rasterize_batch, py::call_guard<py::gil_scoped_release>());
   m.def("mark_visible", &mark_visible, py::call_guard<py::gil_scoped_release>());
   m.def("knn_mean_dist2", &knn_mean_dist2, py::call_guard<py::gil_scoped_release>());
-  m.def("reduce_view_packs", &reduce_view_packs, py::call_guard<py::gil_scoped_release>());
+  m.def("reduce_view_packs", &reduce_view_packs, py::arg("gathered"), py::arg("acc_in") = py::none(),
+        py::call_guard<py::gil_scoped_release>());
   m.def("pack_view_contribution", &pack_view_contribution, py::call_guard<py::gil_scoped_release>());
   m.def("densify_stats", &densify_stats, py::call_guard<py::gil_scoped_release>());
   m.def("densify_masks", &densify_masks, py::call_guard<py::gil_scoped_release>());

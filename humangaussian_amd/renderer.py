@@ -53,13 +53,17 @@ def _tan_half(fov):
     return math.tan(float(fov) * 0.5)
 
 
-def _screenspace_points(xyz):
-    pts = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        pts.retain_grad()
-    except Exception:
-        pass
-    return pts
+# The reference creates `screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0` per view
+# (gaussian_renderer/__init__.py:26): a fill AND an add kernel on the stream in front of every forward, for a tensor whose
+# VALUES nothing reads - the rasterizer only routes dL/dmeans2D into its `.grad` (GaussianDreamer.py:385-387).  Here it is
+# an uninitialised leaf: no kernel at all.  Set ZERO_SCREENSPACE_POINTS = True for callers that read the values.
+ZERO_SCREENSPACE_POINTS = False
+
+
+def _screenspace_points(xyz, views=None):
+    shape = tuple(xyz.shape) if views is None else (int(views),) + tuple(xyz.shape)
+    make = torch.zeros if ZERO_SCREENSPACE_POINTS else torch.empty
+    return make(shape, dtype=xyz.dtype, device=xyz.device).requires_grad_(True)
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
@@ -220,11 +224,7 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_mo
     cams = list(viewpoint_cameras)
     xyz = pc.get_xyz
     B, P = len(cams), xyz.shape[0]
-    screenspace_points = torch.zeros((B, P, 3), dtype=xyz.dtype, device=xyz.device, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    screenspace_points = _screenspace_points(xyz, views=B)
     bg_color = bg_color.to(xyz.device)
     settings = [GaussianRasterizationSettings(
         image_height=int(c.image_height), image_width=int(c.image_width),

@@ -14,6 +14,15 @@ bit-identical on every rank and independent of arrival order.
 
 A direct all-gather of a 6.8 MB pack rides the 7 point-to-point xGMI links in parallel
 (about 45 us at 153 GB/s per link) - a ring all-reduce would be per-link bound.
+
+With MORE than one view per rank the step is a pipeline (`render_views_parallel(..., pipeline=True)`,
+the default then): round j = the views j*G .. j*G+G-1, one per rank; its packs are gathered by an
+ASYNCHRONOUS collective (RCCL's own stream) while the ranks render round j+1, and the rounds are
+chained by `reduce_gathered(gathered, acc_in=total)`:  total = ((total + rank 0) + rank 1) + ... -
+exactly the left-to-right sum over the views in VIEW ORDER that the reference's serial loop forms
+(GaussianDreamer.py:244-266, 385-391), bit for bit, on every rank.  Only the last round's
+collective is exposed; with one view per rank there is nothing to hide it behind.
+
 The rasterizer is passed in (`render_fn`) so the host logic is testable without a GPU;
 the default is the HIP rasterizer and there is no CPU fallback in the product path.
 """
@@ -56,27 +65,57 @@ def unpack_contribution(pack: torch.Tensor, shapes: Dict[str, torch.Size]):
     return out, radii
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """gloo moves host memory: device tensors are staged through the host for it (the debugging /
+    single-GPU test configuration: two ranks on ONE device cannot form an RCCL communicator)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _Gather:
+    """An all-gather of one rank's (P, F) pack that may still be in flight."""
+
+    def __init__(self, pack: torch.Tensor, group=None, async_op: bool = False):
+        world = dist.get_world_size(group)
+        self.shape = (world,) + tuple(pack.shape)
+        self.device = pack.device
+        self.staged = _host_staged(pack, group)
+        src = pack.cpu() if self.staged else pack
+        # flat (world*P, F) output: the concatenation form is accepted by both RCCL and gloo
+        self.flat = torch.empty((world * pack.shape[0],) + tuple(pack.shape[1:]), dtype=pack.dtype, device=src.device)
+        self.src = src                                # (kept alive until the collective has read it)
+        self.work = dist.all_gather_into_tensor(self.flat, src, group=group, async_op=async_op)
+
+    def result(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()                          # RCCL: the CURRENT stream waits for the collective's stream
+            self.work = None
+        flat = self.flat.to(self.device) if self.staged else self.flat
+        return flat.view(self.shape)
+
+
+PackGather = _Gather        # public name: `PackGather(pack, async_op=True)` ... `.result()` (bench.py, pipelines)
+
+
 def allgather(pack: torch.Tensor, group=None) -> torch.Tensor:
     """THE collective of a step: every rank's (P, F) pack -> (world, P, F) on every rank."""
-    world = dist.get_world_size(group)
-    # flat (world*P, F) output: the concatenation form is accepted by both RCCL and gloo
-    flat = torch.empty((world * pack.shape[0],) + tuple(pack.shape[1:]), dtype=pack.dtype,
-                       device=pack.device)
-    dist.all_gather_into_tensor(flat, pack, group=group)
-    return flat.view((world,) + tuple(pack.shape))
+    return _Gather(pack, group).result()
 
 
-def reduce_gathered(gathered: torch.Tensor) -> torch.Tensor:
+def reduce_gathered(gathered: torch.Tensor, acc_in: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Local reduction in rank order (bit-identical on every rank): gradient columns are summed,
-    the last column (radii) takes the max."""
+    the last column (radii) takes the max.  `acc_in` (P, F): the running total of the step's earlier
+    collectives - the chain then continues ((acc_in + rank 0) + rank 1) + ..."""
     world = gathered.shape[0]
     if gathered.is_cuda and gathered.dim() == 3:
         # one HIP pass (rank-order sum, max on the radii column) instead of 2 (world - 1) strided
         # torch kernels launched from a Python loop
         from . import _lib
-        return _lib.load_binding().reduce_view_packs(gathered)
-    total = gathered[0].clone()
-    for r in range(1, world):                     # fixed order => deterministic sum
+        return _lib.load_binding().reduce_view_packs(gathered, acc_in)
+    if acc_in is None:
+        total, first = gathered[0].clone(), 1
+    else:
+        total, first = acc_in.clone(), 0
+    for r in range(first, world):                 # fixed order => deterministic sum
         total[:, :-1] += gathered[r][:, :-1]
         total[:, -1] = torch.maximum(total[:, -1], gathered[r][:, -1])
     return total
@@ -96,12 +135,15 @@ def scatter_reduce_gather(pack: torch.Tensor, group=None) -> torch.Tensor:
         padded = pack.new_zeros((Ps * world, F))
         padded[:P] = pack
         pack = padded
-    recv = torch.empty((world, Ps, F), dtype=pack.dtype, device=pack.device)
-    dist.all_to_all_single(recv.view(world * Ps, F), pack.contiguous(), group=group)
-    shard = reduce_gathered(recv)                           # (Ps, F): rank-ordered sum / max of MY rows
-    full = torch.empty((world * Ps, F), dtype=pack.dtype, device=pack.device)
-    dist.all_gather_into_tensor(full, shard.contiguous(), group=group)
-    return full[:P]
+    dev, staged = pack.device, _host_staged(pack, group)
+    src = pack.contiguous().cpu() if staged else pack.contiguous()
+    recv = torch.empty((world, Ps, F), dtype=pack.dtype, device=src.device)
+    dist.all_to_all_single(recv.view(world * Ps, F), src, group=group)
+    shard = reduce_gathered(recv.to(dev) if staged else recv)      # (Ps, F): rank-ordered sum / max of MY rows
+    shard = shard.contiguous().cpu() if staged else shard.contiguous()
+    full = torch.empty((world * Ps, F), dtype=pack.dtype, device=shard.device)
+    dist.all_gather_into_tensor(full, shard, group=group)
+    return (full.to(dev) if staged else full)[:P]
 
 
 COLLECTIVE_MODES = ("allgather", "scatter")
@@ -123,13 +165,18 @@ def allgather_reduce(pack: torch.Tensor, group=None, mode: str = "allgather") ->
 
 def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg: torch.Tensor,
                           sh_degree: int, loss_grad_fn: Callable, render_fn: Optional[Callable] = None,
-                          group=None, gather_images: bool = False, collective: str = "allgather"):
+                          group=None, gather_images: bool = False, collective: str = "allgather",
+                          pipeline: Optional[bool] = None):
     """One training-style step over `cameras` (the global list, identical on every rank).
 
     params        replicated leaf tensors: means3D, shs, opacities, scales, rotations
     loss_grad_fn  (view_index, color, depth, alpha) -> (dL/dcolor, dL/ddepth, dL/dalpha)
     render_fn     (camera, params, means2D, bg, sh_degree) -> (color, radii, depth, alpha);
                   defaults to the HIP rasterizer.
+    pipeline      True: one asynchronous all-gather per ROUND of views (one view per rank), overlapped with
+                  the render of the next round, rounds chained in view order (module docstring);
+                  False: the rank's views are summed locally and ONE collective ends the step
+                  (`collective` = "allgather" | "scatter"); None: pipeline iff a rank renders > 1 view.
     Returns (grads dict summed over ALL views, radii max over all views, local outputs).
     """
     if render_fn is None:
@@ -137,31 +184,66 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_views(len(cameras), rank, world)
+    rounds = (len(cameras) + world - 1) // world
+    if pipeline is None:
+        pipeline = rounds > 1
     leaves = {k: params[k].detach().requires_grad_(True) for k in
               ("means3D", "shs", "opacities", "scales", "rotations")}
     P = leaves["means3D"].shape[0]
-    acc = {k: torch.zeros_like(leaves[k]) for k in leaves}
-    acc["means2D"] = torch.zeros_like(leaves["means3D"])
-    radii_max = torch.zeros(P, dtype=torch.int32, device=leaves["means3D"].device)
+    dev = leaves["means3D"].device
+    names = ("means3D", "shs", "opacities", "scales", "rotations", "means2D")
+    shapes = {k: leaves[k].shape for k in leaves}
+    shapes["means2D"] = leaves["means3D"].shape
     outputs = []
-    for v in mine:
+
+    def one_view(v):
         means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
         color, radii, depth, alpha = render_fn(cameras[v], leaves, means2D, bg, sh_degree)
         gc, gd, ga = loss_grad_fn(v, color.detach(), depth.detach(), alpha.detach())
-        tens = [leaves[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")] + [means2D]
+        tens = [leaves[k] for k in names[:-1]] + [means2D]
         outs, gouts = [], []
         for o, g in ((color, gc), (depth, gd), (alpha, ga)):
             if g is not None:
                 outs.append(o); gouts.append(g)
         gl = torch.autograd.grad(outs, tens, gouts, allow_unused=True)
-        for k, g in zip(("means3D", "shs", "opacities", "scales", "rotations", "means2D"), gl):
-            if g is not None:
-                acc[k] += g
-        radii_max = torch.maximum(radii_max, radii)
         outputs.append((v, color.detach(), depth.detach(), alpha.detach()))
-    shapes = {k: acc[k].shape for k in GRAD_KEYS}
-    total = allgather_reduce(pack_contribution(acc, radii_max), group, mode=collective)
-    grads, radii_all = unpack_contribution(total, shapes)
+        return {k: (g if g is not None else torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev))
+                for k, g in zip(names, gl)}, radii
+
+    if not pipeline:
+        acc = {k: torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev) for k in names}
+        radii_max = torch.zeros(P, dtype=torch.int32, device=dev)
+        for v in mine:
+            g, radii = one_view(v)
+            for k in names:
+                acc[k] += g[k]
+            radii_max = torch.maximum(radii_max, radii)
+        total = allgather_reduce(pack_contribution(acc, radii_max), group, mode=collective)
+    else:
+        # round j: every rank contributes the pack of its view j * world + rank (zeros beyond the last view:
+        # x + 0 = x exactly), gathered while round j + 1 is rendered; chained in view order
+        total, pending = None, None
+        zero_pack = None
+        for j in range(rounds):
+            v = j * world + rank
+            if v < len(cameras):
+                g, radii = one_view(v)
+                pack = pack_contribution(g, radii)
+            else:
+                if zero_pack is None:
+                    F = sum(int(torch.Size(shapes[k]).numel() // max(P, 1)) for k in GRAD_KEYS) + 1
+                    zero_pack = torch.zeros((P, F), dtype=torch.float32, device=dev)
+                pack = zero_pack
+            if world > 1:
+                started = _Gather(pack, group, async_op=True)
+                if pending is not None:                     # round j - 1 has had a whole render to arrive
+                    total = reduce_gathered(pending.result(), total)
+                pending = started
+            else:
+                total = pack.clone() if total is None else reduce_gathered(pack[None], total)
+        if pending is not None:
+            total = reduce_gathered(pending.result(), total)
+    grads, radii_all = unpack_contribution(total, {k: shapes[k] for k in GRAD_KEYS})
     if gather_images and world > 1:
         outputs = gather_view_images(outputs, len(cameras), group)
     return grads, radii_all, outputs
@@ -177,9 +259,12 @@ def gather_view_images(outputs, num_views: int, group=None):
     slab = torch.zeros((per_rank, 5) + tuple(c0.shape[1:]), dtype=c0.dtype, device=c0.device)
     for i, (_, c, d, a) in enumerate(outputs):
         slab[i, :3], slab[i, 3:4], slab[i, 4:5] = c, d, a
-    flat = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype,
-                       device=slab.device)
-    dist.all_gather_into_tensor(flat, slab, group=group)
+    staged = _host_staged(slab, group)
+    src = slab.cpu() if staged else slab
+    flat = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=src.device)
+    dist.all_gather_into_tensor(flat, src, group=group)
+    if staged:
+        flat = flat.to(slab.device)
     allslab = flat.view((world,) + tuple(slab.shape))
     res = []
     for v in range(num_views):

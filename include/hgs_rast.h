@@ -236,6 +236,13 @@ int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
  * out: [P][F] = sum over ranks in rank order for columns < F-1, max for column F-1. */
 int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gathered, float* out,
                           void* stream);
+/* The same as one link of a CHAIN of collectives (several views per rank, one collective per round of views, each
+ * overlapped with the render of the next round): out = ((acc_in + rank 0) + rank 1) + ... in exactly that order (max on
+ * the radii column), so that the chain over the rounds equals the serial accumulation over the views in view order
+ * (/root/reference/threestudio/systems/GaussianDreamer.py:244-266,385-391) bit for bit.  acc_in may be NULL (= the call
+ * above) and may alias out. */
+int hgs_reduce_view_packs_acc(int32_t world, int64_t P, int32_t F, const float* gathered, const float* acc_in,
+                              float* out, void* stream);
 
 /* Packs one rank's contribution for that all-gather: out[P][15 + 3M] =
  * [dL/dmeans3D 3 | dL/dmeans2D 3 | dL/dsh 3M | dL/dopacity 1 | dL/dscale 3 | dL/drot 4 | radii 1]. */

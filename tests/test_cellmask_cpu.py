@@ -18,7 +18,7 @@ def lib(tmp_path_factory):
                            os.path.join(ROOT, "tests", "cellmask_host.cpp"), "-o", so])
     L = ctypes.CDLL(so)
     L.hgs_cell_mask_host.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9
-    L.hgs_tile_hit_host.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9
+    L.hgs_alpha_rect_host.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7
     return L
 
 
@@ -27,13 +27,6 @@ def _masks(lib, mx, my, ca, cb, cc, op, x0, y0):
     out = np.zeros(len(arrs[0]), np.uint32)
     lib.hgs_cell_mask_host(len(out), *[a.ctypes.data for a in arrs], out.ctypes.data)
     return out
-
-
-def _tile_hits(lib, mx, my, ca, cb, cc, op, x0, y0):
-    arrs = [np.ascontiguousarray(a, np.float32) for a in (mx, my, ca, cb, cc, op, x0, y0)]
-    out = np.zeros(len(arrs[0]), np.uint32)
-    lib.hgs_tile_hit_host(len(out), *[a.ctypes.data for a in arrs], out.ctypes.data)
-    return out.astype(bool)
 
 
 def _live_cells(mx, my, ca, cb, cc, op, x0, y0):
@@ -58,18 +51,18 @@ def _live_cells(mx, my, ca, cb, cc, op, x0, y0):
     return out, live
 
 
-def _random_entries(n, seed):
+def _random_entries(n, seed, s1_max=40.0, aniso_min=0.02):
     rng = np.random.default_rng(seed)
     # covariance = R diag(s1^2, s2^2) R^T + 0.3 I (the rasterizer's low-pass), conic = its inverse
-    s1 = np.exp(rng.uniform(np.log(0.05), np.log(40.0), n))
-    s2 = s1 * np.exp(rng.uniform(np.log(0.02), 0.0, n))
+    s1 = np.exp(rng.uniform(np.log(0.05), np.log(s1_max), n))
+    s2 = s1 * np.exp(rng.uniform(np.log(aniso_min), 0.0, n))
     th = rng.uniform(0, np.pi, n)
     c, s = np.cos(th), np.sin(th)
     a = c * c * s1 ** 2 + s * s * s2 ** 2 + 0.3
     b = c * s * (s1 ** 2 - s2 ** 2)
     d = s * s * s1 ** 2 + c * c * s2 ** 2 + 0.3
     det = a * d - b * b
-    ca, cb, cc = d / det, -b / det, a / det
+    ca, cb, cc = d / det, -b / det, a / det          # (float64 here; the kernel sees their fp32 roundings)
     op = np.where(rng.uniform(size=n) < 0.1, rng.uniform(0.0, 0.01, n), rng.uniform(0.004, 1.0, n))
     x0 = 16.0 * rng.integers(0, 64, n)
     y0 = 16.0 * rng.integers(0, 64, n)
@@ -108,16 +101,34 @@ def test_cell_mask_edge_cases(lib):
     assert _masks(lib, one(500), one(500), one(1), one(0), one(1), one(0.9), one(0), one(0))[0] == 0
 
 
-def test_tile_hit_is_a_superset_of_the_cell_mask_and_of_every_live_pixel(lib):
-    """The binning stage drops a (Gaussian, tile) pair when hgs_tile_hit fails: it must hold whenever a cell bit is
-    set (the blend kernels walk cell lists built from the kept entries) and whenever any pixel of the tile is live."""
-    kept = live_any = n = 0
-    for seed in range(4):
-        e = _random_entries(60000, 10 + seed)
-        hit = _tile_hits(lib, *e)
+def test_cell_mask_with_huge_elongated_gaussians(lib):
+    """Zoomed-in cameras: sigma_major up to 3000 px at anisotropies down to 1e-3.  ca cc - cb^2 cancels in plain fp32
+    there (cleared bits hid pixels with alpha up to 0.0085); the mask uses a compensated determinant and
+    refuses to cull when even that is within rounding of zero."""
+    for seed in range(3):
+        e = _random_entries(40000, 100 + seed, s1_max=3000.0, aniso_min=1e-3)
         m = _masks(lib, *e)
         live_cells, _ = _live_cells(*e)
-        assert not ((m != 0) & ~hit).any()
-        assert not ((live_cells != 0) & ~hit).any()
-        kept += int(hit.sum()); live_any += int((live_cells != 0).sum()); n += len(hit)
-    assert kept <= 1.15 * live_any + 0.01 * n, (kept, live_any, n)      # tight: few tiles kept without a live pixel
+        hidden = live_cells & ~m
+        assert not hidden.any(), (int(np.count_nonzero(hidden)), [v[np.nonzero(hidden)[0][:3]] for v in e])
+
+
+def test_alpha_rect_keeps_every_tile_with_a_live_pixel(lib):
+    """The cut that decides which (Gaussian, tile) pairs get list entries at all (hgs_alpha_rect, used by
+    hgs_k_preprocess_fwd): starting from a generous rect around the Gaussian, every tile that holds a live pixel must
+    survive - checked tile by tile with the kernel's own alpha arithmetic, for ordinary and for huge elongated Gaussians."""
+    f = np.float32
+    for seed, (s1_max, aniso) in enumerate(((40.0, 0.02), (3000.0, 1e-3))):
+        mx, my, ca, cb, cc, op, x0, y0 = _random_entries(20000, 200 + seed, s1_max, aniso)
+        n = len(mx)
+        # the tile (x0, y0) is the one under test; hand the cut a rect of 5 x 5 tiles around it
+        t0x, t0y = (x0 / 16).astype(np.int32), (y0 / 16).astype(np.int32)
+        rect = np.stack([t0x - 2, t0y - 2, t0x + 3, t0y + 3], 1).astype(np.int32).copy()
+        arrs = [np.ascontiguousarray(a, f) for a in (mx, my, ca, cb, cc, op)]
+        lib.hgs_alpha_rect_host(n, *[a.ctypes.data for a in arrs], rect.ctypes.data)
+        kept = (rect[:, 0] <= t0x) & (t0x < rect[:, 2]) & (rect[:, 1] <= t0y) & (t0y < rect[:, 3])
+        live_cells, _ = _live_cells(mx, my, ca, cb, cc, op, x0, y0)
+        lost = (live_cells != 0) & ~kept
+        assert not lost.any(), (int(lost.sum()), [v[np.nonzero(lost)[0][:3]] for v in (mx, my, ca, cb, cc, op, x0, y0)])
+        if s1_max < 100:
+            assert kept.sum() <= 1.6 * (live_cells != 0).sum() + 0.02 * n          # and it cuts: few tiles kept without a live pixel

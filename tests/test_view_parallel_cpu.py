@@ -44,14 +44,15 @@ def _loss_grad(v, color, depth, alpha):
             torch.randn(depth.shape, generator=g, dtype=torch.float64), None)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, pipeline=None, num_views=NUM_VIEWS):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     sc, cams, params = _scene_and_cams()
+    cams = (cams * 2)[:num_views]
     grads, radii, outs = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
-                                                  render_fn=_oracle_render_fn, gather_images=True)
+                                                  render_fn=_oracle_render_fn, gather_images=True, pipeline=pipeline)
     q.put((rank, {k: v.clone() for k, v in grads.items()}, radii.clone(),
            [(v, c.clone()) for v, c, _, _ in outs]))
     dist.barrier()
@@ -79,12 +80,39 @@ def test_pack_roundtrip():
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,num_views", [(2, 4), (3, 5)])
+def test_pipelined_rounds_equal_the_serial_accumulation_bitwise(world, num_views):
+    """Several views per rank: one asynchronous all-gather per round of views, chained in view order
+    (`reduce_gathered(gathered, acc_in)`), must give the BITS of the serial loop over the views
+    (GaussianDreamer.py:244-266,385-391) on every rank - also when the last round is ragged (5 views on 3 ranks:
+    the idle ranks contribute zero packs)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True, num_views)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+    sc, cams, params = _scene_and_cams()
+    cams = (cams * 2)[:num_views]
+    ref, rref, _ = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
+                                            render_fn=_oracle_render_fn, pipeline=True)       # world 1: the serial chain
+    for rank, grads, radii, outs in res:
+        assert torch.equal(radii, rref)
+        for k in ref:
+            assert torch.equal(grads[k], ref[k]), (rank, k)
+        assert [v for v, _ in outs] == list(range(num_views))
+
+
+@pytest.mark.timeout(300)
 def test_two_ranks_reproduce_the_serial_accumulation():
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, False)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
@@ -93,7 +121,7 @@ def test_two_ranks_reproduce_the_serial_accumulation():
     # serial reference = what the single-GPU loop accumulates (GaussianDreamer.py:244-266,385-391)
     sc, cams, params = _scene_and_cams()
     ref, rref, _ = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
-                                            render_fn=_oracle_render_fn)
+                                            render_fn=_oracle_render_fn, pipeline=False)
     for rank, grads, radii, outs in res:
         assert torch.equal(radii, rref)
         for k in ref:
