@@ -46,6 +46,9 @@ HGS_HD bool hgs_conic_cullable(float ca, float cc, float det) {
 }
 
 HGS_HD uint32_t hgs_cell_mask(float mx, float my, float ca, float cb, float cc, float op, float x0, float y0) {
+#ifdef HGS_DEBUG_NO_CUTS       // (tests only: tests/test_gpu_random_cameras.py builds the library once without the two cuts)
+  return 0xffffu;
+#endif
   const float a255 = 255.0f * op;
   if (!(a255 >= 0.999f)) return 0u;                     // alpha <= op < 1/255 everywhere
   const float det = hgs_conic_det(ca, cb, cc);
@@ -82,6 +85,9 @@ HGS_HD uint32_t hgs_cell_mask(float mx, float my, float ca, float cb, float cc, 
 // mask; used by hgs_k_preprocess_fwd and, compiled for the host, by tests/test_cellmask_cpu.py.
 HGS_HD void hgs_alpha_rect(float mx, float my, float ca, float cb, float cc, float op, int& tminx, int& tminy, int& tmaxx,
                            int& tmaxy) {
+#ifdef HGS_DEBUG_NO_CUTS
+  return;
+#endif
   const float a255 = 255.0f * op;
   const float qdet = hgs_conic_det(ca, cb, cc);
   if (!(a255 >= 0.999f)) {
