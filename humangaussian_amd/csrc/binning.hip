@@ -921,7 +921,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 struct RankLds {
   uint32_t hist[HGS_RANK_NB_MAX + 1];   // bucket counts -> exclusive bases (+ sentinel); from step 5 on: the 16-bit masks in list order
-  uint32_t wtot[8];                      // block scan
+  uint32_t wtot[16];                     // block scan (up to 1024 threads: the large class)
   uint32_t tot16[8];                     // cell-list lengths of the tile, two 16-bit fields per word (word 2 q + (c & 1), field (c >> 1) & 1, q = c >> 2)
   uint32_t dmin, dmax, maxcnt, pad;
 };
@@ -1149,10 +1149,14 @@ __device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint3
 // the keys from the tile's key segment (coalesced, L2-resident) and only the ranks stay in registers (16 keys and
 // their bucket words per thread did not fit beside everything else: scratch spills).  The scatter takes its slot from a
 // second LDS atomic on the scanned histogram (hist[b] then ends bucket b), so no arrival position has to be kept.
-template <int NT>
+// SORTED: leave the KEYS in list order in `pairs` (what the large class hands to gather_records_single) instead of
+// (Gaussian | rank << 32) by source position.  Lists of up to 16 * NT keys; bucket starts travel in JB bits.
+template <int NT, bool SORTED = false>
 __device__ __forceinline__ bool rank_keys_stream(const Layout& L, uint32_t start, uint32_t n, uint32_t NB,
                                                  unsigned long long* pairs, RankLds& R) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int JB = NT >= 1024 ? 14 : 12;              // bits of a bucket start (< 16 * NT)
+  constexpr uint32_t JM = (1u << JB) - 1u;
   const unsigned long long* __restrict__ keys = L.keys + start;
   const uint32_t last = n - 1u;
   // ---- 2. depth range
@@ -1225,38 +1229,44 @@ __device__ __forceinline__ bool rank_keys_stream(const Layout& L, uint32_t start
         const uint32_t b = bucket_of(key[e]);
         const uint32_t j1 = R.hist[b], j0 = b ? R.hist[b - 1u] : 0u;
         const uint32_t len = k < n ? j1 - j0 : 0u;
-        w[e] = j0 | (len << 12);                           // bucket start | bucket length << 12 | (smaller keys << 20)
+        w[e] = j0 | (len << JB);                           // bucket start | bucket length << JB | (smaller keys << (JB + 8))
         lmax = max(lmax, len);
       }
       for (uint32_t sidx = 0; sidx < lmax; ++sidx) {
         u64 other[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool on = sidx < ((w[e] >> 12) & 0xffu);
-          other[e] = pairs[on ? (w[e] & 0xfffu) + sidx : 0u];     // (unconditional read from a valid slot)
+          const bool on = sidx < ((w[e] >> JB) & 0xffu);
+          other[e] = pairs[on ? (w[e] & JM) + sidx : 0u];         // (unconditional read from a valid slot)
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool on = sidx < ((w[e] >> 12) & 0xffu);
-          w[e] += (on && other[e] < key[e]) ? (1u << 20) : 0u;
+          const bool on = sidx < ((w[e] >> JB) & 0xffu);
+          w[e] += (on && other[e] < key[e]) ? (1u << (JB + 8)) : 0u;
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) rk[e0 + e] = (w[e] & 0xfffu) + (w[e] >> 20);
+      for (int e = 0; e < 4; ++e) rk[e0 + e] = (w[e] & JM) + (w[e] >> (JB + 8));
     }
     lds_barrier();                                         // every probe is done: `pairs` is free
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const uint32_t k = (uint32_t)e * NT + (uint32_t)tid;
-      if (k < n) pairs[k] = (keys[k] & 0xffffffffull) | ((u64)rk[e] << 32);
+      if (k < n) {
+        if (SORTED) pairs[rk[e]] = keys[k];
+        else pairs[k] = (keys[k] & 0xffffffffull) | ((u64)rk[e] << 32);
+      }
     }
+    if (SORTED) lds_barrier();
   } else {
     // degenerate depths: the bitonic network on the keys in LDS; list position k then holds (Gaussian, rank = k)
     for (uint32_t k = tid; k < n; k += NT) pairs[k] = keys[k];
     __syncthreads();
     bitonic_sort<NT>(pairs, n);
-    for (uint32_t k = tid; k < n; k += NT) pairs[k] = (pairs[k] & 0xffffffffull) | ((u64)k << 32);
-    lds_barrier();
+    if (!SORTED) {
+      for (uint32_t k = tid; k < n; k += NT) pairs[k] = (pairs[k] & 0xffffffffull) | ((u64)k << 32);
+      lds_barrier();
+    }
   }
   return degenerate;
 }
@@ -1458,12 +1468,17 @@ hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_n[t];
   if (n <= 4096u || n > 16384u) return;
-  // long lists: the plain LDS network with all 1024 threads on 2 comparators per stage
-  // beats 16 keys per thread in registers (measured at 500k Gaussians: 181 vs 220 us) and ties
-  // with the register/shuffle hybrid at 8 keys x 1024 threads (153 vs 156 us)
-  for (uint32_t k = threadIdx.x; k < n; k += 1024) keys[k] = L.keys[start + k];
-  __syncthreads();
-  bitonic_sort<1024>(keys, n);
+  // long lists (4097 .. 16384 entries): the same bucket ranking as hgs_k_sort_lds, streaming form, 16 keys per thread at
+  // most; the keys land in list order in LDS and the gather below takes over.  (The bitonic network it replaces - 91
+  // stages of two barriers for 8192 padded keys - was 45 of the 90 us ONE 4411-entry tile cost configs[3].)
+  {
+    __shared__ RankLds R;
+    const uint32_t NB = (uint32_t)HGS_RANK_NB_MAX;
+    for (uint32_t i = threadIdx.x; i <= NB; i += 1024) R.hist[i] = 0u;
+    if (threadIdx.x == 0) { R.dmin = 0xffffffffu; R.dmax = 0u; R.maxcnt = 0u; }
+    rank_keys_stream<1024, true>(L, start, n, NB, keys, R);
+    __syncthreads();
+  }
   gather_records_single<256>(v, L, t, start, n, keys, 1024, S);
 }
 

@@ -226,17 +226,17 @@ def test_long_tile_lists_sort_classes_and_early_termination(n):
     assert np.array_equal(ncon, aux["n_contrib"].numpy().astype(np.uint32))
 
 
-@pytest.mark.parametrize("case", ["equal_depths", "outlier"])
-def test_sort_with_degenerate_depth_distributions(case):
+@pytest.mark.parametrize("case,n", [("equal_depths", 1500), ("outlier", 1500), ("equal_depths", 9000)])
+def test_sort_with_degenerate_depth_distributions(case, n):
     """The rank sort buckets a tile's keys by depth; a bucket of more than HGS_RANK_BUCKET_MAX (192) keys sends the tile
-    through the bitonic network instead.  `equal_depths`: 6 distinct positions x 250 copies (exact ties, broken by the
+    through the bitonic network instead.  `equal_depths`: 6 distinct positions x n / 6 copies (exact ties, broken by the
     Gaussian index like upstream's stable radix sort); `outlier`: one far Gaussian stretches the depth range so that
-    the body of the list shares a few buckets.  Order-sensitive outputs (n_contrib exact, images) against the oracle."""
-    n = 1500
+    the body of the list shares a few buckets; n = 9000: the same in the large class (hgs_k_sort_large, 4097..16384 entries).
+    Order-sensitive outputs (n_contrib exact, images) against the oracle."""
     g = torch.Generator().manual_seed(17)
     sc = make_scene(P=n, seed=123, H=32, W=48, spread=0.02, scale=0.01, dist=2.0)
     if case == "equal_depths":
-        sc["means3D"] = sc["means3D"][torch.arange(n) % 6].clone()
+        sc["means3D"] = sc["means3D"][torch.arange(n) % 6].clone()          # 6 distinct positions x n / 6 copies
     else:
         # one Gaussian far behind the cloud, on the camera axis (still inside the frustum, large enough to reach every tile)
         cam_c = torch.as_tensor(sc["cam"].camera_center, dtype=torch.float32)
@@ -247,7 +247,7 @@ def test_sort_with_degenerate_depth_distributions(case):
     assert rc.forward() == 0 and not rc.status[4]
     oc, orad, od, oa, aux, _ = oracle_forward(sc)
     assert torch.equal(rc.radii.cpu(), orad)
-    assert rc.status[6] > 700                                          # a list long enough to overflow a bucket
+    assert rc.status[6] > (4096 if n > 4096 else n // 3)               # a list long enough to overflow a bucket (n = 9000: of the large class)
     check_images(rc, oc, od, oa)
     ncon = np.frombuffer(rc.img[: rc.H * rc.W * 4].cpu().numpy().tobytes(), dtype=np.uint32).reshape(rc.H, rc.W)
     assert np.array_equal(ncon, aux["n_contrib"].numpy().astype(np.uint32))
