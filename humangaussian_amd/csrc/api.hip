@@ -27,7 +27,8 @@ __device__ unsigned long long hgs_tl[HGS_TL_KERNELS][HGS_TL_SLOTS][4];
 extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*, const float*,
                                             const float*, const float*, const float*, const float*,
                                             const float*, const float*, float*);
-extern "C" __global__ void hgs_k_pair_reduce(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
+extern "C" __global__ void hgs_k_pair_reduce_em(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
+extern "C" __global__ void hgs_k_pair_reduce_cm(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
 
 namespace {
 
@@ -54,6 +55,9 @@ inline int cu_count(hipStream_t stream) {
   cache[dev].store(cus, std::memory_order_relaxed);
   return cus;
 }
+#ifndef HGS_CELLMAJOR_MIN_VIEWS
+#define HGS_CELLMAJOR_MIN_VIEWS 3      // calls with at least this many views keep the backward's pair rows cell-major (binning.hip::hgs_put_pair)
+#endif
 #ifndef HGS_PRE_BWD_VPAR_MIN_VIEWS
 #define HGS_PRE_BWD_VPAR_MIN_VIEWS 2   // calls with at least this many views run the per-Gaussian backward with one thread per
 #endif                                 // (Gaussian, view); fewer: one thread per Gaussian
@@ -114,7 +118,7 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, cell_list, entpair, cstate, items_full, total; };
+struct BinCarve { size_t keys, recs, cell_list, ptab, entpair, cstate, items_full, total; };
 
 // Pair-sized arrays hold HGS_PAIRS_PER_ENTRY slots per entry of capacity: an entry can reach all 16 cells of
 // its tile (zoomed-in cameras), so no second capacity (and no second overflow path) exists.
@@ -127,6 +131,7 @@ BinCarve carve_bin(int64_t cap) {
   c.keys = take(C * 8);
   c.recs = take(C * sizeof(SortRec));
   c.cell_list = take(NP * 8);
+  c.ptab = take(NP * 4);
   c.entpair = take(C * 8);
   // a cell list of len entries has ceil(len / HGS_SEGLEN) - 1 stored states and ceil(len / HGS_SEGLEN) work items, len / HGS_SEGLEN of them full
   c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
@@ -158,6 +163,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.cell_list = bp ? reinterpret_cast<uint2*>(bp + b.cell_list) : nullptr;
+  L.ptab = bp ? reinterpret_cast<uint32_t*>(bp + b.ptab) : nullptr;
   L.entpair = bp ? reinterpret_cast<uint2*>(bp + b.entpair) : nullptr;
   L.cstate = bp ? reinterpret_cast<float*>(bp + b.cstate) : nullptr;
   L.items_full = bp ? reinterpret_cast<uint4*>(bp + b.items_full) : nullptr;
@@ -168,6 +174,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
 View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_tile_hint = 0, int act = 0) {
   View v;
   v.act = act;
+  v.cellmajor = B >= HGS_CELLMAJOR_MIN_VIEWS ? 1 : 0;
   for (int b = 0; b < HGS_MAX_VIEWS; ++b) {
     const hgs_settings& sb = s[b < B ? b : 0];
     Cam& c = v.cam[b];
@@ -513,8 +520,12 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);
     if (X > 0) {
-      hipLaunchKernelGGL(hgs_k_pair_reduce, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
-                         pair_rows, rows);
+      if (v.cellmajor)
+        hipLaunchKernelGGL(hgs_k_pair_reduce_cm, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
+                           pair_rows, rows);
+      else
+        hipLaunchKernelGGL(hgs_k_pair_reduce_em, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
+                           pair_rows, rows);
       HGS_LAUNCH_CHECK();
     }
   }

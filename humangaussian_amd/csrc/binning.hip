@@ -245,6 +245,19 @@ hgs_k_fill_ga(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __r
 // ---------------------------------------------------------------------------- 3. sort
 namespace {
 
+// One (entry, cell) pair of record `rec`: `pidx` = its entry-major index (the pairs of an entry are neighbours, in cell
+// order), `slot` = its cell-list slot.  Where the backward writes the pair's gradient row is a per-call choice
+// (View::cellmajor):
+//  * entry-major rows (1-2 views): row id = pidx, carried in the list element; the reduction streams the rows of 64
+//    entries as one contiguous block (17 us per view) - the backward pays with isolated 40 B stores (+3 us);
+//  * cell-major rows (>= 3 views): row id = slot, ptab[pidx] = slot tells the reduction where the rows of an entry are;
+//    the backward writes 640 B bursts - with 8 views in flight the isolated stores made it bandwidth-bound
+//    (428 -> 273 us), the reduction gathers instead of streaming (179 -> 228 us).
+__device__ __forceinline__ void hgs_put_pair(const View& v, const Layout& L, uint32_t rec, uint32_t pidx, uint32_t slot) {
+  L.cell_list[slot] = make_uint2(rec, v.cellmajor ? slot : pidx);
+  if (v.cellmajor) L.ptab[pidx] = slot;
+}
+
 // Ranges of one tile, from the lengths of its 16 cell lists: pairs (= cell-list slots), cell states, work items.
 // Wave 0 of the workgroup, lane c = cell c.  Two halves: `issue` sends the bump allocation (ONE atomic instruction,
 // lanes 0..2 + one per forward class on 64-bit counters: a device-scope atomic is a ~2 us trip to the memory side of
@@ -468,7 +481,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         if (bit) {
           const uint32_t rank = S.tab[ch][c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
           const uint32_t slot = S.cell_base[c] + rank;
-          L.cell_list[slot] = make_uint2(start + k, pair_base + rel + (uint32_t)__popc(mask & ((1u << c) - 1u)));
+          hgs_put_pair(v, L, start + k, pair_base + rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
         }
       }
     }
@@ -622,7 +635,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
       mask &= mask - 1u;
       const uint32_t exw = (c < 8) ? (c < 4 ? ex[0] : ex[1]) : (c < 12 ? ex[2] : ex[3]);
       const uint32_t slot = S.cell_base[c] + S.tab[ch][c] + ((exw >> (8 * (c & 3))) & 0xffu);
-      L.cell_list[slot] = make_uint2(start + k, pair_base + rel + r);
+      hgs_put_pair(v, L, start + k, pair_base + rel + r, slot);
       ++r;
     }
   }
@@ -1003,7 +1016,7 @@ __device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layou
       const uint32_t cbase = (uint32_t)__builtin_amdgcn_readlane((int)cb, c);
       if ((mask >> c) & 1u) {
         const uint32_t slot = cbase + ((ex[c >> 2] >> (8 * (c & 3))) & 0xffu);
-        L.cell_list[slot] = make_uint2(start + k, rel + (uint32_t)__popc(mask & ((1u << c) - 1u)));
+        hgs_put_pair(v, L, start + k, rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
       }
     }
   }

@@ -149,8 +149,9 @@ struct Layout {          // pointers carved out of the caller's buffers
   Counters* ctr;
   unsigned long long* keys;
   SortRec* recs;
-  uint2* cell_list;           // [16 C]: (record index, pair id)
-  uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first pair id) - what the pair reduction reads
+  uint2* cell_list;           // [16 C]: (record index, id of the pair's gradient row), cell-major per tile
+  uint32_t* ptab;             // [16 C] cell-major rows only (binning.hip::hgs_put_pair): ptab[entry-major pair index] = the pair's slot
+  uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first entry-major pair index) - what the pair reduction reads
   float* cstate;              // [C/4 + 1][6][16]
   uint4* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, entries, first cell-list slot, state slot or ~0): all a wave needs to start
   uint32_t* n_contrib;        // [B][H*W]  1-based TILE-list position of the pixel's last contributor (upstream's meaning)
@@ -174,6 +175,7 @@ struct View {            // per-call constants, passed by value to every kernel
   uint32_t entry_capacity;
   int32_t max_tile_hint;             // >0: caller promises no tile list is longer (else overflow bit 2)
   int32_t act;                       // HGS_ACT_* bits: inputs are RAW parameters, activations fused into preprocess
+  int32_t cellmajor;                 // != 0: the backward's pair rows live at cell-list slots (calls of >= 3 views), else at entry-major ids
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -31,7 +31,8 @@
 // (First version: v_mfma_f32_16x16x4_f32 with a block-diagonal A - K slot = cell - to get the same layout: three
 // quarters of its 32 cycles multiplied zeros, and the matrix pipe was 40 % of the kernel's issue time.)
 //
-// An (entry, cell) pair row lands at the pair's id (entry-major); hgs_k_pair_reduce adds the pair rows of
+// An (entry, cell) pair row lands at the row id the list element carries (the pair's entry-major id, or its cell-list slot
+// in calls of >= 3 views: binning.hip::hgs_put_pair); hgs_k_pair_reduce_{em,cm} adds the pair rows of
 // every entry in cell order (fixed order: no atomics, bitwise reproducible) into one 48 B gradient row per
 // entry, which hgs_k_preprocess_bwd sums per Gaussian.  Pair rows are 40 B (the ten sums, packed).
 //
@@ -377,7 +378,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   }
 }
 
-// ------------------------------------------------------------------------------ pair reduction
+// ------------------------------------------------------------------------------ pair reduction, ENTRY-major rows (calls of 1-2 views)
 // One gradient row per tile entry = the sum of the entry's (entry, cell) pair rows, cells in ascending order
 // (deterministic).  A wave64 takes 64 consecutive entries; pair ids are entry-major, so their pair rows are ONE
 // contiguous range (inside a tile): the wave streams it through LDS with fully coalesced 8 B loads, 128 rows at a
@@ -386,7 +387,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 // kernel of the step.)  A wave whose entries straddle two tiles (pair ranges apart) takes the per-thread path.
 #define HGS_RED_ROWS 128
 extern "C" __global__ void __launch_bounds__(256)
-hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
+hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
                   const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
   __shared__ float2 s_rows[4][HGS_RED_ROWS * HGS_PROW_F2];
   if (status->overflow) return;
@@ -472,4 +473,55 @@ hgs_k_pair_reduce(View v, Layout L, const hgs_status* __restrict__ status, const
     dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
   }
+}
+
+// ------------------------------------------------------------------------------ pair reduction, CELL-major rows (calls of >= 3 views)
+// Pair rows live at the CELL-LIST SLOT of the pair: the backward writes the 16 rows of a batch as one 640 B burst (with
+// entry-major rows every 40 B row is an isolated partial-line store - 5x write amplification at the fabric, which made
+// the batched backward bandwidth-bound: 1.74 GB in 379 us for 8 views).  The sort kernel's entry-major table `ptab`
+// tells the reduction where the rows of an entry are: thread = entry (list position) reads its `cnt` slots (contiguous
+// 4 B words) and gathers the rows, cells in ascending order - the same sums in the same order as the entry-major form.
+// Consecutive entries of a tile sit at consecutive slots of every cell list they share, so the lanes of a wave read
+// neighbouring rows: L1 / L2 serve most of the 40 B gathers.
+#define HGS_RED_UNROLL 4
+typedef float hgs_f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));      // 16 B access at 8 B alignment (40 B pair rows)
+extern "C" __global__ void __launch_bounds__(256)
+hgs_k_pair_reduce_cm(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
+                     const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
+  if (status->overflow) return;
+  const uint32_t R = status->num_rendered;
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= R) return;
+  const uint2 ep = L.entpair[p];                              // entry id | pairs << 27, first entry-major pair index
+  const uint32_t entry = ep.x & 0x7ffffffu, cnt = ep.x >> 27;
+  const uint32_t* __restrict__ ps = L.ptab + ep.y;
+  float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
+  for (uint32_t r0 = 0; r0 < cnt; r0 += HGS_RED_UNROLL) {
+    // slots first, then all rows of the group in flight (unconditional loads from clamped indices), added in cell order
+    uint32_t sl[HGS_RED_UNROLL];
+#pragma unroll
+    for (int u = 0; u < HGS_RED_UNROLL; ++u) sl[u] = ps[min(r0 + (uint32_t)u, cnt - 1u)];
+    hgs_f32x4_a8 a0[HGS_RED_UNROLL], a1[HGS_RED_UNROLL];
+    float2 a2[HGS_RED_UNROLL];
+#pragma unroll
+    for (int u = 0; u < HGS_RED_UNROLL; ++u) {
+      const float* q = pair_rows + (size_t)sl[u] * HGS_PROW_FLOATS;      // (16 + 16 + 8 B loads at 8 B alignment)
+      a0[u] = *reinterpret_cast<const hgs_f32x4_a8*>(q);
+      a1[u] = *reinterpret_cast<const hgs_f32x4_a8*>(q + 4);
+      a2[u] = *reinterpret_cast<const float2*>(q + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < HGS_RED_UNROLL; ++u) {
+      if (r0 + (uint32_t)u < cnt) {
+        s0.x += a0[u][0]; s0.y += a0[u][1]; s1.x += a0[u][2]; s1.y += a0[u][3]; s2.x += a1[u][0]; s2.y += a1[u][1];
+        s3.x += a1[u][2]; s3.y += a1[u][3]; s4.x += a2[u].x; s4.y += a2[u].y;
+      }
+    }
+  }
+  float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
+  dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
+  dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
+#if HGS_GROW_F4 > 3
+  dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
 }

@@ -49,7 +49,7 @@ for r in csv.DictReader(open(f"{O}/r04_kernel_stats.csv")):
     dur[r["Name"]]=float(r["AverageNs"])
 CLK=2.4e9
 busy={}
-for short,k in (("render_bwd","hgs_k_render_bwd"),("render_fwd","hgs_k_render_fwd_store"),("sort","hgs_k_sort_lds"),("pair_reduce","hgs_k_pair_reduce")):
+for short,k in (("render_bwd","hgs_k_render_bwd"),("render_fwd","hgs_k_render_fwd_store"),("sort","hgs_k_sort_lds"),("pair_reduce","hgs_k_pair_reduce_em")):
     if k in out and k in dur and "SQ_ACTIVE_INST_VALU" in out[k]:
         busy[short]=out[k]["SQ_ACTIVE_INST_VALU"]*4.0/(1024*CLK*dur[k]*1e-9)
 res={"_commit":sys.argv[1],"_note":"rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5` (configs[1]); "
