@@ -105,8 +105,9 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   c.tile_order = take(TT * 4);
   c.tile_rec = take(TT * 16);
   c.cell_info = take(TT * 16 * sizeof(CellInfo));
-  c.items_part = take(2 * 16 * TT * sizeof(uint4));      // last (partial) segment of every cell list, by length class
-  c.fwd_cells = take((size_t)HGS_NFC * 16 * TT * 4);       // non-empty cells by length class
+  const size_t dcap = hgs_die_cells((int)TT);            // work tables are per die (Counters::sched)
+  c.items_part = take(HGS_NXCD * 2 * dcap * sizeof(uint4));   // last (partial) segment of every cell list, by length class
+  c.fwd_cells = take((size_t)HGS_NXCD * HGS_NFC * dcap * 4);    // non-empty cells by length class
   c.hist = take(lds ? (size_t)B * nwg * T * 4 : 0);
   c.tile_gbase = take(lds ? (size_t)HGS_ROW_GROUPS * TT * 4 : 0);
   c.tile_count = take(lds ? 0 : TT * 4);
@@ -135,7 +136,7 @@ BinCarve carve_bin(int64_t cap) {
   c.entpair = take(C * 8);
   // a cell list of len entries has ceil(len / HGS_SEGLEN) - 1 stored states and ceil(len / HGS_SEGLEN) work items, len / HGS_SEGLEN of them full
   c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
-  c.items_full = take((NP / HGS_SEGLEN + 1) * sizeof(uint4));
+  c.items_full = take(HGS_NXCD * (NP / HGS_SEGLEN + 1) * sizeof(uint4));     // per die; one die's tiles may hold (nearly) all full segments
   c.total = off;
   return c;
 }
@@ -167,6 +168,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.entpair = bp ? reinterpret_cast<uint2*>(bp + b.entpair) : nullptr;
   L.cstate = bp ? reinterpret_cast<float*>(bp + b.cstate) : nullptr;
   L.items_full = bp ? reinterpret_cast<uint4*>(bp + b.items_full) : nullptr;
+  L.full_cap = (uint32_t)((size_t)(cap > 0 ? cap : 0) * HGS_PAIRS_PER_ENTRY / HGS_SEGLEN + 1);
   L.n_contrib = static_cast<uint32_t*>(img);
   return L;
 }
@@ -434,11 +436,12 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     // (the snake schedule of hgs_k_render_fwd visits every item only when the block count is a multiple of 4)
     const int64_t fwd_blocks = (int64_t)hgs_knob("HGS_FWD_BLOCKS_PER_CU", 4) * ncu;
     const unsigned cell_blocks = (unsigned)std::max<int64_t>(4, std::min<int64_t>(fwd_blocks, (cells + 3) / 4) & ~int64_t(3));
+    const unsigned bg_blocks = (unsigned)v.TT;
     if (store_bwd_state)
-      hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(cell_blocks + v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
+      hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(cell_blocks + bg_blocks), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
                          status_dev, L.recs, L.cstate, out_color, out_depth, out_alpha);
     else
-      hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(cell_blocks + v.TT), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
+      hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(cell_blocks + bg_blocks), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
                          status_dev, L.recs, L.cstate, out_color, out_depth, out_alpha);
   }
   HGS_LAUNCH_CHECK();
@@ -515,7 +518,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     // persistent workgroups of HGS_BWD_BLOCK_WAVES waves: as many waves as the chip holds (LDS: 11.8 KB per wave =>
     // 12 per CU, 3 per SIMD); the waves of a workgroup draw its groups of four work items through an LDS ticket
     const int resident = hgs_knob("HGS_BWD_WAVES_PER_CU", 12) * cu_count(stream);
-    hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)std::max(1, resident / HGS_BWD_BLOCK_WAVES)), dim3(64 * HGS_BWD_BLOCK_WAVES), 0, stream, v, L, status_dev, L.recs, L.cstate,
+    hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)std::max(HGS_NXCD, resident / HGS_BWD_BLOCK_WAVES / HGS_NXCD * HGS_NXCD)), dim3(64 * HGS_BWD_BLOCK_WAVES), 0, stream, v, L, status_dev, L.recs, L.cstate,
                        out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows);
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);

@@ -264,12 +264,13 @@ __device__ __forceinline__ void hgs_put_pair(const View& v, const Layout& L, uin
 // the fabric, five of them in a row were 13 us of every tile's chain), `finish` consumes its result and writes
 // cell_info, the work items, cell_base[] and pair_base (LDS) - the caller may put independent work between the two.
 struct CellAlloc {
-  uint32_t len, nfull, rem, nst, i_len, i_st, i_full, pcls, fcls, frank;
+  uint32_t len, nfull, rem, nst, i_len, i_st, i_full, pcls, fcls, frank, die;
   unsigned long long b1, b2, b3, got;
 };
 
-__device__ __forceinline__ void hgs_alloc_cell_ranges_issue(const Layout& L, uint32_t len_of_lane, CellAlloc& a) {
+__device__ __forceinline__ void hgs_alloc_cell_ranges_issue(const Layout& L, uint32_t order_pos, uint32_t len_of_lane, CellAlloc& a) {
   const int lane = (int)threadIdx.x & 63;
+  a.die = order_pos % HGS_NXCD;                         // the die whose work tables take this tile (Counters::sched)
   const bool cl = lane < 16;
   a.len = cl ? len_of_lane : 0u;
   a.nfull = a.len / HGS_SEGLEN; a.rem = a.len % HGS_SEGLEN;
@@ -281,7 +282,7 @@ __device__ __forceinline__ void hgs_alloc_cell_ranges_issue(const Layout& L, uin
   const uint32_t t_len = (uint32_t)__builtin_amdgcn_readlane((int)a.i_len, 63);
   const uint32_t t_st = (uint32_t)__builtin_amdgcn_readlane((int)a.i_st, 63);
   const uint32_t t_full = (uint32_t)__builtin_amdgcn_readlane((int)a.i_full, 63);
-  // forward work items: every non-empty cell goes into the table of its length class; lane 3 + c allocates for class c
+  // forward work items: every non-empty cell goes into its die's table of its length class; lane 3 + c allocates for class c
   a.fcls = hgs_cell_class(a.len);
   unsigned long long fb_ = 0;                          // cells of this tile in "my" class (lanes 3 .. 3 + HGS_NFC - 1)
   a.frank = 0;                                         // rank of this lane's cell inside its class, within the tile
@@ -296,7 +297,8 @@ __device__ __forceinline__ void hgs_alloc_cell_ranges_issue(const Layout& L, uin
                                : lane == 2 ? ((unsigned long long)__popcll(a.b2) | ((unsigned long long)__popcll(a.b3) << 32))
                                            : (unsigned long long)__popcll(fb_);
   a.got = 0;
-  if (lane < 3 + HGS_NFC && add) a.got = atomicAdd(&L.ctr->alloc3[lane], add);
+  unsigned long long* ctr = lane == 0 ? &L.ctr->alloc_ps : &L.ctr->sched[a.die][min(lane, 2 + HGS_NFC) - 1];
+  if (lane < 3 + HGS_NFC && add) a.got = atomicAdd(ctr, add);
 }
 
 __device__ __forceinline__ void hgs_alloc_cell_ranges_finish(const View& v, const Layout& L, int g, const CellAlloc& a,
@@ -320,28 +322,29 @@ __device__ __forceinline__ void hgs_alloc_cell_ranges_finish(const View& v, cons
     ci.base = base; ci.len = len; ci.sbase = sb + a.i_st - a.nst; ci.pbase = pb;
     L.cell_info[(size_t)g * 16 + lane] = ci;
     const uint32_t key = (uint32_t)g * 16u + (uint32_t)lane;
-    if (len) L.fwd_cells[(size_t)a.fcls * 16u * v.TT + fpos] = key;
+    const size_t dcap = hgs_die_cells(v.TT);
+    if (len) L.fwd_cells[((size_t)a.die * HGS_NFC + a.fcls) * dcap + fpos] = key;
     // a work item carries all its wave needs to start: (cell, entries, first cell-list slot, state slot in front of it)
-    uint4* full = L.items_full + (fb + a.i_full - nfull);
+    uint4* full = L.items_full + ((size_t)a.die * L.full_cap + fb + a.i_full - nfull);
     for (uint32_t sgm = 0; sgm < nfull; ++sgm)
       full[sgm] = make_uint4(key, HGS_SEGLEN, base + sgm * HGS_SEGLEN, sgm ? ci.sbase + sgm - 1u : 0xffffffffu);
     if (rem) {
       const unsigned long long below = (1ull << lane) - 1ull;
-      const size_t ptab = (size_t)16 * v.TT;
+      uint4* part = L.items_part + (size_t)a.die * 2 * dcap;
       const uint4 it = make_uint4(key, rem, base + nfull * HGS_SEGLEN, nfull ? ci.sbase + nfull - 1u : 0xffffffffu);
-      if (a.pcls == 1u) L.items_part[p1 + (uint32_t)__popcll(a.b1 & below)] = it;
-      else if (a.pcls == 2u) L.items_part[ptab - 1 - (p2 + (uint32_t)__popcll(a.b2 & below))] = it;
-      else L.items_part[ptab + p3 + (uint32_t)__popcll(a.b3 & below)] = it;
+      if (a.pcls == 1u) part[p1 + (uint32_t)__popcll(a.b1 & below)] = it;
+      else if (a.pcls == 2u) part[dcap - 1 - (p2 + (uint32_t)__popcll(a.b2 & below))] = it;
+      else part[dcap + p3 + (uint32_t)__popcll(a.b3 & below)] = it;
     }
   }
   if (lane == 0) pair_base_out = pb;
 }
 
-__device__ __forceinline__ void hgs_alloc_cell_ranges(const View& v, const Layout& L, int g, const uint32_t* cell_tot,
+__device__ __forceinline__ void hgs_alloc_cell_ranges(const View& v, const Layout& L, int g, uint32_t order_pos, const uint32_t* cell_tot,
                                                       uint32_t* cell_base, uint32_t& pair_base_out) {
   if (threadIdx.x < 64) {
     CellAlloc a;
-    hgs_alloc_cell_ranges_issue(L, (threadIdx.x & 63) < 16 ? cell_tot[threadIdx.x & 63] : 0u, a);
+    hgs_alloc_cell_ranges_issue(L, order_pos, (threadIdx.x & 63) < 16 ? cell_tot[threadIdx.x & 63] : 0u, a);
     hgs_alloc_cell_ranges_finish(v, L, g, a, cell_base, pair_base_out);
   }
 }
@@ -362,7 +365,7 @@ struct GatherLds {
 // so the backward's pair rows of one entry lie behind each other for the reduce kernel.  `sorted` (LDS or HBM) holds
 // the sorted keys on entry; its slots are reused for the masks.
 template <int MAXCH>
-__device__ __forceinline__ void gather_records(const View& v, const Layout& L, int g,
+__device__ __forceinline__ void gather_records(const View& v, const Layout& L, int g, uint32_t order_pos,
                                                uint32_t start, uint32_t n,
                                                unsigned long long* sorted, int nt, GatherLds<MAXCH>& S) {
   const int t = g % v.T;
@@ -428,7 +431,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
   }
   if (lane < 16 && mytot) atomicAdd(&S.cell_tot[lane], mytot);
   __syncthreads();
-  hgs_alloc_cell_ranges(v, L, g, S.cell_tot, S.cell_base, S.pair_base);
+  hgs_alloc_cell_ranges(v, L, g, order_pos, S.cell_tot, S.cell_base, S.pair_base);
   __syncthreads();
   // ---- sweep 2: cell lists and pair slots, MAXCH chunks per pass
   const uint32_t pair_base = S.pair_base;
@@ -499,7 +502,7 @@ __device__ __forceinline__ uint32_t hgs_spread4(uint32_t nib) {          // 4 bi
 __device__ __forceinline__ uint32_t hgs_bytesum(uint32_t w) { return __builtin_amdgcn_sad_u8(w, 0u, 0u); }
 
 template <int MAXCH>
-__device__ __forceinline__ void gather_records_single(const View& v, const Layout& L, int g,
+__device__ __forceinline__ void gather_records_single(const View& v, const Layout& L, int g, uint32_t order_pos,
                                                       uint32_t start, uint32_t n,
                                                       unsigned long long* sorted, int nt, GatherLds<MAXCH>& S) {
   const int t = g % v.T;
@@ -611,7 +614,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
   }
   __syncthreads();
   HGS_TG(2);
-  hgs_alloc_cell_ranges(v, L, g, S.cell_tot, S.cell_base, S.pair_base);
+  hgs_alloc_cell_ranges(v, L, g, order_pos, S.cell_tot, S.cell_base, S.pair_base);
   __syncthreads();
   HGS_TG(3);
   // ---- sweep 2: cell lists and pair slots
@@ -1413,7 +1416,7 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
   if (tid < 64) {
     const int c = lane & 15;
     const uint32_t word = R.tot16[2 * (c >> 2) + (c & 1)];
-    hgs_alloc_cell_ranges_issue(L, (word >> (16 * ((c >> 1) & 1))) & 0xffffu, ca);
+    hgs_alloc_cell_ranges_issue(L, order_pos, (word >> (16 * ((c >> 1) & 1))) & 0xffffu, ca);
   }
   cell_lists_from_masks<NT>(v, L, order_pos, start, n, masks, S, ca, tp);
 }
@@ -1492,7 +1495,7 @@ hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
     rank_keys_stream<1024, true>(L, start, n, NB, keys, R);
     __syncthreads();
   }
-  gather_records_single<256>(v, L, t, start, n, keys, 1024, S);
+  gather_records_single<256>(v, L, t, b, start, n, keys, 1024, S);
 }
 
 // Tiles with n > 16384 (longer than LDS): the same network run in place on the tile's key
@@ -1509,5 +1512,5 @@ hgs_k_sort_huge(View v, Layout L, const hgs_status* __restrict__ status) {
   if (n <= 16384u) return;
   __shared__ GatherLds<256> S;
   bitonic_sort<1024>(L.keys + start, n);
-  gather_records<256>(v, L, t, start, n, L.keys + start, 1024, S);
+  gather_records<256>(v, L, t, b, start, n, L.keys + start, 1024, S);
 }

@@ -70,6 +70,7 @@
 #define HGS_PROW_FLOATS 10                      // (entry, cell) pair row: the ten sums, packed (40 B: a sixth less pair traffic than 48 B)
 #define HGS_PROW_F2 (HGS_PROW_FLOATS / 2)         // float2 per pair row
 #define HGS_NCLS 33                             // tile classes by log2(list length); class 0 = empty
+#define HGS_NXCD 8                              // accelerator dies (XCDs), each with its own L2: workgroup b of a launch runs on die b % 8
 #define HGS_NFC 11                              // length classes of the non-empty cells (forward work items)
 
 struct __attribute__((aligned(16))) GeomRec {   // 64 B, one per (view, Gaussian)
@@ -104,19 +105,29 @@ struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a
 };
 
 // Device-side counters of one forward call (zeroed by the first workgroup of the preprocess kernel).
-struct Counters {
+struct __attribute__((aligned(128))) Counters {   // (one 128 B line per group of counters that one atomic instruction hits)
   unsigned long long alloc_eb;   // low: entries handed out to tiles (= R when done)
-  unsigned long long alloc3[3 + HGS_NFC];   // bump allocators of the sort kernel (ONE multi-lane atomic per tile - same-address
-                                 // device-scope atomics serialise at ~10 ns each): [0] low: pairs handed out to tiles, high:
-                                 // cell states; [1] low / high: backward work items of class 0 (full segments) / class 1;
-                                 // [2] low / high: class 2 / class 3; [3 + c]: non-empty cells of length class c (forward items)
   uint32_t entry_alloc;          // entry ids handed out to Gaussians (= R when done)
   uint32_t pad0;
   uint32_t max_n;                // longest tile list
   uint32_t pad;
   uint32_t cls_hist[HGS_NCLS];   // tiles per class
   uint32_t cls_cur[HGS_NCLS];    // tile_order cursor per class (starts at the class base, heavy first)
+  __attribute__((aligned(128))) unsigned long long alloc_ps;   // bump allocator of the sort kernel: low: pairs (= cell-list slots) handed out to tiles, high: cell states
+  // Work tables are kept PER DIE: the sort puts the work of the tile at tile_order position b into the tables of die
+  // b % 8.  [x][0] low / high: backward work items of class 0 (full segments) / class 1; [x][1] low / high: class 2 /
+  // class 3; [x][2 + c]: non-empty cells of length class c (forward items).  The sort issues ONE multi-lane atomic per
+  // tile over alloc_ps and its die's row: same-address device-scope atomics serialise at ~10 ns each, eight rows cut
+  // that queue by eight (global forward counters next to per-die backward ones: 39.3 -> 42 us for the sort of a view).
+  //  - the backward's workgroup i draws from the tables of die i % 8 - the die the dispatcher puts it on - so the
+  //    waves that gather one tile's records and lists share ONE L2 (a record crossed the fabric once per die that
+  //    touched it: 205 -> 131 MB per view, 47 -> 44.5 us).  Placement only: any workgroup may process any table;
+  //  - the forward takes the eight tables of a class one behind the other, as ONE list (with a die's workgroups on
+  //    its own table its traffic fell as well, 77 -> 52 MB, but it ran 3 us longer per view, 10 us at 500k - it is
+  //    bound by its most loaded SIMD, not by the gathers; EXPERIMENTS.md).
+  __attribute__((aligned(128))) unsigned long long sched[HGS_NXCD][16];      // (rows padded to a line: 2 + HGS_NFC used)
 };
+static_assert(2 + HGS_NFC <= 16, "a die's row of work counters is one 128 B line");
 
 // Backward work item = HGS_SEGLEN consecutive entries of one cell list (the last item of a list may be
 // shorter).  Four items make a wave (one per row), so items are handed out longest first and in classes of
@@ -144,8 +155,8 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* chunk_sums;       // [B*nblk] tiles_touched summed over a 256-Gaussian chunk
   uint32_t* chunk_base;       // [B*nblk] first entry id of the chunk (bump-allocated)
   CellInfo* cell_info;        // [B*T][16]
-  uint32_t* fwd_cells;        // [HGS_NFC][16 B*T]: cell keys (g * 16 + c) of the non-empty cells, per length class
-  uint4* items_part;          // [2][16 B*T]: table 0 holds class 1 (from the front) and class 2 (from the back), table 1 class 3
+  uint32_t* fwd_cells;        // [HGS_NXCD][HGS_NFC][hgs_die_cells]: cell keys (g * 16 + c) of the non-empty cells, per die and length class
+  uint4* items_part;          // [HGS_NXCD][2][hgs_die_cells]: per die, table 0 holds class 1 (from the front) and class 2 (from the back), table 1 class 3
   Counters* ctr;
   unsigned long long* keys;
   SortRec* recs;
@@ -153,9 +164,13 @@ struct Layout {          // pointers carved out of the caller's buffers
   uint32_t* ptab;             // [16 C] cell-major rows only (binning.hip::hgs_put_pair): ptab[entry-major pair index] = the pair's slot
   uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first entry-major pair index) - what the pair reduction reads
   float* cstate;              // [C/4 + 1][6][16]
-  uint4* items_full;          // [C/4 + 1]: (cell key = g * 16 + c, entries, first cell-list slot, state slot or ~0): all a wave needs to start
+  uint32_t full_cap;          // slots of ONE die's items_full table (the full segments of all lists would fit in each)
+  uint4* items_full;          // [HGS_NXCD][full_cap]: (cell key = g * 16 + c, entries, first cell-list slot, state slot or ~0): all a wave needs to start
   uint32_t* n_contrib;        // [B][H*W]  1-based TILE-list position of the pixel's last contributor (upstream's meaning)
 };
+
+// Cells of the tiles one die can get: tile_order positions b with b % HGS_NXCD == x, at most ceil(B*T / 8) of them.
+__host__ __device__ __forceinline__ size_t hgs_die_cells(int TT) { return (size_t)16 * (size_t)((TT + HGS_NXCD - 1) / HGS_NXCD); }
 
 struct Cam {             // per-view constants (device pointers stay with the caller)
   const float* viewmatrix;
@@ -279,7 +294,21 @@ __device__ __forceinline__ uint32_t hgs_block_excl_scan(uint32_t v, uint32_t* wt
       hgs_tl[KID][tl_slot__][3] = (unsigned long long)(TAG);                                        \
     }                                                                                               \
   } while (0)
+// per work item of a persistent wave: the longest one (10 ns ticks << 40 | items << 28 | item index << 4 | class + 1)
+#define HGS_TLI_DECL() unsigned long long tli_max__ = 0, tli_t__ = 0; uint32_t tli_it__ = 0, tli_n__ = 0
+#define HGS_TLI_BEGIN() tli_t__ = wall_clock64()
+#define HGS_TLI_END(IT, CLS)                                                                        \
+  do {                                                                                              \
+    const unsigned long long d__ = wall_clock64() - tli_t__;                                        \
+    ++tli_n__;                                                                                      \
+    if (d__ > tli_max__) { tli_max__ = d__; tli_it__ = ((uint32_t)(IT) << 4) | (uint32_t)((CLS) + 1); } \
+  } while (0)
+#define HGS_TLI_TAG() ((tli_max__ << 40) | ((unsigned long long)tli_n__ << 28) | (tli_it__ & 0xfffffffu))
 #else
 #define HGS_TL_BEGIN() do {} while (0)
 #define HGS_TL_END(KID, TAG) do {} while (0)
+#define HGS_TLI_DECL() do {} while (0)
+#define HGS_TLI_BEGIN() do {} while (0)
+#define HGS_TLI_END(IT, CLS) do {} while (0)
+#define HGS_TLI_TAG() 1u
 #endif

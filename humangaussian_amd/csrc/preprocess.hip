@@ -294,7 +294,8 @@ __device__ __forceinline__ uint32_t chunk_prefix(uint32_t tt, uint32_t* wtot, ui
 
 // the first workgroup of the first kernel of a forward call clears the call's counters
 __device__ __forceinline__ void zero_counters(const Layout& L) {
-  if (blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) reinterpret_cast<uint32_t*>(L.ctr)[threadIdx.x] = 0u;
+  if (blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(L.ctr)[i] = 0u;
 }
 
 // LDS-histogram variant (T*4 bytes of dynamic LDS <= 64 KB).  Workgroup (view b, g) owns the

@@ -56,21 +56,20 @@ typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 // the four work items of group `grp`, one per row: longest first (class 0 = full segments, then 1, 2, 3)
-__device__ __forceinline__ bool fetch_item(const View& v, const Layout& L, uint32_t q, uint32_t n0, uint32_t n1,
-                                           uint32_t n2, uint32_t n3, uint4& item) {
+__device__ __forceinline__ bool fetch_item(const uint4* __restrict__ full, const uint4* __restrict__ part, size_t dcap,
+                                           uint32_t q, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, uint4& item) {
   // ONE unconditional load from a selected address (a load per branch made the compiler wait for it on the spot)
-  const size_t ptab = (size_t)16 * v.TT;
   const bool ok = q < n0 + n1 + n2 + n3;
-  const uint4* src = L.items_full + q;
+  const uint4* src = full + q;
   if (q >= n0) {
     const uint32_t q1 = q - n0;
-    src = L.items_part + q1;
+    src = part + q1;
     if (q1 >= n1) {
       const uint32_t q2 = q1 - n1;
-      src = (q2 < n2) ? L.items_part + (ptab - 1 - q2) : L.items_part + (ptab + (q2 - n2));
+      src = (q2 < n2) ? part + (dcap - 1 - q2) : part + (dcap + (q2 - n2));
     }
   }
-  if (!ok) src = L.items_part;                          // (any valid slot; the caller masks every use with the result)
+  if (!ok) src = part;                                  // (any valid slot; the caller masks every use with the result)
   item = *src;
   return ok;
 }
@@ -98,8 +97,13 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   if (threadIdx.x == 0) s_ticket = HGS_BWD_BLOCK_WAVES;      // tickets 0 .. waves - 1: every wave's first group
   __syncthreads();
   const int j = lane >> 4, i = lane & 15;
-  const uint32_t n0 = (uint32_t)L.ctr->alloc3[1], n1 = (uint32_t)(L.ctr->alloc3[1] >> 32);      // items per class
-  const uint32_t n2 = (uint32_t)L.ctr->alloc3[2], n3 = (uint32_t)(L.ctr->alloc3[2] >> 32);
+  // the work tables are per die: this workgroup draws from those of the die the dispatcher puts it on (Counters::sched)
+  const uint32_t die = blockIdx.x % HGS_NXCD, lb = blockIdx.x / HGS_NXCD, nlb = gridDim.x / HGS_NXCD;
+  const size_t dcap = hgs_die_cells(v.TT);
+  const uint4* __restrict__ it_full = L.items_full + (size_t)die * L.full_cap;
+  const uint4* __restrict__ it_part = L.items_part + (size_t)die * 2 * dcap;
+  const uint32_t n0 = (uint32_t)L.ctr->sched[die][0], n1 = (uint32_t)(L.ctr->sched[die][0] >> 32);      // items per class
+  const uint32_t n2 = (uint32_t)L.ctr->sched[die][1], n3 = (uint32_t)(L.ctr->sched[die][1] >> 32);
   const uint32_t ngroups = (n0 + n1 + n2 + n3 + 3u) / 4u;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all);
@@ -121,22 +125,22 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   unsigned long long tl_w0 = 0;
   uint32_t tl_nb = 0;
 #endif
-  // Persistent workgroups of HGS_BWD_BLOCK_WAVES waves (12: one workgroup per CU, three waves per SIMD).  The group
-  // table is longest first; workgroup b
-  // owns groups b, 2 G - 1 - b, 2 G + b, ... (G workgroups; odd rounds run backwards, so every workgroup gets a
+  // Persistent workgroups of HGS_BWD_BLOCK_WAVES waves (12: one workgroup per CU, three waves per SIMD).  A die's group
+  // table is longest first; its workgroup b (of G)
+  // owns groups b, 2 G - 1 - b, 2 G + b, ... (odd rounds run backwards, so every workgroup gets a
   // similar total), and its waves DRAW them in that order through an LDS ticket: the wave that finishes first takes
   // the next, the SIMDs of the CU end within one short group of each other.  (Static round-robin per wave: a view
   // has ~1.16 groups per wave, the kernel ran 60 us for 47 us of mean load, a quarter of it with SIMDs running dry.
   // A device-wide ticket - one device-scope atomic per group on ONE address - serialised at the memory side of the
   // fabric: ~10 ns each, 110 us per view.)
   auto group_of = [&](uint32_t tk) {
-    return tk * gridDim.x + ((HGS_BWD_SNAKE && (tk & 1u)) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+    return tk * nlb + ((HGS_BWD_SNAKE && (tk & 1u)) ? nlb - 1u - lb : lb);
   };
   // the item of the NEXT group is fetched while this one is processed (a group's start is a chain of dependent
   // loads - item, cell list, records - at ~2 us each, and a view has more than one group per wave)
   uint32_t grp = group_of((uint32_t)wv);
   uint4 item;                                            // (cell key, entries, first cell-list slot, state slot or ~0)
-  bool have = fetch_item(v, L, 4u * grp + (uint32_t)j, n0, n1, n2, n3, item);
+  bool have = fetch_item(it_full, it_part, dcap, 4u * grp + (uint32_t)j, n0, n1, n2, n3, item);
   while (grp < ngroups) {                                // (every later ticket of this workgroup lies behind it as well)
     uint32_t grp_next;
     {
@@ -235,7 +239,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     // (issued behind the first gather: the wait for that gather covers it; at the top of the group it sat in front of
     // the setup's waits and its latency was exposed)
     uint4 item_next;
-    const bool have_next = fetch_item(v, L, 4u * grp_next + (uint32_t)j, n0, n1, n2, n3, item_next);
+    const bool have_next = fetch_item(it_full, it_part, dcap, 4u * grp_next + (uint32_t)j, n0, n1, n2, n3, item_next);
     {
       // A pixel whose last contributor (n_contrib, a tile-list position) lies before the item's first record
       // finished before this item - its forward row may have stopped without storing the state - and is never active.
@@ -367,7 +371,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
     if (pending) finish(pa1, pa2, pa3, pit);
 #ifdef HGS_TIMELINE
     if (lane == 0) {
-      unsigned long long* o = L.keys + (size_t)grp * 4;
+      unsigned long long* o = L.keys + ((size_t)grp * HGS_NXCD + die) * 4;
       // (physical SIMD: XCC id and the SE / SH / CU / SIMD fields of HW_ID, for the per-SIMD balance in tools/timeline.py)
       const unsigned long long simd_key = ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) << 16) |
                                           (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff30u);

@@ -213,9 +213,26 @@ __device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L,
   }
 }
 
+// Cell q of length class c in the forward's order: the dies' tables of the class, one behind the other.  pre = the
+// workgroup's LDS table [class][HGS_FWD_PRE_STRIDE]: [x] = cells of the class in the tables of dies < x, [8] = all.
+#define HGS_FWD_PRE_STRIDE 12
+__device__ __forceinline__ uint32_t fwd_cell_key(const Layout& L, size_t dcap, const uint32_t* pre, int c, uint32_t q) {
+  const uint4 p0 = *reinterpret_cast<const uint4*>(pre + c * HGS_FWD_PRE_STRIDE);
+  const uint4 p1 = *reinterpret_cast<const uint4*>(pre + c * HGS_FWD_PRE_STRIDE + 4);
+  uint32_t x = 0, base = 0;
+  if (q >= p0.y) { x = 1; base = p0.y; }
+  if (q >= p0.z) { x = 2; base = p0.z; }
+  if (q >= p0.w) { x = 3; base = p0.w; }
+  if (q >= p1.x) { x = 4; base = p1.x; }
+  if (q >= p1.y) { x = 5; base = p1.y; }
+  if (q >= p1.z) { x = 6; base = p1.z; }
+  if (q >= p1.w) { x = 7; base = p1.w; }
+  return L.fwd_cells[((size_t)x * HGS_NFC + (size_t)c) * dcap + (q - base)];
+}
+
 // One wave = four cells of one length class.
 template <bool STORE>
-__device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L, uint32_t wave_id, int w,
+__device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L, const uint32_t* pre, uint32_t wave_id, int w,
                                                  const SortRec* __restrict__ recs_all,
                                                  float* __restrict__ cstate,
                                                  float* __restrict__ out_color,
@@ -229,16 +246,18 @@ __device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L,
   bool have = false;
   int mycls = HGS_NFC;
   {
-    const size_t cap16 = (size_t)16 * v.TT;
     uint32_t total = 0;
 #pragma unroll
     for (int c = HGS_FWD_C4; c < HGS_NFC; ++c) {
-      const uint32_t nc = (uint32_t)L.ctr->alloc3[3 + c];     // (wave-uniform scalar loads)
-      if (!have && q < nc) { key = L.fwd_cells[c * cap16 + q]; have = true; mycls = c; }
+      const uint32_t nc = pre[c * HGS_FWD_PRE_STRIDE + HGS_NXCD];
+      if (!have && q < nc) { have = true; mycls = c; }
       q -= have ? 0u : nc;
       total += nc;
     }
     if (4u * wave_id >= total) return;                  // surplus wave
+    // (one unconditional load: a row without a cell reads a valid slot and drops it)
+    const uint32_t k_ = fwd_cell_key(L, hgs_die_cells(v.TT), pre, have ? mycls : HGS_FWD_C4, have ? q : 0u);
+    key = have ? k_ : 0u;
   }
   const int g = (int)(key >> 4), c = (int)(key & 15u);
   const int bview = g / v.T, t = g % v.T;
@@ -363,12 +382,24 @@ __device__ __forceinline__ void render_fwd_background(const View& v, const Layou
 // first, one each; then groups of four cells by descending length class) - the item count is only known on the device,
 // and a capacity-sized grid cost more in empty waves (56k of them, ~1 us each) than the blending itself; blocks
 // [cell_blocks, cell_blocks + B*T) write the background of the empty cells.
+//
+// Blocks b, b + ncu, b + 2 ncu, ... share a CU (ncu = cell_blocks / 4), the four waves of a block sit on its four
+// SIMDs (which wave on which rotates from block to block): the waves of a block take ADJACENT items of one round,
+// the blocks of a CU different rounds, in SNAKE order (round rho: rho S + slot for even rho, rho S + S - 1 - slot for
+// odd rho) - so every SIMD gets one item of every round, a heavy + light mix of about the same total, whatever the
+// rotation.  A view has about one item per wave (3657 for 4096 at configs[1]; 6 us of SIMD time each): the kernel
+// ends with its most loaded SIMD (per-SIMD totals 49 .. 87 us of wave time for a mean of 65), and every other way of
+// handing the items out that was tried lost or changed nothing - LDS tickets per workgroup (also one 16-wave
+// workgroup per CU: +3 us), 8 or 12 waves per CU (+7 us), issue priorities by item weight, groups of the longest
+// short cells ahead of the long cells they cost as much as, a die's workgroups on the die's own tables (+3 us) -
+// EXPERIMENTS.md, round 4.
 #define HGS_RENDER_FWD_KERNEL(NAME, STORE)                                                                 \
   extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS) NAME(                                       \
       View v, Layout L, uint32_t cell_blocks, const hgs_status* __restrict__ status,                         \
       const SortRec* __restrict__ recs, float* __restrict__ cstate, float* __restrict__ out_color,           \
       float* __restrict__ out_depth, float* __restrict__ out_alpha) {                                        \
     __shared__ float4 s_rec[HGS_FWD_THREADS / 64][4 * HGS_ROW_F4];      /* [wave][row][record][3] (+ pad) */  \
+    __shared__ __attribute__((aligned(16))) uint32_t s_pre[HGS_NFC * HGS_FWD_PRE_STRIDE];                    \
     const bool overflow = status->overflow != 0;                                                             \
     if (blockIdx.x >= cell_blocks) {                                                                         \
       const uint32_t g = blockIdx.x - cell_blocks;                                                           \
@@ -378,31 +409,42 @@ __device__ __forceinline__ void render_fwd_background(const View& v, const Layou
     if (overflow) return;                                                                                    \
     HGS_TL_BEGIN();                                                                                          \
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);                                     \
+    /* the work tables are per die (Counters::sched); the forward takes the dies' tables of a class one behind the other */ \
+    const size_t dcap = hgs_die_cells(v.TT);                                                                 \
+    if (threadIdx.x < HGS_NFC) {                                                                             \
+      uint32_t acc = 0;                                                                                      \
+      for (int x = 0; x < HGS_NXCD; ++x) {                                                                   \
+        s_pre[threadIdx.x * HGS_FWD_PRE_STRIDE + x] = acc;                                                   \
+        acc += (uint32_t)L.ctr->sched[x][2 + threadIdx.x];                                                   \
+      }                                                                                                      \
+      s_pre[threadIdx.x * HGS_FWD_PRE_STRIDE + HGS_NXCD] = acc;                                              \
+    }                                                                                                        \
+    __syncthreads();                                                                                         \
     uint32_t cnt4[HGS_FWD_C4 + 1], n4 = 0, nrest = 0;     /* long cells per class; the other cells */        \
     _Pragma("unroll") for (int c = 0; c < HGS_NFC; ++c) {                                                    \
-      const uint32_t nc = (uint32_t)L.ctr->alloc3[3 + c];                                                    \
+      const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pre[c * HGS_FWD_PRE_STRIDE + HGS_NXCD]); \
       if (c < HGS_FWD_C4) { cnt4[c] = nc; n4 += nc; } else nrest += nc;                                      \
     }                                                                                                        \
-    /* Items are sorted longest first.  Blocks b, b + ncu, b + 2 ncu, ... share a CU (ncu = cell_blocks / 4), wave w of */ \
-    /* each its SIMD w: the waves of one SIMD take items in SNAKE order (round rho: rho S + simd for even rho, */        \
-    /* rho S + S - 1 - simd for odd rho), so every SIMD gets a heavy + light mix of about the same total. */              \
     const uint32_t nitems = n4 + (nrest + 3u) / 4u;                                                          \
     const uint32_t ncu = max(1u, cell_blocks / 4u), S = ncu * 4u;                                            \
-    const uint32_t simd = (blockIdx.x % ncu) * 4u + (uint32_t)w;                                             \
+    const uint32_t slot = (blockIdx.x % ncu) * 4u + (uint32_t)w;                                             \
+    HGS_TLI_DECL();                                                                                          \
     for (uint32_t rho = blockIdx.x / ncu; rho * S < nitems; rho += (cell_blocks + ncu - 1u) / ncu) {         \
-      const uint32_t it = rho * S + ((rho & 1u) ? S - 1u - simd : simd);                                     \
+      const uint32_t it = rho * S + ((rho & 1u) ? S - 1u - slot : slot);                                     \
       if (it >= nitems) continue;                                                                            \
+      HGS_TLI_BEGIN();                                                                                       \
       if (it < n4) {                                                                                         \
         uint32_t q = it;                                                                                     \
         int c4 = 0;                                                                                          \
         _Pragma("unroll") for (int c = 0; c < HGS_FWD_C4 - 1; ++c) if (c4 == c && q >= cnt4[c]) { q -= cnt4[c]; c4 = c + 1; } \
-        render_fwd_cell4<STORE>(v, L, L.fwd_cells[(size_t)c4 * 16 * v.TT + q], recs, cstate, out_color,     \
+        render_fwd_cell4<STORE>(v, L, fwd_cell_key(L, dcap, s_pre, c4, q), recs, cstate, out_color,         \
                                 out_depth, out_alpha, s_rec[w]);                                             \
       } else {                                                                                               \
-        render_fwd_cells<STORE>(v, L, it - n4, w, recs, cstate, out_color, out_depth, out_alpha, s_rec[w]);  \
+        render_fwd_cells<STORE>(v, L, s_pre, it - n4, w, recs, cstate, out_color, out_depth, out_alpha, s_rec[w]); \
       }                                                                                                      \
+      HGS_TLI_END(it, (it < n4 ? 0 : -1));                                                                   \
     }                                                                                                        \
-    HGS_TL_END(4, 1u);                                                                                       \
+    HGS_TL_END(4, HGS_TLI_TAG());                                                                            \
   }
 HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_store, true)
 HGS_RENDER_FWD_KERNEL(hgs_k_render_fwd_nostore, false)

@@ -106,8 +106,9 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_backward_group_schedule_visits_every_group_once():
-    """Host-side restatement of render_bwd.hip's group_of(): workgroup b of G draws tickets 0, 1, 2, ... and ticket t
-    maps to group t * G + (b, or G - 1 - b on odd t).  Every group of the table must be owned by exactly one
+    """Host-side restatement of render_bwd.hip's group_of(), per die (the work tables are per die, Counters::sched; the
+    launch's workgroups i with i % 8 == x are the G workgroups of die x, b = i // 8): workgroup b of G draws tickets
+    0, 1, 2, ... and ticket t maps to group t * G + (b, or G - 1 - b on odd t).  Every group of the table must be owned by exactly one
     (workgroup, ticket), a workgroup's groups must ascend with the ticket (so it may stop at the first one beyond the
     table), and the snake must give every workgroup the same number of groups +- 1."""
     for G, ngroups in ((1, 7), (4, 4), (256, 3557), (256, 28000), (12, 5), (64, 0)):
@@ -128,3 +129,28 @@ def test_backward_group_schedule_visits_every_group_once():
             per_wg.append(len(mine))
         assert seen == set(range(ngroups))
         assert max(per_wg) - min(per_wg) <= 1
+
+
+def test_forward_takes_the_per_die_cell_tables_as_one_list():
+    """Host-side restatement of render_fwd.hip's fwd_cell_key(): the sort fills one table of non-empty cells per (die,
+    length class); the forward indexes a class as the dies' tables one behind the other through a prefix table
+    [x] = cells of the class on dies < x.  Every (die, slot) must be reached by exactly one index of the class."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        counts = rng.integers(0, 50, size=8)
+        if trial == 0:
+            counts[:] = 0
+        if trial == 1:
+            counts[:] = 0
+            counts[7] = 5
+        pre = np.concatenate([[0], np.cumsum(counts)])
+        seen = set()
+        for q in range(int(pre[8])):
+            x, base = 0, 0
+            for d in range(1, 8):
+                if q >= pre[d]:
+                    x, base = d, int(pre[d])
+            assert 0 <= q - base < counts[x], (q, x, counts)
+            seen.add((x, q - base))
+        assert seen == {(x, i) for x in range(8) for i in range(int(counts[x]))}

@@ -61,7 +61,7 @@ def simd_balance(key, dur, en, what):
           f"last end per SIMD (us): {pc(last)}")
 
 
-def waves(kid, name):
+def waves(kid, name, items=False):
     tm = read(kid)
     slot = np.nonzero(tm[:, 0])[0]
     tm = tm[slot]
@@ -79,6 +79,43 @@ def waves(kid, name):
     simd_balance(((tm[:, 2] >> 32) & 0xf) << 16 | (tm[:, 2] & 0xff30), dur, en, "waves")
     order = np.argsort(-en)[:8]
     print("last waves to finish (slot, start, dur, tag):", [(int(slot[i]), round(float(st[i]), 1), round(float(dur[i]), 1), int(tag[i])) for i in order])
+    if items:
+        wpb = int(os.environ.get("HGS_TL_FWD_WAVES", "4"))
+        xcc = (tm[:, 2] >> 32) & 0xf
+        blk = slot // wpb
+        print("  workgroup -> die: fraction with XCC_ID == workgroup % 8:", float((xcc == blk % 8).mean()), "; XCC_ID of workgroups 0..15:", [int(xcc[blk == b][0]) if (blk == b).any() else -1 for b in range(16)])
+        simd_id = (tm[:, 2] >> 4) & 3
+        print("  SIMD id of waves 0.. of the first workgroups:", [[int(simd_id[slot == b * wpb + k][0]) if (slot == b * wpb + k).any() else -1 for k in range(wpb)] for b in range(3)])
+    if items:       # persistent waves: tag = longest work item (10 ns ticks << 40 | items << 28 | item index << 4 | class + 1)
+        imax, icnt, iidx, icls = (tag >> 40) * TICK_US, (tag >> 28) & 0xfff, (tag >> 4) & 0xffffff, (tag & 0xf) - 1
+        print("  work items per wave min/p50/max: %d / %d / %d (total %d); longest item of a wave us: p50 %.1f p90 %.1f max %.1f" % (
+            icnt.min(), np.percentile(icnt, 50), icnt.max(), icnt.sum(), np.percentile(imax, 50), np.percentile(imax, 90), imax.max()))
+        top = np.argsort(-imax)[:12]
+        print("  longest items (us, item index in the die's order, long class or -1 = group of short cells, wave slot, wave start, wave end):",
+              [(round(float(imax[i]), 1), int(iidx[i]), int(icls[i]), int(slot[i]), round(float(st[i]), 1), round(float(en[i]), 1)) for i in top])
+        # SIMD time a wave consumed, assuming its SIMD's resident waves share the issue slots evenly: with end times
+        # e1 <= e2 <= ... of the n waves of a SIMD, wave k used sum_{i<=k} (e_i - e_{i-1}) / (n - i + 1)
+        key = ((tm[:, 2] >> 32) & 0xf) << 16 | (tm[:, 2] & 0xff30)
+        use = np.zeros(len(en))
+        for kx in np.unique(key):
+            ix = np.nonzero(key == kx)[0]
+            ix = ix[np.argsort(en[ix])]
+            prev, acc = 0.0, 0.0
+            for r, i in enumerate(ix):
+                acc += (en[i] - prev) / (len(ix) - r)
+                prev = en[i]
+                use[i] = acc
+        one = icnt == 1
+        print("  SIMD time per work item (waves with exactly one item), by class and position in the die's order:")
+        for c in sorted(set(icls[one].tolist())):
+            m = one & (icls == c)
+            qs = np.percentile(iidx[m], [0, 25, 50, 75, 100])
+            print(f"    class {c}: {int(m.sum())} items, index {qs[0]:.0f}..{qs[4]:.0f}, SIMD us mean {use[m].mean():.2f} p10 {np.percentile(use[m], 10):.2f} p90 {np.percentile(use[m], 90):.2f} max {use[m].max():.2f}")
+        if one.any():
+            edges = np.linspace(0, iidx[one].max() + 1, 17)
+            print("    by index (16 bins): " + " ".join("%.1f" % (use[one & (iidx >= a) & (iidx < b)].mean() if (one & (iidx >= a) & (iidx < b)).any() else 0) for a, b in zip(edges[:-1], edges[1:])))
+        print(f"    per SIMD: total us min/p10/p50/p90/max: " + " / ".join("%.1f" % np.percentile(np.bincount(np.unique(key, return_inverse=True)[1], weights=use), q) for q in (0, 10, 50, 90, 100)))
+        return
     for lo, hi in ((0, 1), (1, 64), (64, 256), (256, 512), (512, 1024), (1024, 1 << 31)):
         m = (tag >= lo) & (tag < hi)
         if m.any():
@@ -86,7 +123,7 @@ def waves(kid, name):
 
 
 waves(3, "sort_lds")
-waves(4, "render_fwd")
+waves(4, "render_fwd", items=True)
 ph = read(5)
 gp = read(2)
 ok = ph[:, 3] != 0
