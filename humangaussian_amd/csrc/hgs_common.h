@@ -105,14 +105,17 @@ struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a
 };
 
 // Device-side counters of one forward call (zeroed by the first workgroup of the preprocess kernel).
-struct __attribute__((aligned(128))) Counters {   // (one 128 B line per group of counters that one atomic instruction hits)
+struct __attribute__((aligned(128))) CounterLine { uint32_t v; };
+struct __attribute__((aligned(128))) Counters {   // One 128 B line per counter (group) that one kernel's atomics hit: atomics
+  // on DIFFERENT words of a line queue behind each other like same-address ones (with the entry allocator of `fill` on
+  // the line of the sort's allocators, `fill` ran 74 instead of 66 us with 8 views; with the tile allocator, the list
+  // maximum and the class histogram of `tiles` on one line, `tiles` 25 us with 8 views, 14.5 with the three on a line
+  // each (2048 class-histogram atomics queueing at ~7 ns).  Hence also: a line per tile class.
   unsigned long long alloc_eb;   // low: entries handed out to tiles (= R when done)
-  uint32_t entry_alloc;          // entry ids handed out to Gaussians (= R when done)
-  uint32_t pad0;
-  uint32_t max_n;                // longest tile list
-  uint32_t pad;
-  uint32_t cls_hist[HGS_NCLS];   // tiles per class
-  uint32_t cls_cur[HGS_NCLS];    // tile_order cursor per class (starts at the class base, heavy first)
+  __attribute__((aligned(128))) uint32_t entry_alloc;   // entry ids handed out to Gaussians (= R when done)
+  __attribute__((aligned(128))) uint32_t max_n;         // longest tile list
+  CounterLine cls_hist[HGS_NCLS];   // tiles per class (a line each: a view's tiles fall into three or four classes)
+  CounterLine cls_cur[HGS_NCLS];    // tile_order cursor per class (starts at the class base, heavy first)
   __attribute__((aligned(128))) unsigned long long alloc_ps;   // bump allocator of the sort kernel: low: pairs (= cell-list slots) handed out to tiles, high: cell states
   // Work tables are kept PER DIE: the sort puts the work of the tile at tile_order position b into the tables of die
   // b % 8.  [x][0] low / high: backward work items of class 0 (full segments) / class 1; [x][1] low / high: class 2 /
