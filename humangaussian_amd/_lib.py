@@ -19,7 +19,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("HGS_LIB") or os.path.join(_PKG_DIR, "libhgs_rast.so")   # HGS_LIB: A/B experiments only
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared"]
@@ -39,7 +39,7 @@ class HgsSettings(Structure):
 
 class HgsStatus(Structure):
     _fields_ = [
-        ("num_rendered", c_uint32), ("active_tiles", c_uint32), ("num_buckets", c_uint32),
+        ("num_rendered", c_uint32), ("active_tiles", c_uint32), ("num_pairs", c_uint32),
         ("bwd_groups", c_uint32), ("overflow", c_uint32), ("reserved", c_uint32 * 3),
     ]
 
@@ -50,6 +50,7 @@ EXPORTS = {
     "hgs_bin_bytes": (c_size_t, [c_int64]),
     "hgs_img_bytes": (c_size_t, [c_int32, c_int32]),
     "hgs_bwd_scratch_bytes": (c_size_t, [c_int64]),
+    "hgs_bwd_scratch_bytes_pairs": (c_size_t, [c_int64, c_int64]),
     "hgs_geom_bytes_batch": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "hgs_img_bytes_batch": (c_size_t, [c_int32, c_int32, c_int32]),
     "hgs_forward_batch": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 7

@@ -302,7 +302,7 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 12; }
+int hgs_abi_version(void) { return 13; }
 
 size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t H, int32_t W) {
   if (B < 1 || B > HGS_MAX_VIEWS || P < 0 || H <= 0 || W <= 0) return 0;
@@ -318,6 +318,11 @@ size_t hgs_img_bytes(int32_t H, int32_t W) { return hgs_img_bytes_batch(1, H, W)
 // one gradient row per entry + one per (entry, cell) pair
 size_t hgs_bwd_scratch_bytes(int64_t R) {
   return hgs_align_up((size_t)(R > 0 ? R : 0) * (HGS_ROW_FLOATS + HGS_PAIRS_PER_ENTRY * HGS_PROW_FLOATS) * sizeof(float), ALIGN);
+}
+size_t hgs_bwd_scratch_bytes_pairs(int64_t R, int64_t pairs) {
+  if (R <= 0) return 0;
+  if (pairs <= 0 || pairs > R * HGS_PAIRS_PER_ENTRY) return hgs_bwd_scratch_bytes(R);
+  return hgs_align_up(((size_t)R * HGS_ROW_FLOATS + (size_t)pairs * HGS_PROW_FLOATS) * sizeof(float), ALIGN);
 }
 
 int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
@@ -439,10 +444,10 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     const unsigned bg_blocks = (unsigned)v.TT;
     if (store_bwd_state)
       hipLaunchKernelGGL(hgs_k_render_fwd_store, dim3(cell_blocks + bg_blocks), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
-                         status_dev, L.recs, L.cstate, out_color, out_depth, out_alpha);
+                         status_dev, status_mapped, L.recs, L.cstate, out_color, out_depth, out_alpha);
     else
       hipLaunchKernelGGL(hgs_k_render_fwd_nostore, dim3(cell_blocks + bg_blocks), dim3(HGS_FWD_THREADS), 0, stream, v, L, cell_blocks,
-                         status_dev, L.recs, L.cstate, out_color, out_depth, out_alpha);
+                         status_dev, status_mapped, L.recs, L.cstate, out_color, out_depth, out_alpha);
   }
   HGS_LAUNCH_CHECK();
   HGS_STAGE(5);

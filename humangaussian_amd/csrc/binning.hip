@@ -135,8 +135,8 @@ __device__ __forceinline__ void place_tiles(const View& v, const Layout& L, int 
     hgs_status st;
     st.num_rendered = (uint32_t)a_eb;
     st.active_tiles = (uint32_t)v.TT - cls_cnt[0];
-    st.num_buckets = 0;                  // (ABI v10 fields of the bucket design: unused since v11)
-    st.bwd_groups = 0;
+    st.num_pairs = 0;                    // (known when the sort has run: the blend forward publishes it)
+    st.bwd_groups = 0;                   // (ABI v10 field of the bucket design: unused since v11)
     st.overflow = overflow_from_counters(v, L);
     st.reserved[0] = v.entry_capacity;   // carve key for hgs_backward
     st.reserved[1] = L.ctr->max_n;       // longest tile list

@@ -395,8 +395,8 @@ __device__ __forceinline__ void render_fwd_background(const View& v, const Layou
 // EXPERIMENTS.md, round 4.
 #define HGS_RENDER_FWD_KERNEL(NAME, STORE)                                                                 \
   extern "C" __global__ void __launch_bounds__(HGS_FWD_THREADS) NAME(                                       \
-      View v, Layout L, uint32_t cell_blocks, const hgs_status* __restrict__ status,                         \
-      const SortRec* __restrict__ recs, float* __restrict__ cstate, float* __restrict__ out_color,           \
+      View v, Layout L, uint32_t cell_blocks, hgs_status* __restrict__ status,                               \
+      hgs_status* __restrict__ status_host, const SortRec* __restrict__ recs, float* __restrict__ cstate, float* __restrict__ out_color,           \
       float* __restrict__ out_depth, float* __restrict__ out_alpha) {                                        \
     __shared__ float4 s_rec[HGS_FWD_THREADS / 64][4 * HGS_ROW_F4];      /* [wave][row][record][3] (+ pad) */  \
     __shared__ __attribute__((aligned(16))) uint32_t s_pre[HGS_NFC * HGS_FWD_PRE_STRIDE];                    \
@@ -407,6 +407,11 @@ __device__ __forceinline__ void render_fwd_background(const View& v, const Layou
       return;                                                                                                \
     }                                                                                                        \
     if (overflow) return;                                                                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {       /* the sort has finished: the pair total is final (hgs_status.num_pairs) */ \
+      const uint32_t np = (uint32_t)L.ctr->alloc_ps;                                                         \
+      status->num_pairs = np;                                                                                \
+      if (status_host) *reinterpret_cast<volatile uint32_t*>(&status_host->num_pairs) = np;                  \
+    }                                                                                                        \
     HGS_TL_BEGIN();                                                                                          \
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);                                     \
     /* the work tables are per die (Counters::sched); the forward takes the dies' tables of a class one behind the other */ \

@@ -35,7 +35,7 @@ using torch::Tensor;
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
 
-constexpr int RING = 4;
+constexpr int RING = 64;      // status slots (pinned, 32 B each): a slot stays untouched for the next RING - 1 forwards
 
 // Switch the current HIP device only when it is not already the tensors' device.  (torch's own
 // HIPGuard types are keyed on DeviceType::HIP, which the ROCm build masquerades as CUDA.)
@@ -71,6 +71,8 @@ struct DevState {
   hgs_status* ring = nullptr;
   hipEvent_t status_event = nullptr;          // recorded by the library right behind the tiles stage
   int ring_pos = 0;
+  int64_t ring_issued = 0;    // slots handed out so far
+  int64_t last_scratch = 0, last_pairs = 0;   // of the last backward (diagnostic)
   int64_t calls = 0;
   int64_t retries = 0;        // forwards that had to be re-run (capacity or hint exceeded)
   int64_t wait_ns = 0;        // host time blocked in the per-forward status wait (diagnostic)
@@ -172,6 +174,10 @@ struct BwdPlan : torch::CustomClassHolder {
   char *geom = nullptr, *bin = nullptr, *img = nullptr, *rows = nullptr;
   int64_t cap = 0;
   hgs_status status{};
+  // the pinned status slot of the forward call and its issue number: the blend forward writes num_pairs there once the
+  // sort has run; backward() sizes its pair rows by it while the slot is known not to have been handed out again
+  const hgs_status* slot = nullptr;
+  int64_t slot_issue = 0;
   int32_t B = 1, P = 0, M = 0, act = 0;
   bool batched = false;
   bool has_sh = false, has_cp = false, has_sr = false, has_cv = false;
@@ -282,6 +288,9 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     for (; attempt < 4; ++attempt) {
       const int slot = st.ring_pos;
       st.ring_pos = (st.ring_pos + 1) % RING;
+      st.ring_issued += 1;
+      plan->slot = &st.ring[slot];
+      plan->slot_issue = st.ring_issued;
       // The library stores the status into this pinned slot from the fill launch and sets reserved[2] = 1 LAST (behind a
       // system-scope fence): the host polls that word.  (An event recorded behind the fill stage cost the GPU ~6 us of
       // idle time per forward: the record is a barrier packet with a system-scope release in the middle of the chain.)
@@ -403,7 +412,18 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     plan->pre_grads.clear();
     if (g.empty()) plan->alloc_grads(g, dev);
     Tensor &d_means3D = g[0], &d_means2D = g[1], &d_sh = g[2], &d_cp = g[3], &d_opac = g[4], &d_sc = g[5], &d_ro = g[6], &d_cv = g[7];
-    Tensor scratch = at::empty({al256(hgs_bwd_scratch_bytes((int64_t)plan->status.num_rendered))},
+    // pair rows: 16 per entry in the worst case, ~4.4 on an avatar - counted once the forward's sort has run (the
+    // blend forward then publishes hgs_status.num_pairs into the call's pinned slot; nothing is waited for here)
+    int64_t pairs = 0;
+    {
+      DevState& st = state_for(dev.index());
+      std::lock_guard<std::mutex> lk(st.mu);
+      if (plan->slot && st.ring_issued - plan->slot_issue < RING - 1)
+        pairs = (int64_t)*reinterpret_cast<const volatile uint32_t*>(&plan->slot->num_pairs);
+      st.last_pairs = pairs;
+      st.last_scratch = al256(hgs_bwd_scratch_bytes_pairs((int64_t)plan->status.num_rendered, pairs));
+    }
+    Tensor scratch = at::empty({al256(hgs_bwd_scratch_bytes_pairs((int64_t)plan->status.num_rendered, pairs))},
                                at::TensorOptions().dtype(at::kByte).device(dev));
     plan->rows = static_cast<char*>(scratch.data_ptr());
     const auto tb1 = std::chrono::steady_clock::now();
@@ -712,6 +732,8 @@ py::dict device_state(int64_t dev) {
   d["calls"] = st.calls;
   d["retries"] = st.retries;
   d["wait_ns"] = st.wait_ns;
+  d["bwd_pairs_last"] = st.last_pairs;          // pair count the last backward sized its scratch by (0: worst case)
+  d["bwd_scratch_last"] = st.last_scratch;
   {
     static const char* names[8] = {"fwd_pre", "fwd_launch", "fwd_shadow", "fwd_wait", "fwd_total", "bwd_pre", "bwd_launch", "bwd_total"};
     py::dict hn;

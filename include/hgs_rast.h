@@ -60,7 +60,11 @@ typedef struct hgs_status {
                            /* (Gaussian, tile) pair gets an entry only if the box of its         */
                            /* alpha >= 1/255 ellipse touches the tile (results are unchanged)    */
   uint32_t active_tiles;   /* tiles with a non-empty list                              */
-  uint32_t num_buckets;    /* unused since ABI v11 (0)                                 */
+  uint32_t num_pairs;      /* (entry, 4x4-pixel cell) pairs = the pair rows of the backward scratch.  Known */
+                           /* only when the sort has run: 0 in what the status mirror / event delivers, set */
+                           /* in the device copy and in a MAPPED host mirror when the blend forward starts  */
+                           /* (a host that finds it non-zero later may size the scratch by it, see          */
+                           /* hgs_bwd_scratch_bytes_pairs; 0 = not known (yet): size for the worst case)    */
   uint32_t bwd_groups;     /* unused since ABI v11 (0): the blend kernels run persistent waves */
   uint32_t overflow;       /* != 0: outputs are INVALID.  bit0: R exceeded              */
                            /* entry_capacity (retry with >= num_rendered); bit1: a tile */
@@ -81,6 +85,9 @@ size_t hgs_geom_bytes(int32_t P, int32_t image_height, int32_t image_width);
 size_t hgs_bin_bytes(int64_t entry_capacity);
 size_t hgs_img_bytes(int32_t image_height, int32_t image_width);
 size_t hgs_bwd_scratch_bytes(int64_t num_rendered);
+/* the same with the pair rows counted instead of bounded (hgs_status.num_pairs of THAT forward call, once
+ * published; ~4.4 per entry on an avatar instead of 16): 48 B per entry + 40 B per pair */
+size_t hgs_bwd_scratch_bytes_pairs(int64_t num_rendered, int64_t num_pairs);
 /* the same for a batch of B views (geom / img scale with B; the bin buffer and the backward
  * scratch are sized by the entry capacity / num_rendered of ALL views together) */
 size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t image_height, int32_t image_width);

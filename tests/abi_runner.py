@@ -84,7 +84,7 @@ class RawCall:
         raw = self.geom[: self.P * 64].cpu().numpy().tobytes()
         return np.frombuffer(raw, dtype=GEOM_DTYPE)
 
-    def backward(self, g_color, g_depth, g_alpha, use_status=True):
+    def backward(self, g_color, g_depth, g_alpha, use_status=True, pairs_scratch=False):
         lib, dev, P, M = self.lib, self.dev, self.P, self.M
         d = lambda t: None if t is None else t.to(dev).float().contiguous()  # noqa: E731
         gc, gd, ga = d(g_color), d(g_depth), d(g_alpha)
@@ -96,9 +96,14 @@ class RawCall:
                    rotations=nan(P, 4) if self.rots is not None else None,
                    cov3D_precomp=nan(P, 6) if self.cov3D is not None else None)
         st = HgsStatus()
-        (st.num_rendered, st.active_tiles, st.num_buckets, st.bwd_groups, st.overflow) = self.status[:5]
+        (st.num_rendered, st.active_tiles, st.num_pairs, st.bwd_groups, st.overflow) = self.status[:5]
         st.reserved[0], st.reserved[1], st.reserved[2] = self.status[5:8]
-        scratch = torch.zeros(int(lib.hgs_bwd_scratch_bytes(st.num_rendered if use_status else self.capacity)), dtype=torch.uint8, device=dev)
+        if pairs_scratch:      # sized by the published pair count, with a guard region behind it that must stay untouched
+            nbytes = int(lib.hgs_bwd_scratch_bytes_pairs(st.num_rendered, st.num_pairs))
+            scratch = torch.full((nbytes + 4096,), 0xAB, dtype=torch.uint8, device=dev)
+            self.scratch_bytes = nbytes
+        else:
+            scratch = torch.zeros(int(lib.hgs_bwd_scratch_bytes(st.num_rendered if use_status else self.capacity)), dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev)
         rc = lib.hgs_backward(ctypes.byref(self.settings), P, M, _p(self.means3D), _p(self.shs),
                               _p(self.colors_precomp), _p(self.opac), _p(self.scales), _p(self.rots),
@@ -110,4 +115,6 @@ class RawCall:
                               _p(out["cov3D_precomp"]), None, ctypes.c_void_p(stream.cuda_stream))
         stream.synchronize()
         assert rc == 0, rc
+        if pairs_scratch:
+            assert bool((scratch[self.scratch_bytes:] == 0xAB).all()), "the backward wrote behind a scratch sized by num_pairs"
         return {k: (None if v is None else v.cpu()) for k, v in out.items()}

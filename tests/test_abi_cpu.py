@@ -51,6 +51,11 @@ def test_buffer_sizing(lib):
     # backward scratch (include/hgs_rast.h): one 48 B gradient row per entry + 16 (entry, cell) pair rows of 40 B
     assert lib.hgs_bwd_scratch_bytes(1000) == -(-1000 * (48 + 16 * 40) // 256) * 256
     assert lib.hgs_bwd_scratch_bytes(0) == 0 and lib.hgs_bwd_scratch_bytes(-5) == 0
+    # sized by a published pair count: 48 B per entry + 40 B per pair; unknown / impossible counts fall back to the worst case
+    assert lib.hgs_bwd_scratch_bytes_pairs(1000, 4400) == -(-(1000 * 48 + 4400 * 40) // 256) * 256
+    assert lib.hgs_bwd_scratch_bytes_pairs(1000, 0) == lib.hgs_bwd_scratch_bytes(1000)
+    assert lib.hgs_bwd_scratch_bytes_pairs(1000, 16001) == lib.hgs_bwd_scratch_bytes(1000)
+    assert lib.hgs_bwd_scratch_bytes_pairs(0, 5) == 0
 
 
 def test_argument_validation_without_gpu(lib):

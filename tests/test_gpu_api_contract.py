@@ -369,3 +369,21 @@ def test_reference_render_call_replayed_on_the_hip_rasterizer():
         assert float((got.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
     for got, ref in [(ins[k].grad, oin[k].grad) for k in names] + [(m2.grad, om2.grad)]:
         assert float((got.cpu().double() - ref).abs().max()) <= 1e-3 * max(float(ref.abs().max()), 1e-12)
+
+
+def test_backward_scratch_is_sized_by_the_published_pair_count():
+    """The binding allocates the backward's pair rows per backward() call: by hgs_status.num_pairs of the forward call when
+    the blend forward has published it (always the case once the device has been synchronised), else for the worst case
+    of 16 pairs per entry.  Same gradients either way (tests/test_gpu_parity.py)."""
+    from humangaussian_amd import _lib
+    sc, pc, cam = _scene(P=2000, deg=0)
+    bg = torch.zeros(3, device=DEV)
+    out = render(cam, pc, Pipe(), bg)
+    torch.cuda.synchronize()
+    (out["render"].sum() + out["depth_3dgs"].sum()).backward()
+    torch.cuda.synchronize()
+    st = _lib.load_binding().device_state(0)
+    R, pairs = int(st["max_R"]), int(st["bwd_pairs_last"])
+    assert 0 < pairs <= 16 * R
+    assert int(st["bwd_scratch_last"]) == -(-(R * 48 + pairs * 40) // 256) * 256 < -(-(R * 688) // 256) * 256
+    assert all(torch.isfinite(p.grad).all() for p in pc.params() if p.grad is not None)

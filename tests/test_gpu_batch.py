@@ -292,7 +292,7 @@ def test_raw_abi_batch_call_matches_raw_single_calls():
         n_contrib = img[: B * H * W * 4].view(torch.int32).reshape(B, H, W)[b]
         assert torch.equal(n_contrib, s.img[: H * W * 4].view(torch.int32).reshape(H, W))
     hs = HgsStatus()
-    (hs.num_rendered, hs.active_tiles, hs.num_buckets, hs.bwd_groups, hs.overflow) = st[:5]
+    (hs.num_rendered, hs.active_tiles, hs.num_pairs, hs.bwd_groups, hs.overflow) = st[:5]
     hs.reserved[0], hs.reserved[1], hs.reserved[2] = st[5:8]
     nan = lambda *s: torch.full(s, float("nan"), device=dev)  # noqa: E731
     out = dict(means3D=nan(P, 3), means2D=nan(B, P, 3), shs=nan(P, 4, 3), opacities=nan(P, 1), scales=nan(P, 3), rotations=nan(P, 4))

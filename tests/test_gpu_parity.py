@@ -405,4 +405,31 @@ def test_status_via_mapped_pinned_memory_equals_copied_status():
     sc = make_scene(P=500, seed=81, H=48, W=48)
     a = RawCall(sc, mapped=0); assert a.forward() == 0
     b = RawCall(sc, mapped=1); assert b.forward() == 0
-    assert a.status == b.status and a.status[0] > 0
+    # (word 2 = num_pairs: known only once the sort has run - 0 in the copy taken behind the fill stage, published into a
+    #  mapped mirror by the blend forward)
+    assert a.status[:2] + a.status[3:] == b.status[:2] + b.status[3:] and a.status[0] > 0
+    assert a.status[2] == 0 and b.status[2] > 0
+
+
+def test_pair_count_is_published_and_sizes_the_backward_scratch():
+    """hgs_status.num_pairs: 0 in what the status copy delivers (the sort has not run then), the (entry, cell) pair total
+    in a MAPPED host mirror once the blend forward has started.  A scratch of hgs_bwd_scratch_bytes_pairs(R, num_pairs)
+    - 48 B per entry + 40 B per pair instead of 16 pairs per entry - gives the same gradients bit for bit and nothing is
+    written behind it."""
+    sc = make_scene(P=4000, sh_degree=1, seed=11, H=160, W=208, spread=0.5)
+    rc0 = RawCall(sc, capacity=1 << 17, mapped=0)
+    assert rc0.forward() == 0 and not rc0.status[4]
+    assert rc0.status[2] == 0                                   # copied behind the fill stage: not known yet
+    rc = RawCall(sc, capacity=1 << 17, mapped=1)
+    assert rc.forward() == 0 and not rc.status[4]
+    R, pairs = rc.status[0], rc.status[2]
+    assert R == rc0.status[0] and 0 < pairs <= 16 * R
+    lib = rc.lib
+    assert lib.hgs_bwd_scratch_bytes_pairs(R, pairs) < lib.hgs_bwd_scratch_bytes(R)
+    assert lib.hgs_bwd_scratch_bytes_pairs(R, 0) == lib.hgs_bwd_scratch_bytes(R)
+    gc, gd, ga = rand_grads(160, 208, seed=5)
+    g_worst = rc.backward(gc, gd, ga)
+    g_pairs = rc.backward(gc, gd, ga, pairs_scratch=True)
+    for k, a in g_worst.items():
+        if a is not None:
+            assert torch.equal(a.view(torch.int32), g_pairs[k].view(torch.int32)), k
