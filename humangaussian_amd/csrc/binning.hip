@@ -427,7 +427,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
         dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
         dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-        dst[2] = make_uint4(g2.x, g2.y, entry, 0u);
+        dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, false));
         L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);      // (.y, the first pair id, follows in sweep 2)
         sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
       }
@@ -569,7 +569,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
         const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
         dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
         dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-        dst[2] = make_uint4(g2.x, g2.y, entry, 0u);
+        dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, false));
         L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);      // (.y, the first pair id, follows in sweep 2)
         sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
       }
@@ -1014,22 +1014,41 @@ __device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layou
     const bool in = k < n;
     const uint32_t mask = in ? (uint32_t)masks[k] : 0u;
     uint32_t ex[4], before = 0;                          // records of this chunk before this lane, per cell (bytes)
+#if HGS_PAIR_CHUNKS
+    uint32_t tot[4];                                     // records of the chunk, per cell (bytes)
+#endif
 #pragma unroll
     for (int wd = 0; wd < 4; ++wd) {
       const uint32_t mine = hgs_spread4((mask >> (4 * wd)) & 0xfu);
-      ex[wd] = hgs_wave_incl_scan(mine) - mine;
+      const uint32_t inc = hgs_wave_incl_scan(mine);
+      ex[wd] = inc - mine;
+#if HGS_PAIR_CHUNKS
+      tot[wd] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#endif
       before += hgs_bytesum(ex[wd]);
     }
-    const uint32_t rel = pair_base + S.tab[ch][16] + before;      // first pair id of this entry (entry-major)
-    if (in) L.entpair[start + k].y = rel;
+    const uint32_t rel_chunk = pair_base + S.tab[ch][16];          // first pair id of the chunk
+    const uint32_t rel = rel_chunk + before;                       // first pair id of this entry (entry-major)
+    if (in) L.entpair[start + k].y = HGS_PAIR_CHUNKS ? rel_chunk : rel;
     const uint32_t cb = lane < 16 ? S.cell_base[lane] + S.tab[ch][lane] : 0u;
+#if HGS_PAIR_CHUNKS
+    uint32_t cp = 0;                                     // pairs of the chunk in the cells before c (chunk-cell-major rows)
+#endif
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const uint32_t cbase = (uint32_t)__builtin_amdgcn_readlane((int)cb, c);
       if ((mask >> c) & 1u) {
-        const uint32_t slot = cbase + ((ex[c >> 2] >> (8 * (c & 3))) & 0xffu);
+        const uint32_t exc = (ex[c >> 2] >> (8 * (c & 3))) & 0xffu;
+        const uint32_t slot = cbase + exc;
+#if HGS_PAIR_CHUNKS
+        hgs_put_pair(v, L, start + k, rel_chunk + cp + exc, slot);
+#else
         hgs_put_pair(v, L, start + k, rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
+#endif
       }
+#if HGS_PAIR_CHUNKS
+      cp += (tot[c >> 2] >> (8 * (c & 3))) & 0xffu;
+#endif
     }
   }
 }
@@ -1378,7 +1397,7 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
       const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E; \
       dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));              \
       dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);                             \
-      dst[2] = make_uint4(g2.x, g2.y, entry, 0u);                                             \
+      dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, true));                  \
       L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);   /* (.y, the first pair id, follows with the lists) */ \
       masks[k] = (uint16_t)mask;                                                              \
       _Pragma("unroll") for (int wd = 0; wd < 4; ++wd) acc[wd] += hgs_spread4((mask >> (4 * wd)) & 0xfu); \

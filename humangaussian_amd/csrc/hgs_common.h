@@ -96,6 +96,23 @@ struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian
   uint32_t pad;
 };
 #define HGS_LOG2E 1.4426950408889634f
+#ifndef HGS_PAIR_CHUNKS
+#define HGS_PAIR_CHUNKS 0      // 1: pair rows cell-major inside every 64-record chunk of a tile list, for every call (prepared: DESIGN.md 8)
+#endif
+// (HGS_PAIR_CHUNKS builds) SortRec::pad of the record at list position k of a tile of n entries (both blend kernels overwrite the word with the
+// list position when they gather a record; the pair reduction reads it): its 16-bit cell mask, its place in the 64-record
+// CHUNK of the tile list it belongs to (chunks start at the tile's first record) and the chunk's record count, plus the
+// layout of the chunk's pair rows - bit 28 set: chunk-cell-major (the rows of the chunk are one block starting at
+// entpair.y, cell by cell, inside a cell in list order), clear: entry-major (entpair.y = the entry's first row).
+__host__ __device__ __forceinline__ uint32_t hgs_rec_tag(uint32_t mask, uint32_t k, uint32_t n, bool chunk_rows) {
+#if HGS_PAIR_CHUNKS
+  const uint32_t left = n - (k & ~63u);
+  return (mask & 0xffffu) | ((k & 63u) << 16) | (((left < 64u ? left : 64u) - 1u) << 22) | (chunk_rows ? 1u << 28 : 0u);
+#else
+  (void)mask; (void)k; (void)n; (void)chunk_rows;
+  return 0u;
+#endif
+}
 
 struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a tile
   uint32_t base;        // first slot of the list in cell_list (absolute)
@@ -194,6 +211,7 @@ struct View {            // per-call constants, passed by value to every kernel
   int32_t max_tile_hint;             // >0: caller promises no tile list is longer (else overflow bit 2)
   int32_t act;                       // HGS_ACT_* bits: inputs are RAW parameters, activations fused into preprocess
   int32_t cellmajor;                 // != 0: the backward's pair rows live at cell-list slots (calls of >= 3 views), else at entry-major ids
+  int32_t pairchunks;                // != 0 (-DHGS_PAIR_CHUNKS=1 builds): rows cell-major inside every 64-record chunk of a tile list (hgs_rec_tag)
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
