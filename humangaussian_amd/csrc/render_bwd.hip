@@ -539,7 +539,7 @@ hgs_k_pair_reduce_cm(View v, Layout L, const hgs_status* __restrict__ status, co
 // tile starts, not at multiples of 64).  Chunks of the long-list sort classes keep entry-major rows (tag bit 28 clear:
 // entpair.y = the entry's first row).  Cells in ascending order for every entry: the same sums, bit for bit, as the
 // other two forms.
-#define HGS_REDCH_STEPS 8
+struct RedChBuf { hgs_f32x4_a8 a0[4], a1[4]; float2 a2[4]; };
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce_ch(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
                      const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
@@ -549,61 +549,77 @@ hgs_k_pair_reduce_ch(View v, Layout L, const hgs_status* __restrict__ status, co
   const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;      // the wave's window of records
   if (w0 >= R) return;                                                   // (wave-uniform)
   const uint32_t* __restrict__ tags = reinterpret_cast<const uint32_t*>(recs_all) + 11;      // SortRec::pad
-  const uint32_t p = w0 + (uint32_t)lane;
-  const uint32_t tag0 = tags[(size_t)min(p, R - 1u) * 12u];
-  unsigned long long starts = __ballot(p < R && ((tag0 >> 16) & 63u) == 0u);
+  // ONE round trip for everything the wave's chunks can need: a chunk that starts in the window ends inside the next one
+  const uint32_t pa = w0 + (uint32_t)lane;
+  const uint32_t qa = min(pa, R - 1u), qb = min(pa + 64u, R - 1u);
+  const uint32_t tagA = tags[(size_t)qa * 12u], tagB = tags[(size_t)qb * 12u];
+  const uint2 epA = L.entpair[qa], epB = L.entpair[qb];                  // entry id | pairs << 27, first row of the chunk / of the entry
+  unsigned long long starts = __ballot(pa < R && ((tagA >> 16) & 63u) == 0u);
   while (starts) {                                                        // (wave-uniform)
     const int s = (int)__builtin_ctzll(starts);
     starts &= starts - 1ull;
-    const uint32_t t_s = (uint32_t)__builtin_amdgcn_readlane((int)tag0, s);
+    const uint32_t t_s = (uint32_t)__builtin_amdgcn_readlane((int)tagA, s);
     const uint32_t C = ((t_s >> 22) & 63u) + 1u;                          // records of the chunk
     const bool chunk_rows = ((t_s >> 28) & 1u) != 0u;
     const bool have = (uint32_t)lane < C;
-    const uint32_t q = w0 + (uint32_t)s + (have ? (uint32_t)lane : 0u);   // (a chunk lies inside one tile: q < R)
-    const uint2 ep = L.entpair[q];                                        // entry id | pairs << 27, first row of the chunk / of the entry
-    const uint32_t tag = tags[(size_t)q * 12u];
+    // lane l takes record s + l of the two windows
+    const int src = (s + lane) & 63;
+    const bool from_b = s + lane >= 64;
+    const uint32_t tA = (uint32_t)__shfl((int)tagA, src, 64), tB = (uint32_t)__shfl((int)tagB, src, 64);
+    const uint32_t xA = (uint32_t)__shfl((int)epA.x, src, 64), xB = (uint32_t)__shfl((int)epB.x, src, 64);
+    const uint32_t yA = (uint32_t)__shfl((int)epA.y, src, 64), yB = (uint32_t)__shfl((int)epB.y, src, 64);
+    const uint32_t tag = from_b ? tB : tA, epx = from_b ? xB : xA, epy = from_b ? yB : yA;
     const uint32_t mask = have ? (tag & 0xffffu) : 0u;
-    const uint32_t entry = ep.x & 0x7ffffffu, cnt = have ? (ep.x >> 27) : 0u;
-    float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
-    uint32_t cp = 0;                                                      // rows of the chunk in the cells before the step's
-    for (int u0 = 0; u0 < 16; u0 += HGS_REDCH_STEPS) {
-      uint32_t row[HGS_REDCH_STEPS];
-      bool on[HGS_REDCH_STEPS];
-      bool any = false;
+    const uint32_t entry = epx & 0x7ffffffu, cnt = have ? (epx >> 27) : 0u;
+    // the rows of the 16 steps (chunk rows: step = cell; entry-major rows: step = the entry's step-th pair)
+    uint32_t row[16], onbits = 0;
+    {
+      uint32_t cp = 0;                                                    // rows of the chunk in the cells before the step's
 #pragma unroll
-      for (int u = 0; u < HGS_REDCH_STEPS; ++u) {
-        const int step = u0 + u;
-        if (chunk_rows) {                                                 // step = cell
-          on[u] = ((mask >> step) & 1u) != 0u;
-          const unsigned long long bal = __ballot(on[u]);
-          row[u] = ep.y + cp + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      for (int step = 0; step < 16; ++step) {
+        bool on;
+        uint32_t r;
+        if (chunk_rows) {
+          on = ((mask >> step) & 1u) != 0u;
+          const unsigned long long bal = __ballot(on);
+          r = epy + cp + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
           cp += (uint32_t)__popcll(bal);
-          any = any || bal != 0ull;
-        } else {                                                          // step = the entry's step-th pair
-          on[u] = (uint32_t)step < cnt;
-          row[u] = ep.y + (uint32_t)step;
-          any = any || __ballot(on[u]) != 0ull;
+        } else {
+          on = (uint32_t)step < cnt;
+          r = epy + (uint32_t)step;
         }
-        if (!on[u]) row[u] = 0u;                                          // (a valid row: unconditional loads)
-      }
-      if (!any) continue;                                                 // (wave-uniform)
-      hgs_f32x4_a8 a0[HGS_REDCH_STEPS], a1[HGS_REDCH_STEPS];
-      float2 a2[HGS_REDCH_STEPS];
-#pragma unroll
-      for (int u = 0; u < HGS_REDCH_STEPS; ++u) {
-        const float* qq = pair_rows + (size_t)row[u] * HGS_PROW_FLOATS;   // (16 + 16 + 8 B loads at 8 B alignment)
-        a0[u] = *reinterpret_cast<const hgs_f32x4_a8*>(qq);
-        a1[u] = *reinterpret_cast<const hgs_f32x4_a8*>(qq + 4);
-        a2[u] = *reinterpret_cast<const float2*>(qq + 8);
-      }
-#pragma unroll
-      for (int u = 0; u < HGS_REDCH_STEPS; ++u) {
-        if (on[u]) {
-          s0.x += a0[u][0]; s0.y += a0[u][1]; s1.x += a0[u][2]; s1.y += a0[u][3]; s2.x += a1[u][0]; s2.y += a1[u][1];
-          s3.x += a1[u][2]; s3.y += a1[u][3]; s4.x += a2[u].x; s4.y += a2[u].y;
-        }
+        row[step] = on ? r : 0u;                                          // (a valid row: unconditional loads)
+        onbits |= on ? 1u << step : 0u;
       }
     }
+    float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
+    // four batches of four steps, two in flight
+    RedChBuf X, Y;
+#define HGS_REDCH_LOAD(B, U0)                                                                        \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                    \
+    const float* qq = pair_rows + (size_t)row[(U0) + u] * HGS_PROW_FLOATS;      /* 16 + 16 + 8 B at 8 B alignment */ \
+    B.a0[u] = *reinterpret_cast<const hgs_f32x4_a8*>(qq);                                            \
+    B.a1[u] = *reinterpret_cast<const hgs_f32x4_a8*>(qq + 4);                                        \
+    B.a2[u] = *reinterpret_cast<const float2*>(qq + 8);                                              \
+  }
+#define HGS_REDCH_SUM(B, U0)                                                                         \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                    \
+    if ((onbits >> ((U0) + u)) & 1u) {                                                               \
+      s0.x += B.a0[u][0]; s0.y += B.a0[u][1]; s1.x += B.a0[u][2]; s1.y += B.a0[u][3];                \
+      s2.x += B.a1[u][0]; s2.y += B.a1[u][1]; s3.x += B.a1[u][2]; s3.y += B.a1[u][3];                \
+      s4.x += B.a2[u].x; s4.y += B.a2[u].y;                                                          \
+    }                                                                                                \
+  }
+    HGS_REDCH_LOAD(X, 0)
+    HGS_REDCH_LOAD(Y, 4)
+    HGS_REDCH_SUM(X, 0)
+    HGS_REDCH_LOAD(X, 8)
+    HGS_REDCH_SUM(Y, 4)
+    HGS_REDCH_LOAD(Y, 12)
+    HGS_REDCH_SUM(X, 8)
+    HGS_REDCH_SUM(Y, 12)
+#undef HGS_REDCH_LOAD
+#undef HGS_REDCH_SUM
     if (have) {
       float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
       dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
