@@ -30,6 +30,7 @@ extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, con
 extern "C" __global__ void hgs_k_pair_reduce_em(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
 extern "C" __global__ void hgs_k_pair_reduce_cm(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
 extern "C" __global__ void hgs_k_pair_reduce_ch(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
+extern "C" __global__ void hgs_k_pair_reduce_chl(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
 
 namespace {
 
@@ -530,7 +531,10 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);
     if (X > 0) {
-      if (v.pairchunks)
+      if (v.pairchunks && HGS_PAIR_CHUNKS == 2)
+        hipLaunchKernelGGL(hgs_k_pair_reduce_chl, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
+                           pair_rows, rows);
+      else if (v.pairchunks)
         hipLaunchKernelGGL(hgs_k_pair_reduce_ch, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
                            pair_rows, rows);
       else if (v.cellmajor)

@@ -630,3 +630,129 @@ hgs_k_pair_reduce_ch(View v, Layout L, const hgs_status* __restrict__ status, co
     }
   }
 }
+
+// ---- the same with the chunk's block of rows staged in LDS (HGS_PAIR_CHUNKS == 2: parity + batch suites green, 25 us per view).
+// hgs_k_pair_reduce_ch gathers 40 B rows at 40 B stride with a quarter of the lanes live - ten times the cache-line
+// requests of the entry-major stream (31 vs 18 us per view).  Here the block [first row of the chunk, + its pairs) is
+// loaded the way hgs_k_pair_reduce_em loads its rows - coalesced, 128 rows per step, the next step's loads in flight -
+// and the cell steps read it from LDS: the rows of cell c are block positions [cp_c, cp_c + n_c), lane with the r-th set
+// bit takes cp_c + r.  An entry's rows ascend with the cell, so taking them window by window keeps the cell order.
+extern "C" __global__ void __launch_bounds__(256)
+hgs_k_pair_reduce_chl(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
+                      const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
+  __shared__ float2 s_rows[4][HGS_RED_ROWS * HGS_PROW_F2];
+  if (status->overflow) return;
+  const uint32_t R = status->num_rendered;
+  const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+  const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;      // the wave's window of records
+  if (w0 >= R) return;                                                   // (wave-uniform)
+  const uint32_t* __restrict__ tags = reinterpret_cast<const uint32_t*>(recs_all) + 11;      // SortRec::pad
+  const uint32_t pa = w0 + (uint32_t)lane;
+  const uint32_t qa = min(pa, R - 1u), qb = min(pa + 64u, R - 1u);
+  const uint32_t tagA = tags[(size_t)qa * 12u], tagB = tags[(size_t)qb * 12u];
+  const uint2 epA = L.entpair[qa], epB = L.entpair[qb];
+  float2* __restrict__ sl = s_rows[w];
+  unsigned long long starts = __ballot(pa < R && ((tagA >> 16) & 63u) == 0u);
+  while (starts) {                                                        // (wave-uniform)
+    const int s = (int)__builtin_ctzll(starts);
+    starts &= starts - 1ull;
+    const uint32_t t_s = (uint32_t)__builtin_amdgcn_readlane((int)tagA, s);
+    const uint32_t C = ((t_s >> 22) & 63u) + 1u;
+    const bool chunk_rows = ((t_s >> 28) & 1u) != 0u;
+    const bool have = (uint32_t)lane < C;
+    const int src = (s + lane) & 63;
+    const bool from_b = s + lane >= 64;
+    const uint32_t tA = (uint32_t)__shfl((int)tagA, src, 64), tB = (uint32_t)__shfl((int)tagB, src, 64);
+    const uint32_t xA = (uint32_t)__shfl((int)epA.x, src, 64), xB = (uint32_t)__shfl((int)epB.x, src, 64);
+    const uint32_t yA = (uint32_t)__shfl((int)epA.y, src, 64), yB = (uint32_t)__shfl((int)epB.y, src, 64);
+    const uint32_t tag = from_b ? tB : tA, epx = from_b ? xB : xA, epy = from_b ? yB : yA;
+    const uint32_t mask = have ? (tag & 0xffffu) : 0u;
+    const uint32_t entry = epx & 0x7ffffffu, cnt = have ? (epx >> 27) : 0u;
+    float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
+    if (chunk_rows) {
+      // block positions of this lane's rows, per cell; cells' first positions and sizes (wave-uniform)
+      uint32_t rel[16], cp0[16], ncell[16];
+      uint32_t total = 0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const unsigned long long bal = __ballot(((mask >> c) & 1u) != 0u);
+        rel[c] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        cp0[c] = total;
+        ncell[c] = (uint32_t)__popcll(bal);
+        total += ncell[c];
+      }
+      const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)epy, 0);       // the chunk's first row (the same in all its lanes)
+      const float2* __restrict__ srcp = reinterpret_cast<const float2*>(pair_rows) + (size_t)base * HGS_PROW_F2;
+      static_assert(HGS_RED_ROWS * HGS_PROW_F2 == 10 * 64, "ten float2 per lane and window");
+      float2 b0, b1, b2, b3, b4, b5, b6, b7, b8, b9;
+#define HGS_REDL_ISSUE(T0)                                                                                     \
+  {                                                                                                            \
+    const uint32_t t0n__ = (T0);                                                                               \
+    const bool any__ = t0n__ < total;                                                                          \
+    const uint32_t last__ = any__ ? min((uint32_t)HGS_RED_ROWS, total - t0n__) * HGS_PROW_F2 - 1u : 0u;        \
+    const float2* p__ = srcp + (any__ ? (size_t)t0n__ * HGS_PROW_F2 : 0);                                      \
+    b0 = p__[min((uint32_t)lane, last__)];        b1 = p__[min((uint32_t)lane + 64u, last__)];                 \
+    b2 = p__[min((uint32_t)lane + 128u, last__)]; b3 = p__[min((uint32_t)lane + 192u, last__)];                \
+    b4 = p__[min((uint32_t)lane + 256u, last__)]; b5 = p__[min((uint32_t)lane + 320u, last__)];                \
+    b6 = p__[min((uint32_t)lane + 384u, last__)]; b7 = p__[min((uint32_t)lane + 448u, last__)];                \
+    b8 = p__[min((uint32_t)lane + 512u, last__)]; b9 = p__[min((uint32_t)lane + 576u, last__)];                \
+  }
+      if (total) {
+        HGS_REDL_ISSUE(0u);
+        for (uint32_t t0 = 0; t0 < total; t0 += HGS_RED_ROWS) {
+          const uint32_t nrow = min((uint32_t)HGS_RED_ROWS, total - t0);
+          const uint32_t nfl = nrow * HGS_PROW_F2;
+          __builtin_amdgcn_wave_barrier();             // the previous window's LDS reads are done
+          if ((uint32_t)lane < nfl) sl[lane] = b0;
+          if ((uint32_t)lane + 64u < nfl) sl[lane + 64] = b1;
+          if ((uint32_t)lane + 128u < nfl) sl[lane + 128] = b2;
+          if ((uint32_t)lane + 192u < nfl) sl[lane + 192] = b3;
+          if ((uint32_t)lane + 256u < nfl) sl[lane + 256] = b4;
+          if ((uint32_t)lane + 320u < nfl) sl[lane + 320] = b5;
+          if ((uint32_t)lane + 384u < nfl) sl[lane + 384] = b6;
+          if ((uint32_t)lane + 448u < nfl) sl[lane + 448] = b7;
+          if ((uint32_t)lane + 512u < nfl) sl[lane + 512] = b8;
+          if ((uint32_t)lane + 576u < nfl) sl[lane + 576] = b9;
+          HGS_REDL_ISSUE(t0 + HGS_RED_ROWS);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (cp0[c] < t0 + nrow && cp0[c] + ncell[c] > t0) {          // (wave-uniform: the cell has rows in this window)
+              const uint32_t r = rel[c] - t0;                            // (wraps for rows of earlier windows: the range test drops them)
+              if (((mask >> c) & 1u) && r < nrow) {
+                const float2* q = sl + HGS_PROW_F2 * r;
+                const float2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+                s0.x += a0.x; s0.y += a0.y; s1.x += a1.x; s1.y += a1.y; s2.x += a2.x; s2.y += a2.y;
+                s3.x += a3.x; s3.y += a3.y; s4.x += a4.x; s4.y += a4.y;
+              }
+            }
+          }
+        }
+      }
+#undef HGS_REDL_ISSUE
+    } else {
+      // chunks of the long-list sort classes: entry-major rows, gathered (16 + 16 + 8 B loads at 8 B alignment)
+      for (uint32_t j = 0; j < 16u; ++j) {
+        const bool on = j < cnt;
+        if (__ballot(on) == 0ull) break;                                  // (wave-uniform)
+        const float* qq = pair_rows + (size_t)(on ? epy + j : 0u) * HGS_PROW_FLOATS;
+        const hgs_f32x4_a8 a0 = *reinterpret_cast<const hgs_f32x4_a8*>(qq);
+        const hgs_f32x4_a8 a1 = *reinterpret_cast<const hgs_f32x4_a8*>(qq + 4);
+        const float2 a2 = *reinterpret_cast<const float2*>(qq + 8);
+        if (on) {
+          s0.x += a0[0]; s0.y += a0[1]; s1.x += a0[2]; s1.y += a0[3]; s2.x += a1[0]; s2.y += a1[1];
+          s3.x += a1[2]; s3.y += a1[3]; s4.x += a2.x; s4.y += a2.y;
+        }
+      }
+    }
+    if (have) {
+      float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
+      dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
+      dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
+#if HGS_GROW_F4 > 3
+      dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+    }
+  }
+}
