@@ -178,7 +178,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
 View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_tile_hint = 0, int act = 0) {
   View v;
   v.act = act;
-  v.pairchunks = HGS_PAIR_CHUNKS ? 1 : 0;
+  v.pairchunks = HGS_PAIR_CHUNKS == 3 ? (B >= HGS_CELLMAJOR_MIN_VIEWS ? 1 : 0) : (HGS_PAIR_CHUNKS ? 1 : 0);
   v.cellmajor = (!v.pairchunks && B >= HGS_CELLMAJOR_MIN_VIEWS) ? 1 : 0;
   for (int b = 0; b < HGS_MAX_VIEWS; ++b) {
     const hgs_settings& sb = s[b < B ? b : 0];
@@ -531,7 +531,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);
     if (X > 0) {
-      if (v.pairchunks && HGS_PAIR_CHUNKS == 2)
+      if (v.pairchunks && HGS_PAIR_CHUNKS >= 2)
         hipLaunchKernelGGL(hgs_k_pair_reduce_chl, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
                            pair_rows, rows);
       else if (v.pairchunks)

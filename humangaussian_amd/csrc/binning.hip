@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layou
     }
     const uint32_t rel_chunk = pair_base + S.tab[ch][16];          // first pair id of the chunk
     const uint32_t rel = rel_chunk + before;                       // first pair id of this entry (entry-major)
-    if (in) L.entpair[start + k].y = HGS_PAIR_CHUNKS ? rel_chunk : rel;
+    if (in) L.entpair[start + k].y = HGS_CHUNK_ROWS(v) ? rel_chunk : rel;
     const uint32_t cb = lane < 16 ? S.cell_base[lane] + S.tab[ch][lane] : 0u;
 #if HGS_PAIR_CHUNKS
     uint32_t cp = 0;                                     // pairs of the chunk in the cells before c (chunk-cell-major rows)
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layou
         const uint32_t exc = (ex[c >> 2] >> (8 * (c & 3))) & 0xffu;
         const uint32_t slot = cbase + exc;
 #if HGS_PAIR_CHUNKS
-        hgs_put_pair(v, L, start + k, rel_chunk + cp + exc, slot);
+        hgs_put_pair(v, L, start + k, HGS_CHUNK_ROWS(v) ? rel_chunk + cp + exc : rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
 #else
         hgs_put_pair(v, L, start + k, rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
 #endif
@@ -1397,7 +1397,7 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
       const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E; \
       dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));              \
       dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);                             \
-      dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, true));                  \
+      dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, HGS_CHUNK_ROWS(v)));     \
       L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);   /* (.y, the first pair id, follows with the lists) */ \
       masks[k] = (uint16_t)mask;                                                              \
       _Pragma("unroll") for (int wd = 0; wd < 4; ++wd) acc[wd] += hgs_spread4((mask >> (4 * wd)) & 0xfu); \
