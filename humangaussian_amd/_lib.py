@@ -19,7 +19,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("HGS_LIB") or os.path.join(_PKG_DIR, "libhgs_rast.so")   # HGS_LIB: A/B experiments only
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared"]

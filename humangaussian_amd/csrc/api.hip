@@ -26,11 +26,9 @@ __device__ unsigned long long hgs_tl[HGS_TL_KERNELS][HGS_TL_SLOTS][4];
 // render_bwd.hip is a separate translation unit (different optimisation flags)
 extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*, const float*,
                                             const float*, const float*, const float*, const float*,
-                                            const float*, const float*, float*);
-extern "C" __global__ void hgs_k_pair_reduce_em(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
-extern "C" __global__ void hgs_k_pair_reduce_cm(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
-extern "C" __global__ void hgs_k_pair_reduce_ch(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
-extern "C" __global__ void hgs_k_pair_reduce_chl(View, Layout, const hgs_status*, const SortRec*, const float*, float*);
+                                            const float*, const float*, float*, uint32_t);
+extern "C" __global__ void hgs_k_pair_reduce_em(View, Layout, const hgs_status*, const SortRec*, const float*, float*, uint32_t);
+extern "C" __global__ void hgs_k_pair_reduce_ch(View, Layout, const hgs_status*, const SortRec*, const float*, float*, uint32_t);
 
 namespace {
 
@@ -57,8 +55,8 @@ inline int cu_count(hipStream_t stream) {
   cache[dev].store(cus, std::memory_order_relaxed);
   return cus;
 }
-#ifndef HGS_CELLMAJOR_MIN_VIEWS
-#define HGS_CELLMAJOR_MIN_VIEWS 3      // calls with at least this many views keep the backward's pair rows cell-major (binning.hip::hgs_put_pair)
+#ifndef HGS_CHUNK_ROWS_MIN_VIEWS
+#define HGS_CHUNK_ROWS_MIN_VIEWS 3     // calls with at least this many views keep the backward's pair rows chunk-cell-major (binning.hip::hgs_put_pair)
 #endif
 #ifndef HGS_PRE_BWD_VPAR_MIN_VIEWS
 #define HGS_PRE_BWD_VPAR_MIN_VIEWS 2   // calls with at least this many views run the per-Gaussian backward with one thread per
@@ -121,7 +119,7 @@ GeomCarve carve_geom(int B, int P, int H, int W) {
   return c;
 }
 
-struct BinCarve { size_t keys, recs, cell_list, ptab, entpair, cstate, items_full, total; };
+struct BinCarve { size_t keys, recs, cell_list, entpair, cstate, items_full, total; };
 
 // Pair-sized arrays hold HGS_PAIRS_PER_ENTRY slots per entry of capacity: an entry can reach all 16 cells of
 // its tile (zoomed-in cameras), so no second capacity (and no second overflow path) exists.
@@ -134,7 +132,6 @@ BinCarve carve_bin(int64_t cap) {
   c.keys = take(C * 8);
   c.recs = take(C * sizeof(SortRec));
   c.cell_list = take(NP * 8);
-  c.ptab = take(NP * 4);
   c.entpair = take(C * 8);
   // a cell list of len entries has ceil(len / HGS_SEGLEN) - 1 stored states and ceil(len / HGS_SEGLEN) work items, len / HGS_SEGLEN of them full
   c.cstate = take((NP / HGS_SEGLEN + 1) * HGS_CSTATE_FLOATS * sizeof(float));
@@ -166,7 +163,6 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
   L.keys = bp ? reinterpret_cast<unsigned long long*>(bp + b.keys) : nullptr;
   L.recs = bp ? reinterpret_cast<SortRec*>(bp + b.recs) : nullptr;
   L.cell_list = bp ? reinterpret_cast<uint2*>(bp + b.cell_list) : nullptr;
-  L.ptab = bp ? reinterpret_cast<uint32_t*>(bp + b.ptab) : nullptr;
   L.entpair = bp ? reinterpret_cast<uint2*>(bp + b.entpair) : nullptr;
   L.cstate = bp ? reinterpret_cast<float*>(bp + b.cstate) : nullptr;
   L.items_full = bp ? reinterpret_cast<uint4*>(bp + b.items_full) : nullptr;
@@ -178,8 +174,7 @@ Layout make_layout(void* geom, void* bin, void* img, int B, int P, int H, int W,
 View make_view(const hgs_settings* s, int B, int P, int M, int64_t cap, int max_tile_hint = 0, int act = 0) {
   View v;
   v.act = act;
-  v.pairchunks = HGS_PAIR_CHUNKS == 3 ? (B >= HGS_CELLMAJOR_MIN_VIEWS ? 1 : 0) : (HGS_PAIR_CHUNKS ? 1 : 0);
-  v.cellmajor = (!v.pairchunks && B >= HGS_CELLMAJOR_MIN_VIEWS) ? 1 : 0;
+  v.pairchunks = B >= HGS_CHUNK_ROWS_MIN_VIEWS ? 1 : 0;
   for (int b = 0; b < HGS_MAX_VIEWS; ++b) {
     const hgs_settings& sb = s[b < B ? b : 0];
     Cam& c = v.cam[b];
@@ -305,7 +300,7 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 13; }
+int hgs_abi_version(void) { return 14; }
 
 size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t H, int32_t W) {
   if (B < 1 || B > HGS_MAX_VIEWS || P < 0 || H <= 0 || W <= 0) return 0;
@@ -336,7 +331,7 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
                           int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
                           int32_t status_host_mapped, void* status_event, void* const* stage_events,
                           int32_t activation_flags, void* stream_) {
-  if (activation_flags & ~7) return HGS_EINVAL;
+  if (activation_flags & ~(7 | HGS_GRAD_SCALE_TRUE_DERIVATIVE)) return HGS_EINVAL;      // (the gradient bit is the backward's: ignored here)
   if (!batch_ok(s, B) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
     return HGS_EINVAL;
@@ -430,7 +425,10 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     }
     // persistent workgroups (53 KB of LDS: three per CU), tiles heavy first round-robin
     const unsigned sort_wgs = std::min<unsigned>(class_grid(1), (unsigned)(hgs_knob("HGS_SORT_WGS_PER_CU", 3) * ncu));
-    hipLaunchKernelGGL(hgs_k_sort_lds, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
+    if (v.pairchunks)
+      hipLaunchKernelGGL(hgs_k_sort_lds_ch, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
+    else
+      hipLaunchKernelGGL(hgs_k_sort_lds, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
     HGS_LAUNCH_CHECK();
   } else {
     HGS_STAGE(3);
@@ -497,7 +495,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
                            float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
                            int32_t activation_flags, void* stream_) {
   (void)radii;
-  if (activation_flags & ~7) return HGS_EINVAL;
+  if (activation_flags & ~(7 | HGS_GRAD_SCALE_TRUE_DERIVATIVE)) return HGS_EINVAL;
   if ((activation_flags & HGS_ACT_OPACITY_SIGMOID) && P > 0 && !opacities) return HGS_EINVAL;
   if (!batch_ok(s, B) || P < 0 || !geom || !img || entry_capacity < 0 || entry_capacity > HGS_MAX_ENTRY_CAPACITY) return HGS_EINVAL;
   if (status && status->overflow) return HGS_EINVAL;
@@ -517,8 +515,14 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
                                const_cast<void*>(img), B, P, v.H, v.W, cap);
   const hgs_status* status_dev = reinterpret_cast<const hgs_status*>(
       static_cast<const char*>(geom) + carve_geom(B, P, v.H, v.W).status);
-  // gradient rows: [X entries][12] then the pair rows [16 X][10], X = what the caller sized the scratch by
+  // gradient rows: [X entries][12] then the pair rows [pair_cap][10]; X = what the caller sized the scratch by, pair_cap =
+  // status->num_pairs (hgs_bwd_scratch_bytes_pairs) or the worst case of 16 per entry (hgs_bwd_scratch_bytes).  The kernels
+  // compare pair_cap with the count the sort left on the device: a stale / wrong count writes nothing out of bounds and
+  // turns the gradients into NaN instead.
   const int64_t X = status ? (int64_t)status->num_rendered : cap;
+  const int64_t worst = X * HGS_PAIRS_PER_ENTRY;
+  const int64_t pc = (status && status->num_pairs > 0 && (int64_t)status->num_pairs < worst) ? (int64_t)status->num_pairs : worst;
+  const uint32_t pair_cap = (uint32_t)(pc > 0xffffffffll ? 0xffffffffll : pc);
   float* rows = static_cast<float*>(bwd_scratch);
   float* pair_rows = rows + (size_t)X * HGS_ROW_FLOATS;
   HGS_STAGE(0);
@@ -527,22 +531,16 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     // 12 per CU, 3 per SIMD); the waves of a workgroup draw its groups of four work items through an LDS ticket
     const int resident = hgs_knob("HGS_BWD_WAVES_PER_CU", 12) * cu_count(stream);
     hipLaunchKernelGGL(hgs_k_render_bwd, dim3((unsigned)std::max(HGS_NXCD, resident / HGS_BWD_BLOCK_WAVES / HGS_NXCD * HGS_NXCD)), dim3(64 * HGS_BWD_BLOCK_WAVES), 0, stream, v, L, status_dev, L.recs, L.cstate,
-                       out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows);
+                       out_color, out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, pair_rows, pair_cap);
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);
     if (X > 0) {
-      if (v.pairchunks && HGS_PAIR_CHUNKS >= 2)
-        hipLaunchKernelGGL(hgs_k_pair_reduce_chl, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
-                           pair_rows, rows);
-      else if (v.pairchunks)
+      if (v.pairchunks)
         hipLaunchKernelGGL(hgs_k_pair_reduce_ch, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
-                           pair_rows, rows);
-      else if (v.cellmajor)
-        hipLaunchKernelGGL(hgs_k_pair_reduce_cm, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
-                           pair_rows, rows);
+                           pair_rows, rows, pair_cap);
       else
         hipLaunchKernelGGL(hgs_k_pair_reduce_em, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
-                           pair_rows, rows);
+                           pair_rows, rows, pair_cap);
       HGS_LAUNCH_CHECK();
     }
   }

@@ -254,17 +254,15 @@ hgs_k_fill_ga(View v, Layout L, hgs_status* __restrict__ status, hgs_status* __r
 // ---------------------------------------------------------------------------- 3. sort
 namespace {
 
-// One (entry, cell) pair of record `rec`: `pidx` = its entry-major index (the pairs of an entry are neighbours, in cell
-// order), `slot` = its cell-list slot.  Where the backward writes the pair's gradient row is a per-call choice
-// (View::cellmajor):
-//  * entry-major rows (1-2 views): row id = pidx, carried in the list element; the reduction streams the rows of 64
+// One (entry, cell) pair of record `rec`: its cell-list element = (record index, id of the pair's gradient row).  Where the
+// blend backward writes the row is a per-call choice (View::pairchunks):
+//  * entry-major ids (1-2 views): the rows of an entry are neighbours, in cell order; the reduction streams the rows of 64
 //    entries as one contiguous block (17 us per view) - the backward pays with isolated 40 B stores (+3 us);
-//  * cell-major rows (>= 3 views): row id = slot, ptab[pidx] = slot tells the reduction where the rows of an entry are;
-//    the backward writes 640 B bursts - with 8 views in flight the isolated stores made it bandwidth-bound
-//    (428 -> 273 us), the reduction gathers instead of streaming (179 -> 228 us).
-__device__ __forceinline__ void hgs_put_pair(const View& v, const Layout& L, uint32_t rec, uint32_t pidx, uint32_t slot) {
-  L.cell_list[slot] = make_uint2(rec, v.cellmajor ? slot : pidx);
-  if (v.cellmajor) L.ptab[pidx] = slot;
+//  * chunk-cell-major ids (>= 3 views): the rows of every 64-record chunk of the tile list are one block, cell by cell, inside
+//    a cell in list order (hgs_rec_tag): a 16-record batch of the backward writes one or two contiguous runs of rows - with 8
+//    views in flight the isolated stores made it bandwidth-bound (428 -> 273 us) - and the reduction still reads blocks.
+__device__ __forceinline__ void hgs_put_pair(const Layout& L, uint32_t rec, uint32_t row_id, uint32_t slot) {
+  L.cell_list[slot] = make_uint2(rec, row_id);
 }
 
 // Ranges of one tile, from the lengths of its 16 cell lists: pairs (= cell-list slots), cell states, work items.
@@ -427,7 +425,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
         dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
         dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-        dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, false));
+        dst[2] = make_uint4(g2.x, g2.y, entry, v.pairchunks ? hgs_rec_tag(mask, k, n, false) : 0u);
         L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);      // (.y, the first pair id, follows in sweep 2)
         sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
       }
@@ -493,7 +491,7 @@ __device__ __forceinline__ void gather_records(const View& v, const Layout& L, i
         if (bit) {
           const uint32_t rank = S.tab[ch][c] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
           const uint32_t slot = S.cell_base[c] + rank;
-          hgs_put_pair(v, L, start + k, pair_base + rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
+          hgs_put_pair(L, start + k, pair_base + rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
         }
       }
     }
@@ -569,7 +567,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
         const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E;
         dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));
         dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);
-        dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, false));
+        dst[2] = make_uint4(g2.x, g2.y, entry, v.pairchunks ? hgs_rec_tag(mask, k, n, false) : 0u);
         L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);      // (.y, the first pair id, follows in sweep 2)
         sorted[k] = (unsigned long long)mask;               // the key is consumed: its slot keeps the mask
       }
@@ -647,7 +645,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
       mask &= mask - 1u;
       const uint32_t exw = (c < 8) ? (c < 4 ? ex[0] : ex[1]) : (c < 12 ? ex[2] : ex[3]);
       const uint32_t slot = S.cell_base[c] + S.tab[ch][c] + ((exw >> (8 * (c & 3))) & 0xffu);
-      hgs_put_pair(v, L, start + k, pair_base + rel + r, slot);
+      hgs_put_pair(L, start + k, pair_base + rel + r, slot);
       ++r;
     }
   }
@@ -954,7 +952,7 @@ static_assert(sizeof(uint32_t) * (HGS_RANK_NB_MAX + 1) >= sizeof(uint16_t) * 409
 
 // Cell tables + cell lists of one tile from the masks of its records in list order (what gather_records_single does
 // behind its sweep 1).  All NT threads of the workgroup take part; wave 0 has ISSUED the range allocation (`ca`).
-template <int NT>
+template <int NT, bool CH>
 __device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layout& L, uint32_t order_pos, uint32_t start, uint32_t n,
                                                       const uint16_t* __restrict__ masks, GatherLds<64>& S, const CellAlloc& ca,
                                                       unsigned long long* tp) {
@@ -1014,41 +1012,29 @@ __device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layou
     const bool in = k < n;
     const uint32_t mask = in ? (uint32_t)masks[k] : 0u;
     uint32_t ex[4], before = 0;                          // records of this chunk before this lane, per cell (bytes)
-#if HGS_PAIR_CHUNKS
-    uint32_t tot[4];                                     // records of the chunk, per cell (bytes)
-#endif
+    uint32_t tot[4];                                     // (CH) records of the chunk, per cell (bytes)
 #pragma unroll
     for (int wd = 0; wd < 4; ++wd) {
       const uint32_t mine = hgs_spread4((mask >> (4 * wd)) & 0xfu);
       const uint32_t inc = hgs_wave_incl_scan(mine);
       ex[wd] = inc - mine;
-#if HGS_PAIR_CHUNKS
-      tot[wd] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-#endif
+      if (CH) tot[wd] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
       before += hgs_bytesum(ex[wd]);
     }
     const uint32_t rel_chunk = pair_base + S.tab[ch][16];          // first pair id of the chunk
     const uint32_t rel = rel_chunk + before;                       // first pair id of this entry (entry-major)
-    if (in) L.entpair[start + k].y = HGS_CHUNK_ROWS(v) ? rel_chunk : rel;
+    if (in) L.entpair[start + k].y = CH ? rel_chunk : rel;
     const uint32_t cb = lane < 16 ? S.cell_base[lane] + S.tab[ch][lane] : 0u;
-#if HGS_PAIR_CHUNKS
-    uint32_t cp = 0;                                     // pairs of the chunk in the cells before c (chunk-cell-major rows)
-#endif
+    uint32_t cp = 0;                                     // (CH) pairs of the chunk in the cells before c
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const uint32_t cbase = (uint32_t)__builtin_amdgcn_readlane((int)cb, c);
       if ((mask >> c) & 1u) {
         const uint32_t exc = (ex[c >> 2] >> (8 * (c & 3))) & 0xffu;
         const uint32_t slot = cbase + exc;
-#if HGS_PAIR_CHUNKS
-        hgs_put_pair(v, L, start + k, HGS_CHUNK_ROWS(v) ? rel_chunk + cp + exc : rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
-#else
-        hgs_put_pair(v, L, start + k, rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
-#endif
+        hgs_put_pair(L, start + k, CH ? rel_chunk + cp + exc : rel + (uint32_t)__popc(mask & ((1u << c) - 1u)), slot);
       }
-#if HGS_PAIR_CHUNKS
-      cp += (tot[c >> 2] >> (8 * (c & 3))) & 0xffu;
-#endif
+      if (CH) cp += (tot[c >> 2] >> (8 * (c & 3))) & 0xffu;
     }
   }
 }
@@ -1315,7 +1301,7 @@ __device__ __forceinline__ bool rank_keys_stream(const Layout& L, uint32_t start
   return degenerate;
 }
 
-template <int NT>
+template <int NT, bool CH>
 __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, uint32_t order_pos, int g, uint32_t start, uint32_t n,
                                                unsigned long long* pairs, RankLds& R, GatherLds<64>& S, bool& degenerate_out,
                                                unsigned long long* tp) {
@@ -1397,7 +1383,7 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
       const float qa = -0.5f * ca * HGS_LOG2E, qb = -cb * HGS_LOG2E, qc = -0.5f * cc * HGS_LOG2E; \
       dst[0] = make_uint4(g0.x, g0.y, __float_as_uint(qa), __float_as_uint(qb));              \
       dst[1] = make_uint4(__float_as_uint(qc), g1.y, g1.z, g1.w);                             \
-      dst[2] = make_uint4(g2.x, g2.y, entry, hgs_rec_tag(mask, k, n, HGS_CHUNK_ROWS(v)));     \
+      dst[2] = make_uint4(g2.x, g2.y, entry, CH ? hgs_rec_tag(mask, k, n, true) : 0u);        \
       L.entpair[start + k].x = entry | ((uint32_t)__popc(mask) << 27);   /* (.y, the first pair id, follows with the lists) */ \
       masks[k] = (uint16_t)mask;                                                              \
       _Pragma("unroll") for (int wd = 0; wd < 4; ++wd) acc[wd] += hgs_spread4((mask >> (4 * wd)) & 0xfu); \
@@ -1446,10 +1432,10 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
     const uint32_t word = R.tot16[2 * (c >> 2) + (c & 1)];
     hgs_alloc_cell_ranges_issue(L, order_pos, (word >> (16 * ((c >> 1) & 1))) & 0xffffu, ca);
   }
-  cell_lists_from_masks<NT>(v, L, order_pos, start, n, masks, S, ca, tp);
+  cell_lists_from_masks<NT, CH>(v, L, order_pos, start, n, masks, S, ca, tp);
 }
 
-template <int NT>
+template <int NT, bool CH>
 __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, const hgs_status* __restrict__ status,
                                                unsigned long long* pairs, RankLds& R, GatherLds<64>& S) {
   if (status->overflow) return;
@@ -1468,7 +1454,7 @@ __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, c
     // the kernel ends with its longest list: those workgroups win the issue arbitration against their co-residents
     if (n > (uint32_t)HGS_RANK_PRIO) __builtin_amdgcn_s_setprio(3);
 #endif
-    rank_sort_tile<NT>(v, L, b, g, start, n, pairs, R, S, degenerate, tp);
+    rank_sort_tile<NT, CH>(v, L, b, g, start, n, pairs, R, S, degenerate, tp);
 #if HGS_RANK_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1491,15 +1477,20 @@ __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, c
 }  // namespace
 
 static_assert(16 * HGS_SORT_NT >= 4096, "the rank sort takes every list of the LDS class");
-extern "C" __global__ void __launch_bounds__(HGS_SORT_NT) __attribute__((amdgpu_waves_per_eu(HGS_SORT_WAVES_PER_EU, HGS_SORT_WAVES_PER_EU)))
-hgs_k_sort_lds(View v, Layout L, const hgs_status* __restrict__ status) {
-  __shared__ unsigned long long pairs[4096];
-  __shared__ GatherLds<64> S;
-  __shared__ RankLds R;
-  HGS_TL_BEGIN();
-  sort_rank_body<HGS_SORT_NT>(v, L, status, pairs, R, S);
-  HGS_TL_END(3, 0u);
-}
+// Two instantiations: pair-row ids entry-major (calls of 1-2 views) / chunk-cell-major (hgs_k_sort_lds_ch: >= 3 views,
+// View::pairchunks) - a compile-time choice inside the kernel, so neither form pays for the other's id arithmetic.
+#define HGS_SORT_LDS_KERNEL(NAME, CH)                                                                                  \
+  extern "C" __global__ void __launch_bounds__(HGS_SORT_NT) __attribute__((amdgpu_waves_per_eu(HGS_SORT_WAVES_PER_EU, HGS_SORT_WAVES_PER_EU))) \
+  NAME(View v, Layout L, const hgs_status* __restrict__ status) {                                                      \
+    __shared__ unsigned long long pairs[4096];                                                                         \
+    __shared__ GatherLds<64> S;                                                                                        \
+    __shared__ RankLds R;                                                                                              \
+    HGS_TL_BEGIN();                                                                                                    \
+    sort_rank_body<HGS_SORT_NT, CH>(v, L, status, pairs, R, S);                                                        \
+    HGS_TL_END(3, 0u);                                                                                                 \
+  }
+HGS_SORT_LDS_KERNEL(hgs_k_sort_lds, false)
+HGS_SORT_LDS_KERNEL(hgs_k_sort_lds_ch, true)
 
 extern "C" __global__ void __launch_bounds__(1024)
 hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {

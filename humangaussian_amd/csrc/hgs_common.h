@@ -96,25 +96,16 @@ struct __attribute__((aligned(16))) SortRec {   // 48 B, one per (tile, Gaussian
   uint32_t pad;
 };
 #define HGS_LOG2E 1.4426950408889634f
-#ifndef HGS_PAIR_CHUNKS
-#define HGS_PAIR_CHUNKS 0      // pair rows cell-major inside every 64-record chunk of a tile list (prepared: DESIGN.md 8): 1: every call,
-#endif                         // gathering reduction; 2: every call, reduction through LDS; 3: calls of >= HGS_CELLMAJOR_MIN_VIEWS views
-                               // (a run-time choice, View::pairchunks), reduction through LDS, entry-major rows otherwise
-// (does this call keep chunk-cell-major rows?  a compile-time constant except in mode 3)
-#define HGS_CHUNK_ROWS(v) (HGS_PAIR_CHUNKS == 3 ? ((v).pairchunks != 0) : (HGS_PAIR_CHUNKS != 0))
-// (HGS_PAIR_CHUNKS builds) SortRec::pad of the record at list position k of a tile of n entries (both blend kernels overwrite the word with the
-// list position when they gather a record; the pair reduction reads it): its 16-bit cell mask, its place in the 64-record
-// CHUNK of the tile list it belongs to (chunks start at the tile's first record) and the chunk's record count, plus the
-// layout of the chunk's pair rows - bit 28 set: chunk-cell-major (the rows of the chunk are one block starting at
-// entpair.y, cell by cell, inside a cell in list order), clear: entry-major (entpair.y = the entry's first row).
+// SortRec::pad of the record at list position k of a tile of n entries, written by the sort in calls that keep their pair rows
+// CHUNK-cell-major (View::pairchunks: calls of >= HGS_CHUNK_ROWS_MIN_VIEWS views); both blend kernels overwrite the word with the
+// list position when they gather a record, the pair reduction hgs_k_pair_reduce_ch reads it: the entry's 16-bit cell mask, its
+// place in the 64-record CHUNK of the tile list it belongs to (chunks start at the tile's first record) and the chunk's record
+// count, plus the layout of the chunk's pair rows - bit 28 set: chunk-cell-major (the rows of the chunk are one block starting
+// at entpair.y, cell by cell, inside a cell in list order), clear: entry-major (entpair.y = the entry's first row; the long-list
+// sort classes).  tests/test_pair_rows_cpu.py restates the id arithmetic of both kernels.
 __host__ __device__ __forceinline__ uint32_t hgs_rec_tag(uint32_t mask, uint32_t k, uint32_t n, bool chunk_rows) {
-#if HGS_PAIR_CHUNKS  /* (mode 3 tags every record: the reduction of an entry-major call does not read the word) */
   const uint32_t left = n - (k & ~63u);
   return (mask & 0xffffu) | ((k & 63u) << 16) | (((left < 64u ? left : 64u) - 1u) << 22) | (chunk_rows ? 1u << 28 : 0u);
-#else
-  (void)mask; (void)k; (void)n; (void)chunk_rows;
-  return 0u;
-#endif
 }
 
 struct __attribute__((aligned(16))) CellInfo {  // one of the 16 cell lists of a tile
@@ -184,8 +175,7 @@ struct Layout {          // pointers carved out of the caller's buffers
   unsigned long long* keys;
   SortRec* recs;
   uint2* cell_list;           // [16 C]: (record index, id of the pair's gradient row), cell-major per tile
-  uint32_t* ptab;             // [16 C] cell-major rows only (binning.hip::hgs_put_pair): ptab[entry-major pair index] = the pair's slot
-  uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first entry-major pair index) - what the pair reduction reads
+  uint2* entpair;             // [C] by record index: (entry id | pairs << 27, first pair row of the entry - or of its chunk, hgs_rec_tag) - what the pair reduction reads
   float* cstate;              // [C/4 + 1][6][16]
   uint32_t full_cap;          // slots of ONE die's items_full table (the full segments of all lists would fit in each)
   uint4* items_full;          // [HGS_NXCD][full_cap]: (cell key = g * 16 + c, entries, first cell-list slot, state slot or ~0): all a wave needs to start
@@ -213,8 +203,8 @@ struct View {            // per-call constants, passed by value to every kernel
   uint32_t entry_capacity;
   int32_t max_tile_hint;             // >0: caller promises no tile list is longer (else overflow bit 2)
   int32_t act;                       // HGS_ACT_* bits: inputs are RAW parameters, activations fused into preprocess
-  int32_t cellmajor;                 // != 0: the backward's pair rows live at cell-list slots (calls of >= 3 views), else at entry-major ids
-  int32_t pairchunks;                // != 0 (-DHGS_PAIR_CHUNKS builds only): rows cell-major inside every 64-record chunk of a tile list (hgs_rec_tag)
+  int32_t pairchunks;                // != 0 (calls of >= 3 views): the backward's pair rows are cell-major inside every 64-record chunk of a
+                                     // tile list (hgs_rec_tag): a batch of the blend backward writes runs of rows; 0: entry-major ids
 };
 
 static inline size_t hgs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -584,7 +584,9 @@ __device__ __forceinline__ void preprocess_bwd_body(
             ds += dLik * Rm[ii][k];
             D[ii][k] = dLik * sv[k];
           }
-          a_sc[k] += ds * v.scale_modifier;
+          // the fork returns dL/d(mod * scale) here (its computeCov3D backward drops the modifier's factor); the true
+          // derivative only on request (HGS_GRAD_SCALE_TRUE_DERIVATIVE) - identical at scale_modifier 1
+          a_sc[k] += (v.act & HGS_GRAD_SCALE_TRUE_DERIVATIVE) ? ds * v.scale_modifier : ds;
         }
         const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
         a_rot[0] += 2.f * (-qz * D[0][1] + qy * D[0][2] + qz * D[1][0] - qx * D[1][2] - qy * D[2][0] + qx * D[2][1]);

@@ -31,8 +31,8 @@
 // (First version: v_mfma_f32_16x16x4_f32 with a block-diagonal A - K slot = cell - to get the same layout: three
 // quarters of its 32 cycles multiplied zeros, and the matrix pipe was 40 % of the kernel's issue time.)
 //
-// An (entry, cell) pair row lands at the row id the list element carries (the pair's entry-major id, or its cell-list slot
-// in calls of >= 3 views: binning.hip::hgs_put_pair); hgs_k_pair_reduce_{em,cm} adds the pair rows of
+// An (entry, cell) pair row lands at the row id the list element carries (the pair's entry-major id, or its chunk-cell-major
+// id in calls of >= 3 views: binning.hip::hgs_put_pair); hgs_k_pair_reduce_{em,ch} adds the pair rows of
 // every entry in cell order (fixed order: no atomics, bitwise reproducible) into one 48 B gradient row per
 // entry, which hgs_k_preprocess_bwd sums per Gaussian.  Pair rows are 40 B (the ten sums, packed).
 //
@@ -82,13 +82,16 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
                  const float* __restrict__ out_color,
                  const float* __restrict__ out_depth, const float* __restrict__ out_alpha,
                  const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-                 const float* __restrict__ dL_dalpha, float* __restrict__ pair_rows) {
+                 const float* __restrict__ dL_dalpha, float* __restrict__ pair_rows, uint32_t pair_cap) {
   // wave-private LDS slices
   __shared__ float4 s_rec_all[HGS_BWD_BLOCK_WAVES][4 * HGS_ROW_F4];                 // [row][record][3] (+ pad: rows on different banks)
   __shared__ __attribute__((aligned(16))) float stage_k_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];   // [iteration][pixel lane]
   __shared__ __attribute__((aligned(16))) float stage_w_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];
   __shared__ uint32_t s_ticket;
   if (status->overflow) return;
+  // the caller sized the scratch for pair_cap pair rows (hgs_backward*: status->num_pairs, or 16 per entry); a count the
+  // device does not confirm writes nothing here and poisons the gradient rows in the reduction (NaN: loud, in bounds)
+  if ((uint32_t)L.ctr->alloc_ps > pair_cap) return;
   const int lane = (int)threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   float4* __restrict__ s_rec = s_rec_all[wv];
@@ -392,7 +395,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #define HGS_RED_ROWS 128
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
-                  const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
+                  const float* __restrict__ pair_rows, float* __restrict__ grad_rows, uint32_t pair_cap) {
   __shared__ float2 s_rows[4][HGS_RED_ROWS * HGS_PROW_F2];
   if (status->overflow) return;
   const uint32_t R = status->num_rendered;
@@ -402,7 +405,10 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
   const bool have = p < R;
   uint2 ep = make_uint2(0u, 0u);
   if (have) ep = L.entpair[p];                                // entry id | pairs << 27, first pair id
-  const uint32_t entry = ep.x & 0x7ffffffu, cnt = ep.x >> 27;
+  const uint32_t entry = ep.x & 0x7ffffffu;
+  // more pairs than the scratch was sized for (hgs_k_render_bwd wrote none): no row is read, the gradient rows are NaN
+  const bool poisoned = (uint32_t)L.ctr->alloc_ps > pair_cap;
+  const uint32_t cnt = poisoned ? 0u : ep.x >> 27;
   const uint32_t incl = hgs_wave_incl_scan(cnt), off = incl - cnt;
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
@@ -470,6 +476,7 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
     }
   }
   if (have) {
+    if (poisoned) s0.x = s0.y = s1.x = s1.y = s2.x = s2.y = s3.x = s3.y = s4.x = s4.y = __builtin_nanf("");
     float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
     dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
     dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
@@ -479,167 +486,25 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
   }
 }
 
-// ------------------------------------------------------------------------------ pair reduction, CELL-major rows (calls of >= 3 views)
-// Pair rows live at the CELL-LIST SLOT of the pair: the backward writes the 16 rows of a batch as one 640 B burst (with
-// entry-major rows every 40 B row is an isolated partial-line store - 5x write amplification at the fabric, which made
-// the batched backward bandwidth-bound: 1.74 GB in 379 us for 8 views).  The sort kernel's entry-major table `ptab`
-// tells the reduction where the rows of an entry are: thread = entry (list position) reads its `cnt` slots (contiguous
-// 4 B words) and gathers the rows, cells in ascending order - the same sums in the same order as the entry-major form.
-// Consecutive entries of a tile sit at consecutive slots of every cell list they share, so the lanes of a wave read
-// neighbouring rows: L1 / L2 serve most of the 40 B gathers.
-#define HGS_RED_UNROLL 4
+// ------------------------------------------------------------------------------ pair reduction, CHUNK-cell-major rows (calls of >= 3 views)
+// With entry-major rows every 40 B row of the blend backward is an isolated partial-line store - 5x write amplification at
+// the fabric, which made the batched backward bandwidth-bound (1.74 GB in 379 us for 8 views).  In calls of >= 3 views
+// (View::pairchunks) the rows of every 64-record chunk of a tile list are ONE block (entpair.y = its first row), cell by
+// cell, inside a cell in list order: a 16-record batch of the backward lies in one or two chunks and writes one or two
+// contiguous runs of rows.  Here a wave takes the chunks that START in its window of 64 records (chunks start at tile
+// starts, not at multiples of 64); lane l = record l of the chunk.  The chunk's block [first row, + its pairs) is loaded the
+// way hgs_k_pair_reduce_em loads its rows - coalesced, 128 rows per step, the next step's loads in flight - and the cell
+// steps read it from LDS: the rows of cell c are block positions [cp_c, cp_c + n_c), the lane with the r-th set bit of
+// cell c (ballots over the masks the sort left in the records, hgs_rec_tag) takes cp_c + r.  An entry's rows ascend with
+// the cell, so taking them window by window keeps the cell order: the same sums, bit for bit, as the entry-major form.
+// Chunks of the long-list sort classes keep entry-major rows (tag bit 28 clear: entpair.y = the entry's first row).
+// (Gathering the rows straight from HBM - a 16 B load at 40 B stride with a quarter of the lanes live - issued ten times
+// the cache-line requests of this form: 31 vs 25 us per view; a cell-major layout with a slot table for the reduction,
+// round 4's first answer, cost 64 B of bin buffer per entry of capacity and 25 us more per 8-view call: EXPERIMENTS.md.)
 typedef float hgs_f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));      // 16 B access at 8 B alignment (40 B pair rows)
 extern "C" __global__ void __launch_bounds__(256)
-hgs_k_pair_reduce_cm(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
-                     const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
-  if (status->overflow) return;
-  const uint32_t R = status->num_rendered;
-  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= R) return;
-  const uint2 ep = L.entpair[p];                              // entry id | pairs << 27, first entry-major pair index
-  const uint32_t entry = ep.x & 0x7ffffffu, cnt = ep.x >> 27;
-  const uint32_t* __restrict__ ps = L.ptab + ep.y;
-  float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
-  for (uint32_t r0 = 0; r0 < cnt; r0 += HGS_RED_UNROLL) {
-    // slots first, then all rows of the group in flight (unconditional loads from clamped indices), added in cell order
-    uint32_t sl[HGS_RED_UNROLL];
-#pragma unroll
-    for (int u = 0; u < HGS_RED_UNROLL; ++u) sl[u] = ps[min(r0 + (uint32_t)u, cnt - 1u)];
-    hgs_f32x4_a8 a0[HGS_RED_UNROLL], a1[HGS_RED_UNROLL];
-    float2 a2[HGS_RED_UNROLL];
-#pragma unroll
-    for (int u = 0; u < HGS_RED_UNROLL; ++u) {
-      const float* q = pair_rows + (size_t)sl[u] * HGS_PROW_FLOATS;      // (16 + 16 + 8 B loads at 8 B alignment)
-      a0[u] = *reinterpret_cast<const hgs_f32x4_a8*>(q);
-      a1[u] = *reinterpret_cast<const hgs_f32x4_a8*>(q + 4);
-      a2[u] = *reinterpret_cast<const float2*>(q + 8);
-    }
-#pragma unroll
-    for (int u = 0; u < HGS_RED_UNROLL; ++u) {
-      if (r0 + (uint32_t)u < cnt) {
-        s0.x += a0[u][0]; s0.y += a0[u][1]; s1.x += a0[u][2]; s1.y += a0[u][3]; s2.x += a1[u][0]; s2.y += a1[u][1];
-        s3.x += a1[u][2]; s3.y += a1[u][3]; s4.x += a2[u].x; s4.y += a2[u].y;
-      }
-    }
-  }
-  float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
-  dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
-  dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
-#if HGS_GROW_F4 > 3
-  dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-}
-
-// ------------------------------------------------------------------------------ pair reduction, CHUNK-cell-major rows (HGS_PAIR_CHUNKS builds)
-// The rows of every 64-record chunk of a tile list are ONE block (entpair.y = its first row), cell by cell, inside a cell
-// in list order: a 16-record batch of the backward lies in one or two chunks and writes one or two contiguous runs of
-// rows, and here the lanes of a wave = the records of a chunk read, cell after cell, CONSECUTIVE rows (lane with the
-// r-th set bit of cell c reads row `rows before cell c` + r: ballots over the masks the sort left in the records,
-// hgs_rec_tag) - both kernels stream.  A wave takes the chunks that START in its window of 64 records (chunks start at
-// tile starts, not at multiples of 64).  Chunks of the long-list sort classes keep entry-major rows (tag bit 28 clear:
-// entpair.y = the entry's first row).  Cells in ascending order for every entry: the same sums, bit for bit, as the
-// other two forms.
-struct RedChBuf { hgs_f32x4_a8 a0[4], a1[4]; float2 a2[4]; };
-extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce_ch(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
-                     const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
-  if (status->overflow) return;
-  const uint32_t R = status->num_rendered;
-  const int lane = (int)threadIdx.x & 63;
-  const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;      // the wave's window of records
-  if (w0 >= R) return;                                                   // (wave-uniform)
-  const uint32_t* __restrict__ tags = reinterpret_cast<const uint32_t*>(recs_all) + 11;      // SortRec::pad
-  // ONE round trip for everything the wave's chunks can need: a chunk that starts in the window ends inside the next one
-  const uint32_t pa = w0 + (uint32_t)lane;
-  const uint32_t qa = min(pa, R - 1u), qb = min(pa + 64u, R - 1u);
-  const uint32_t tagA = tags[(size_t)qa * 12u], tagB = tags[(size_t)qb * 12u];
-  const uint2 epA = L.entpair[qa], epB = L.entpair[qb];                  // entry id | pairs << 27, first row of the chunk / of the entry
-  unsigned long long starts = __ballot(pa < R && ((tagA >> 16) & 63u) == 0u);
-  while (starts) {                                                        // (wave-uniform)
-    const int s = (int)__builtin_ctzll(starts);
-    starts &= starts - 1ull;
-    const uint32_t t_s = (uint32_t)__builtin_amdgcn_readlane((int)tagA, s);
-    const uint32_t C = ((t_s >> 22) & 63u) + 1u;                          // records of the chunk
-    const bool chunk_rows = ((t_s >> 28) & 1u) != 0u;
-    const bool have = (uint32_t)lane < C;
-    // lane l takes record s + l of the two windows
-    const int src = (s + lane) & 63;
-    const bool from_b = s + lane >= 64;
-    const uint32_t tA = (uint32_t)__shfl((int)tagA, src, 64), tB = (uint32_t)__shfl((int)tagB, src, 64);
-    const uint32_t xA = (uint32_t)__shfl((int)epA.x, src, 64), xB = (uint32_t)__shfl((int)epB.x, src, 64);
-    const uint32_t yA = (uint32_t)__shfl((int)epA.y, src, 64), yB = (uint32_t)__shfl((int)epB.y, src, 64);
-    const uint32_t tag = from_b ? tB : tA, epx = from_b ? xB : xA, epy = from_b ? yB : yA;
-    const uint32_t mask = have ? (tag & 0xffffu) : 0u;
-    const uint32_t entry = epx & 0x7ffffffu, cnt = have ? (epx >> 27) : 0u;
-    // the rows of the 16 steps (chunk rows: step = cell; entry-major rows: step = the entry's step-th pair)
-    uint32_t row[16], onbits = 0;
-    {
-      uint32_t cp = 0;                                                    // rows of the chunk in the cells before the step's
-#pragma unroll
-      for (int step = 0; step < 16; ++step) {
-        bool on;
-        uint32_t r;
-        if (chunk_rows) {
-          on = ((mask >> step) & 1u) != 0u;
-          const unsigned long long bal = __ballot(on);
-          r = epy + cp + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          cp += (uint32_t)__popcll(bal);
-        } else {
-          on = (uint32_t)step < cnt;
-          r = epy + (uint32_t)step;
-        }
-        row[step] = on ? r : 0u;                                          // (a valid row: unconditional loads)
-        onbits |= on ? 1u << step : 0u;
-      }
-    }
-    float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
-    // four batches of four steps, two in flight
-    RedChBuf X, Y;
-#define HGS_REDCH_LOAD(B, U0)                                                                        \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                    \
-    const float* qq = pair_rows + (size_t)row[(U0) + u] * HGS_PROW_FLOATS;      /* 16 + 16 + 8 B at 8 B alignment */ \
-    B.a0[u] = *reinterpret_cast<const hgs_f32x4_a8*>(qq);                                            \
-    B.a1[u] = *reinterpret_cast<const hgs_f32x4_a8*>(qq + 4);                                        \
-    B.a2[u] = *reinterpret_cast<const float2*>(qq + 8);                                              \
-  }
-#define HGS_REDCH_SUM(B, U0)                                                                         \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                    \
-    if ((onbits >> ((U0) + u)) & 1u) {                                                               \
-      s0.x += B.a0[u][0]; s0.y += B.a0[u][1]; s1.x += B.a0[u][2]; s1.y += B.a0[u][3];                \
-      s2.x += B.a1[u][0]; s2.y += B.a1[u][1]; s3.x += B.a1[u][2]; s3.y += B.a1[u][3];                \
-      s4.x += B.a2[u].x; s4.y += B.a2[u].y;                                                          \
-    }                                                                                                \
-  }
-    HGS_REDCH_LOAD(X, 0)
-    HGS_REDCH_LOAD(Y, 4)
-    HGS_REDCH_SUM(X, 0)
-    HGS_REDCH_LOAD(X, 8)
-    HGS_REDCH_SUM(Y, 4)
-    HGS_REDCH_LOAD(Y, 12)
-    HGS_REDCH_SUM(X, 8)
-    HGS_REDCH_SUM(Y, 12)
-#undef HGS_REDCH_LOAD
-#undef HGS_REDCH_SUM
-    if (have) {
-      float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
-      dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
-      dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
-#if HGS_GROW_F4 > 3
-      dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-    }
-  }
-}
-
-// ---- the same with the chunk's block of rows staged in LDS (HGS_PAIR_CHUNKS == 2: parity + batch suites green, 25 us per view).
-// hgs_k_pair_reduce_ch gathers 40 B rows at 40 B stride with a quarter of the lanes live - ten times the cache-line
-// requests of the entry-major stream (31 vs 18 us per view).  Here the block [first row of the chunk, + its pairs) is
-// loaded the way hgs_k_pair_reduce_em loads its rows - coalesced, 128 rows per step, the next step's loads in flight -
-// and the cell steps read it from LDS: the rows of cell c are block positions [cp_c, cp_c + n_c), lane with the r-th set
-// bit takes cp_c + r.  An entry's rows ascend with the cell, so taking them window by window keeps the cell order.
-extern "C" __global__ void __launch_bounds__(256)
-hgs_k_pair_reduce_chl(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
-                      const float* __restrict__ pair_rows, float* __restrict__ grad_rows) {
+                      const float* __restrict__ pair_rows, float* __restrict__ grad_rows, uint32_t pair_cap) {
   __shared__ float2 s_rows[4][HGS_RED_ROWS * HGS_PROW_F2];
   if (status->overflow) return;
   const uint32_t R = status->num_rendered;
@@ -666,8 +531,10 @@ hgs_k_pair_reduce_chl(View v, Layout L, const hgs_status* __restrict__ status, c
     const uint32_t xA = (uint32_t)__shfl((int)epA.x, src, 64), xB = (uint32_t)__shfl((int)epB.x, src, 64);
     const uint32_t yA = (uint32_t)__shfl((int)epA.y, src, 64), yB = (uint32_t)__shfl((int)epB.y, src, 64);
     const uint32_t tag = from_b ? tB : tA, epx = from_b ? xB : xA, epy = from_b ? yB : yA;
-    const uint32_t mask = have ? (tag & 0xffffu) : 0u;
-    const uint32_t entry = epx & 0x7ffffffu, cnt = have ? (epx >> 27) : 0u;
+    // (more pairs than the scratch was sized for - hgs_k_render_bwd wrote none: no row is read, the gradient rows are NaN)
+    const bool poisoned = (uint32_t)L.ctr->alloc_ps > pair_cap;
+    const uint32_t mask = (have && !poisoned) ? (tag & 0xffffu) : 0u;
+    const uint32_t entry = epx & 0x7ffffffu, cnt = (have && !poisoned) ? (epx >> 27) : 0u;
     float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
     if (chunk_rows) {
       // block positions of this lane's rows, per cell; cells' first positions and sizes (wave-uniform)
@@ -747,6 +614,7 @@ hgs_k_pair_reduce_chl(View v, Layout L, const hgs_status* __restrict__ status, c
       }
     }
     if (have) {
+      if (poisoned) s0.x = s0.y = s1.x = s1.y = s2.x = s2.y = s3.x = s3.y = s4.x = s4.y = __builtin_nanf("");
       float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
       dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
       dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);

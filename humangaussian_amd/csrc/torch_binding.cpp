@@ -426,6 +426,9 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     Tensor scratch = at::empty({al256(hgs_bwd_scratch_bytes_pairs((int64_t)plan->status.num_rendered, pairs))},
                                at::TensorOptions().dtype(at::kByte).device(dev));
     plan->rows = static_cast<char*>(scratch.data_ptr());
+    // tell the library what the scratch holds: its kernels check the count against the one the sort left on the device and
+    // write nothing (NaN gradients) if the slot delivered a stale number (hgs_rast.h: hgs_backward)
+    plan->status.num_pairs = (uint32_t)pairs;
     const auto tb1 = std::chrono::steady_clock::now();
     const int rc = hgs_backward_batch_act(
         plan->settings.s.data(), plan->B, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_), fptr(ro_),

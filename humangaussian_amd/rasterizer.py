@@ -87,6 +87,9 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 
 ACT_OPACITY_SIGMOID, ACT_SCALE_EXP, ACT_ROTATION_NORMALIZE = 1, 2, 4      # HGS_ACT_* of include/hgs_rast.h
+# backward only: dL/dscales as the TRUE derivative at scale_modifier != 1 (the default follows the fork, whose backward
+# drops the modifier's factor; identical at 1.0, the only value the reference passes) - HGS_GRAD_SCALE_TRUE_DERIVATIVE
+GRAD_SCALE_TRUE_DERIVATIVE = 8
 
 
 def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -99,7 +102,7 @@ def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, s
                           sh_degree and scale_modifier (cameras, fov and bg may differ)
     means2D               (B, P, 3) zeros whose .grad receives the per-view screen-space gradient
                           (may be None under no_grad)
-    activation_flags      ACT_* bits: `opacities` / `scales` / `rotations` are the model's RAW parameters
+    activation_flags      GRAD_SCALE_TRUE_DERIVATIVE and / or ACT_* bits: `opacities` / `scales` / `rotations` are the model's RAW parameters
                           (`_opacity` logits, `_scaling` log-scales, un-normalised `_rotation`) and
                           sigmoid / exp / normalize (scene/gaussian_model.py:95-115) run inside the
                           per-Gaussian kernels, forward and backward; gradients are w.r.t. the raw tensors

@@ -54,10 +54,13 @@ def _tan_half(fov):
 
 
 # The reference creates `screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0` per view
-# (gaussian_renderer/__init__.py:26): a fill AND an add kernel on the stream in front of every forward, for a tensor whose
-# VALUES nothing reads - the rasterizer only routes dL/dmeans2D into its `.grad` (GaussianDreamer.py:385-387).  Here it is
-# an uninitialised leaf: no kernel at all.  Set ZERO_SCREENSPACE_POINTS = True for callers that read the values.
-ZERO_SCREENSPACE_POINTS = False
+# (gaussian_renderer/__init__.py:26): a fill AND an add kernel in front of every forward.  The rasterizer only routes
+# dL/dmeans2D into the tensor's `.grad` (GaussianDreamer.py:385-387), but the reference's own 3DGS trainer reads the VALUES
+# too (`gaussiansplatting/train.py:113` -> `gaussian_model.py:436`), so a drop-in hands out ZEROS like the reference: one
+# zero-filled leaf (the `+ 0` kernel is gone, the values are the same).  ZERO_SCREENSPACE_POINTS = False is the opt-in fast
+# path for loops that never read the values (an uninitialised leaf: no kernel at all) - bench.py's step does the same with
+# its own tensor and says so in its workload string.
+ZERO_SCREENSPACE_POINTS = True
 
 
 def _screenspace_points(xyz, views=None):

@@ -64,7 +64,10 @@ typedef struct hgs_status {
                            /* only when the sort has run: 0 in what the status mirror / event delivers, set */
                            /* in the device copy and in a MAPPED host mirror when the blend forward starts  */
                            /* (a host that finds it non-zero later may size the scratch by it, see          */
-                           /* hgs_bwd_scratch_bytes_pairs; 0 = not known (yet): size for the worst case)    */
+                           /* hgs_bwd_scratch_bytes_pairs; 0 = not known (yet): size for the worst case).   */
+                           /* LIFETIME: a mapped mirror is therefore written a SECOND time, after the ready */
+                           /* word reserved[2]: it must stay valid (not freed, not reused for another call) */
+                           /* until the forward's stream work has completed, not merely until the poll ends */
   uint32_t bwd_groups;     /* unused since ABI v11 (0): the blend kernels run persistent waves */
   uint32_t overflow;       /* != 0: outputs are INVALID.  bit0: R exceeded              */
                            /* entry_capacity (retry with >= num_rendered); bit1: a tile */
@@ -172,10 +175,17 @@ int hgs_backward_batch(const hgs_settings* views, int32_t B, int32_t P, int32_t 
  * caller hands over the RAW parameters and the activation runs inside the per-Gaussian kernels
  * (forward: as the value is loaded; backward: chain rule applied to the summed gradient, so
  * dL_dopacities / dL_dscales / dL_drotations are gradients w.r.t. the raw parameters).
- * activation_flags: any combination of the bits below; 0 = identical to the plain entry points. */
+ * activation_flags: any combination of the HGS_ACT_* bits below (+ HGS_GRAD_SCALE_TRUE_DERIVATIVE for the backward);
+ * 0 = identical to the plain entry points. */
 #define HGS_ACT_OPACITY_SIGMOID 1    /* opacities are logits                                  */
 #define HGS_ACT_SCALE_EXP 2          /* scales are log-scales                                 */
 #define HGS_ACT_ROTATION_NORMALIZE 4 /* rotations are un-normalised quaternions (w,x,y,z)      */
+/* Backward only (ignored by the forward).  dL_dscales at scale_modifier != 1: the fork's backward (computeCov3D:
+ * `s = mod * scale`, `dL_dscale = dot(Rt[i], dL_dMt[i])`) returns dL/d(mod * scale) - the modifier's factor is missing -
+ * and that is what this library returns by default, like the extension it replaces (identical at 1.0, the only value
+ * the reference passes: gaussian_renderer/__init__.py:18, gs_renderer.py:925).  With this bit set dL_dscales is the
+ * true derivative dL/dscale = mod * dL/d(mod * scale). */
+#define HGS_GRAD_SCALE_TRUE_DERIVATIVE 8
 int hgs_forward_batch_act(const hgs_settings* views, int32_t B, int32_t P, int32_t M,
                           const float* means3D, const float* shs, const float* colors_precomp,
                           const float* opacities, const float* scales, const float* rotations,
@@ -206,7 +216,12 @@ int hgs_backward_batch_act(const hgs_settings* views, int32_t B, int32_t P, int3
  * (entry_capacity/64 + tiles) and every kernel reads the device-side status (an
  * overflowed forward yields all-zero gradients).  `entry_capacity` must equal the value
  * given to hgs_forward (it fixes the carve of `bin`), bwd_scratch must hold
- * hgs_bwd_scratch_bytes(num_rendered) - or (entry_capacity) when status is NULL.
+ * hgs_bwd_scratch_bytes(num_rendered) - or (entry_capacity) when status is NULL - or, when
+ * status->num_pairs is non-zero, hgs_bwd_scratch_bytes_pairs(num_rendered, status->num_pairs):
+ * status->num_pairs DECLARES how many pair rows the scratch holds (0 = the worst case of 16 per
+ * entry).  The kernels compare it with the count the forward left on the device; if the device
+ * holds more pairs than declared (a stale or foreign status) no pair row is written and every
+ * gradient of the call is NaN - loud, and in bounds (ABI v14; up to v13 this overran the scratch).
  * out_* are the forward's outputs (unmodified), dL_dout_* the incoming
  * gradients (any of them may be NULL = zeros).  Every dL_d* output that is non-NULL is
  * fully overwritten (no pre-zeroing needed, no atomics: results are deterministic);

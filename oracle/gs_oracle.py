@@ -68,9 +68,20 @@ class OracleSettings(NamedTuple):
 
 # --------------------------------------------------------------------------- preprocess
 
+# The fork's computeCov3D backward forms `s = mod * scale` and returns dL/ds as `dL_dscale` - the factor `mod` of the
+# chain rule is missing [UPSTREAM-KNOWLEDGE: cuda_rasterizer/backward.cu, computeCov3D: `dL_dscale->x = dot(Rt[0],
+# dL_dMt[0])`].  True (the default) mimics that: value mod * scale, derivative 1 w.r.t. scale.  False = the true
+# derivative (the HIP library's HGS_GRAD_SCALE_TRUE_DERIVATIVE).  Identical at scale_modifier == 1, the only value the
+# reference passes (gaussian_renderer/__init__.py:18, gs_renderer.py:925).
+FORK_SCALE_GRADIENT = True
+
+
 def _cov3d_from_scale_rot(scales, rots, mod):
     """Sigma = R S^2 R^T, S = diag(mod*scale); quaternion (w,x,y,z) used AS GIVEN
     (no renormalisation: SURVEY A.6 'rotation').  Returns 6 columns xx,xy,xz,yy,yz,zz."""
+    if FORK_SCALE_GRADIENT and mod != 1.0 and scales.requires_grad:
+        scales = scales + (mod * scales - scales).detach()        # value mod * scale, d/dscale = 1
+        mod = 1.0
     sx, sy, sz = mod * scales[:, 0], mod * scales[:, 1], mod * scales[:, 2]
     r, x, y, z = rots[:, 0], rots[:, 1], rots[:, 2], rots[:, 3]
     R00 = 1.0 - 2.0 * (y * y + z * z)

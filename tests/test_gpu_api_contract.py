@@ -86,6 +86,8 @@ def test_render_dict_contract_and_oracle_values():
     assert out["alpha_3dgs"].shape == (1, 64, 80) and out["radii"].dtype == torch.int32
     assert out["visibility_filter"].dtype == torch.bool and torch.equal(out["visibility_filter"], out["radii"] > 0)
     assert out["viewspace_points"].shape == pc.get_xyz.shape and out["viewspace_points"].requires_grad
+    # zeros, like gaussian_renderer/__init__.py:26 (gaussiansplatting/train.py:113 -> gaussian_model.py:436 reads the VALUES)
+    assert out["viewspace_points"].is_leaf and float(out["viewspace_points"].detach().abs().max()) == 0.0
     # values: the activated parameters through the oracle
     st = oracle_settings(sc)
     oc, orad, od, oa = oracle.rasterize(pc.get_xyz.detach().cpu(), None, pc.get_features.detach().cpu(), None,

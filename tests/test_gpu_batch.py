@@ -495,3 +495,47 @@ def test_render_views_with_host_side_cameras():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for x, y in zip(outs[0][2], outs[1][2]):
         assert torch.equal(x, y)
+
+
+def test_scale_gradient_follows_the_fork_by_default_and_the_true_derivative_on_request(monkeypatch):
+    """scale_modifier != 1: the fork's dL/dscales lacks the modifier's factor (include/hgs_rast.h:
+    HGS_GRAD_SCALE_TRUE_DERIVATIVE, oracle FORK_SCALE_GRADIENT) - the default here, through the reference API; the true
+    derivative is a RUN-TIME request (activation_flags of the batched call), never a build flag."""
+    import math
+    import oracle
+    from oracle import gs_oracle
+    from humangaussian_amd.rasterizer import GRAD_SCALE_TRUE_DERIVATIVE
+    P, H, W, mod = 400, 64, 80, 1.3
+    sc = make_scene(P=P, sh_degree=0, seed=71, H=H, W=W, spread=0.3)
+    cam = sc["cam"]
+    rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), sc["bg"].to(DEV), mod,
+                                       cam.world_view_transform.to(DEV), cam.full_proj_transform.to(DEV), 0,
+                                       cam.camera_center.to(DEV), False, False)
+    g = torch.Generator().manual_seed(3)
+    w = [torch.randn(s, generator=g) for s in ((3, H, W), (1, H, W), (1, H, W))]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def hip(flags):
+        ins = {k: sc[k].to(DEV).requires_grad_(True) for k in names}
+        if flags is None:        # the reference's API: one view, no flags
+            c, r, d, a = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=torch.zeros_like(ins["means3D"], requires_grad=True),
+                                                shs=ins["shs"], opacities=ins["opacities"], scales=ins["scales"], rotations=ins["rotations"])
+        else:
+            c, r, d, a = rasterize_gaussians_batch(ins["means3D"], torch.zeros((1, P, 3), device=DEV, requires_grad=True), ins["shs"], None,
+                                                   ins["opacities"], ins["scales"], ins["rotations"], None, [rs], activation_flags=flags)
+        ((c * w[0].to(DEV)).sum() + (d * w[1].to(DEV)).sum() + (a * w[2].to(DEV)).sum()).backward()
+        return {k: ins[k].grad.cpu() for k in names}
+
+    def ref(fork):
+        monkeypatch.setattr(gs_oracle, "FORK_SCALE_GRADIENT", fork)
+        ins = {k: sc[k].double().clone().requires_grad_(True) for k in names}
+        c, r, d, a = oracle.rasterize(ins["means3D"], None, ins["shs"], None, ins["opacities"], ins["scales"], ins["rotations"], None,
+                                      oracle_settings(sc, mod), dtype=torch.float64)
+        gl = torch.autograd.grad((c * w[0]).sum() + (d * w[1]).sum() + (a * w[2]).sum(), list(ins.values()))
+        return dict(zip(names, gl))
+    for got, want in ((hip(None), ref(True)), (hip(0), ref(True)), (hip(GRAD_SCALE_TRUE_DERIVATIVE), ref(False))):
+        for k in names:
+            scale = max(float(want[k].abs().max()), 1e-12)
+            assert float((got[k].double() - want[k]).abs().max()) <= 1e-3 * scale, k
+    f, t = hip(0)["scales"], hip(GRAD_SCALE_TRUE_DERIVATIVE)["scales"]
+    assert float(t.abs().max()) > 0 and torch.allclose(f * mod, t, rtol=1e-6, atol=0)

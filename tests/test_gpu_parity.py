@@ -433,3 +433,26 @@ def test_pair_count_is_published_and_sizes_the_backward_scratch():
     for k, a in g_worst.items():
         if a is not None:
             assert torch.equal(a.view(torch.int32), g_pairs[k].view(torch.int32)), k
+
+
+def test_understated_pair_count_poisons_the_gradients_and_stays_in_bounds():
+    """ABI v14: status->num_pairs DECLARES the pair rows the scratch holds.  A count below what the forward left on the
+    device (a stale status slot, a status of another call) must not overrun the scratch: the blend backward writes no
+    pair row, the reduction poisons the gradient rows, every gradient that depends on a tile entry is NaN - loud, in bounds."""
+    sc = make_scene(P=3000, sh_degree=0, seed=12, H=128, W=160, spread=0.5)
+    rc = RawCall(sc, capacity=1 << 16, mapped=1)
+    assert rc.forward() == 0 and not rc.status[4]
+    R, pairs = rc.status[0], rc.status[2]
+    assert R > 0 and pairs > R
+    gc, gd, ga = rand_grads(128, 160, seed=6)
+    good = rc.backward(gc, gd, ga, pairs_scratch=True)
+    assert all(torch.isfinite(v).all() for v in good.values() if v is not None)
+    rc.status[2] = pairs // 2                       # understate: the scratch (and its guard region) is sized by it
+    bad = rc.backward(gc, gd, ga, pairs_scratch=True)
+    vis = rc.radii.cpu() > 0
+    assert vis.any() and torch.isnan(bad["means3D"][vis]).any() and torch.isnan(bad["opacities"][vis]).any()
+    rc.status[2] = pairs                            # the true count again: same bits as before
+    again = rc.backward(gc, gd, ga, pairs_scratch=True)
+    for k, a in good.items():
+        if a is not None:
+            assert torch.equal(a.view(torch.int32), again[k].view(torch.int32)), k

@@ -247,3 +247,29 @@ def test_streamed_forward_backward_equals_autograd_of_rasterize():
     assert float((out["grads"]["means2D"] - m2.grad).abs().max()) <= 1e-10 * float(m2.grad.abs().max())
     # the fragile mask flags only a small minority of pixels on a generic scene
     assert out["fragile"].dtype == torch.bool and float(out["fragile"].float().mean()) < 0.02
+
+
+def test_fork_scale_gradient_switch_drops_exactly_the_modifier_factor(monkeypatch):
+    """scale_modifier != 1: the fork's dL/dscale is dL/d(mod * scale) - the modifier's factor is missing (SURVEY A.6 list,
+    oracle/gs_oracle.py::FORK_SCALE_GRADIENT) - every other gradient and every output is the same either way."""
+    sc = make_scene(P=60, sh_degree=1, seed=5)
+    st = oracle_settings(sc, 1.3)
+    g = torch.Generator().manual_seed(2)
+    w = [torch.randn(s, generator=g, dtype=torch.float64) for s in ((3, 48, 64), (1, 48, 64), (1, 48, 64))]
+
+    def run(fork):
+        monkeypatch.setattr(gs_oracle, "FORK_SCALE_GRADIENT", fork)
+        ins = {k: sc[k].double().clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        c, r, d, a = oracle.rasterize(ins["means3D"], None, ins["shs"], None, ins["opacities"], ins["scales"],
+                                      ins["rotations"], None, st, dtype=torch.float64)
+        gl = torch.autograd.grad((c * w[0]).sum() + (d * w[1]).sum() + (a * w[2]).sum(), list(ins.values()))
+        return (c.detach(), d.detach(), a.detach()), dict(zip(ins, gl))
+    out_f, g_f = run(True)
+    out_t, g_t = run(False)
+    for x, y in zip(out_f, out_t):
+        assert torch.equal(x, y)
+    for k in g_f:
+        if k != "scales":
+            assert torch.allclose(g_f[k], g_t[k], rtol=1e-12, atol=0)
+    assert float(g_t["scales"].abs().max()) > 0
+    assert torch.allclose(g_f["scales"] * float(np.float32(1.3)), g_t["scales"], rtol=1e-12, atol=1e-300)   # (the modifier is an fp32 scalar)

@@ -1,4 +1,4 @@
-"""CPU restatement of the chunk-cell-major pair-row ids (HGS_PAIR_CHUNKS builds): the sort kernel's
+"""CPU restatement of the chunk-cell-major pair-row ids (calls of >= 3 views, View::pairchunks): the sort kernel's
 formula (binning.hip::cell_lists_from_masks - prefix over the 64-record chunks of a tile list, prefix over the cells of
 a chunk, rank inside the cell) and the pair reduction's (render_bwd.hip::hgs_k_pair_reduce_ch - ballots over the masks of
 a chunk's records, cell after cell) must name the same row for every (entry, cell) pair, the rows must tile [0, pairs)
