@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--points", type=int, default=P_POINTS)
     ap.add_argument("--sh-degree", type=int, default=SH_DEGREE)
     ap.add_argument("--variant", default="mid", choices=["mid", "init"])
+    ap.add_argument("--cloud", default="human_obj", choices=["human_obj", "capsule"],
+                    help="where the points come from: area-uniform samples of the reference's load/shapes/human.obj (SURVEY.md 8(d); "
+                         "committed mesh fixture) or the analytic capsule humanoid of rounds 1-4")
     ap.add_argument("--views", type=int, default=1,
                     help="views per rank per step rendered by ONE batched call (extra measurement when > 1)")
     ap.add_argument("--views-per-rank", type=int, default=1,
@@ -154,7 +157,7 @@ def main():
         def __init__(self, P, sh_degree, variant, views, forward_only, first_view, seq_views=1, collectives=True):
             self.P, self.sh_degree, self.views, self.forward_only = P, sh_degree, views, forward_only
             self.seq_views, self.collectives = seq_views, collectives
-            cloud = synth.init_cloud(P, sh_degree, variant, seed=0)
+            cloud = synth.init_cloud(P, sh_degree, variant, seed=0, source=args.cloud)
             self.cloud = cloud
             self.M = cloud.shs.shape[1]
             # sequential mode: round j of the step = global views j * world + rank (view_parallel's round-robin)
@@ -394,7 +397,8 @@ def main():
             su = wl.stage_times(10)
             extra[name] = {"value": units * steps / t, "unit": "Gaussians/s", "ms_per_step": t / steps * 1e3,
                            "ms_per_step_runs": [x / steps * 1e3 for x in ts],
-                           "steps": steps, "warmup": warmup, "init_steps": INIT_STEPS, "workload": note,
+                           "steps": steps, "warmup": warmup, "init_steps": INIT_STEPS,
+                           "workload": note + f" [the FASTER of two timed runs of {steps} steps; both in ms_per_step_runs]",
                            "num_rendered_R": int(_rast._state(dev).max_R), "stage_us": su}
         k8 = max(20, args.steps // 6)
         measure("batched_8_views", Workload(P, sh_degree, "mid", 8, False, 0), k8, max(5, args.warmup // 5), 8 * P,
@@ -449,13 +453,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": args.init_steps,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {P} SMPL-X-like Gaussians ({args.variant}-training state, SH degree "
-                                   f"{sh_degree}; a capsule humanoid with SMPL-X extents, NOT load/shapes/human.obj - "
-                                   f"R lies inside SURVEY App. B's range), {args.views * VPR} 1024x1024 orbit view(s) per GPU per step"
+            "config": {"workload": f"configs[1]: {P} Gaussians on " + ("the reference's load/shapes/human.obj (area-uniform, seed 0, normalised "
+                                   "as threestudio/utils/poser.py:337-357: SURVEY.md 8(d)'s cloud)" if args.cloud == "human_obj" else
+                                   "a capsule humanoid with SMPL-X extents (the stand-in of rounds 1-4)")
+                                   + f", {args.variant}-training state, SH degree {sh_degree}; {args.views * VPR} 1024x1024 orbit view(s) per GPU per step"
                                    + (" in ONE batched call" if args.views > 1 else "")
                                    + (" one after the other (the reference's loop)" if VPR > 1 else "")
                                    + " (elev 10, azim 30+45*view, dist 1.75, fovy 55), "
-                                   + ("fwd only" if args.forward_only else "fwd+bwd"),
+                                   + ("fwd only" if args.forward_only else "fwd+bwd")
+                                   + "; the step's means2D leaf is uninitialised (its values are never read; the drop-in render() hands out zeros)",
+                       "cloud": args.cloud,
                        "views_per_step": world * args.views * VPR, "views_per_rank_sequential": VPR, "num_rendered_R": int(R),
                        "host_mode": "sync (one host wait per forward for the device-side status, as upstream)",
                        "parallelism": f"view-parallel x{world}" + (f", collective {collective_mode[0]}" if world > 1 else "")},

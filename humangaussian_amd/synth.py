@@ -1,9 +1,10 @@
 """Synthetic inputs for benchmarks and tests (no datasets, no SMPL-X files on the box).
 
-* `humanoid_points`  - area-uniform samples on a capsule humanoid with the extents of the
-  SMPL-X body HumanGaussian initialises from (after `threestudio/utils/poser.py:337-352`:
-  about 1.20 x 0.30 x 1.56, z-up, surface area ~1.5), standing in for `pcb()`
-  (`threestudio/systems/GaussianDreamer.py:220-232`).
+* `human_points`     - area-uniform samples on the reference's `load/shapes/human.obj`, normalised as
+  `threestudio/utils/poser.py:337-357` (1.20 x 0.30 x 1.56, z-up, area 1.51): the cloud SURVEY.md 8(d)
+  prescribes, standing in for `pcb()` (`threestudio/systems/GaussianDreamer.py:220-232`); the mesh is a
+  committed fixture (tests/golden/human_mesh.npz).
+* `humanoid_points`  - the same extents as an analytic capsule humanoid (rounds 1-4; source="capsule").
 * `init_cloud`       - Gaussian parameters as `GaussianModel.create_from_pcd` makes them
   (`gaussiansplatting/scene/gaussian_model.py:124-147`: isotropic scale from the mean 3-NN
   distance, opacity 0.1, identity rotation, colour 0.5), or a randomised "mid-training"
@@ -16,6 +17,7 @@ All numpy / CPU torch; callers move tensors to the device.
 from __future__ import annotations
 
 import math
+import os
 from typing import NamedTuple
 
 import numpy as np
@@ -76,6 +78,33 @@ def humanoid_points(n: int, seed: int = 0) -> np.ndarray:
     return pts.astype(np.float32)
 
 
+_HUMAN_MESH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "human_mesh.npz")
+
+
+def human_points(n: int, seed: int = 0) -> np.ndarray:
+    """(n,3) float32 points sampled AREA-UNIFORMLY on the reference's `load/shapes/human.obj`, normalised as the reference
+    normalises its body mesh (threestudio/utils/poser.py:337-357 with `scale(-10)`: extent 1.20 x 0.30 x 1.56, z-up,
+    area 1.51) - the cloud SURVEY.md 8(d) prescribes for every benchmark configuration, standing in for
+    `skel.sample_smplx_points` (GaussianDreamer.py:220-232).  The mesh is the committed fixture
+    tests/golden/human_mesh.npz (tests/golden/make_human_mesh.py); seeded `numpy.random.default_rng(seed)`."""
+    if not os.path.exists(_HUMAN_MESH):
+        raise FileNotFoundError(f"{_HUMAN_MESH} is missing (generate it with tests/golden/make_human_mesh.py where "
+                                f"/root/reference exists), or ask for source='capsule'")
+    m = np.load(_HUMAN_MESH)
+    v, f = m["vertices"].astype(np.float64), m["faces"]
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    rng = np.random.default_rng(seed)
+    tri = np.searchsorted(np.cumsum(area) / area.sum(), rng.uniform(0, 1, n), side="right").clip(0, len(f) - 1)
+    r1, r2 = np.sqrt(rng.uniform(0, 1, n)), rng.uniform(0, 1, n)
+    w0, w1, w2 = 1.0 - r1, r1 * (1.0 - r2), r1 * r2                   # uniform on the triangle
+    pts = w0[:, None] * a[tri] + w1[:, None] * b[tri] + w2[:, None] * c[tri]
+    return pts.astype(np.float32)                                     # (drawn independently: no spatial order in index space)
+
+
+CLOUD_SOURCES = ("human_obj", "capsule")
+
+
 def mean_knn_dist2(points: np.ndarray, k: int = 3) -> np.ndarray:
     """Mean squared distance to the k nearest neighbours (what simple_knn.distCUDA2
     returns, `submodules/simple-knn/simple_knn.cu:147-183`)."""
@@ -93,9 +122,16 @@ class Cloud(NamedTuple):
     sh_degree: int
 
 
-def init_cloud(n: int, sh_degree: int = 0, variant: str = "mid", seed: int = 0) -> Cloud:
+def init_cloud(n: int, sh_degree: int = 0, variant: str = "mid", seed: int = 0, source: str = "human_obj") -> Cloud:
+    """source "human_obj" (the default: SURVEY.md 8(d)'s cloud, `human_points`) or "capsule" (`humanoid_points`: the
+    analytic stand-in of rounds 1-4, kept as a named variant and for boxes without the fixture)."""
     rng = np.random.default_rng(seed + 1)
-    pts = humanoid_points(n, seed)
+    if source == "human_obj":
+        pts = human_points(n, seed)
+    elif source == "capsule":
+        pts = humanoid_points(n, seed)
+    else:
+        raise ValueError(source)
     M = (sh_degree + 1) ** 2
     d2 = np.maximum(mean_knn_dist2(pts), 1e-7)
     log_scale = np.log(np.sqrt(d2))[:, None].repeat(3, 1)

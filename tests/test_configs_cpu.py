@@ -120,3 +120,35 @@ def test_cameras_from_c2w_match_the_per_camera_arithmetic_and_append_rows():
     a, b, c_ = densify.append_rows([xyz, m1, acc], [new, None, None])
     assert torch.equal(a, torch.cat((xyz, new))) and torch.equal(b, torch.cat((m1, torch.zeros(2, 3))))
     assert torch.equal(c_, torch.cat((acc, torch.zeros(2, 1))))
+
+
+def test_human_obj_cloud_is_the_surveys_normalised_mesh_sampled_area_uniformly():
+    """benchmark clouds are area-uniform samples of the reference's load/shapes/human.obj, normalised as
+    threestudio/utils/poser.py:337-357 (+ scale(-10)): extent (1.20, 0.30, 1.56), z-up, centred, area 1.51 (App. B).  The
+    mesh travels as tests/golden/human_mesh.npz (make_human_mesh.py); the sampler is seeded and area-proportional."""
+    import os
+    m = np.load(os.path.join(os.path.dirname(__file__), "golden", "human_mesh.npz"))
+    v, f = m["vertices"].astype(np.float64), m["faces"]
+    assert v.shape == (1629, 3) and f.shape[1] == 3 and f.min() == 0 and f.max() == 1628
+    ext = v.max(0) - v.min(0)
+    assert np.allclose(ext, [1.205, 0.301, 1.556], atol=2e-3) and np.allclose((v.max(0) + v.min(0)) / 2, 0, atol=1e-6)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    assert abs(area.sum() - 1.508) < 2e-3
+    pts = synth.human_points(200_000, seed=0)
+    assert pts.dtype == np.float32 and np.array_equal(pts, synth.human_points(200_000, seed=0))
+    assert not np.array_equal(pts[:1000], synth.human_points(1000, seed=1))
+    assert np.all(pts.min(0) >= v.min(0) - 1e-6) and np.all(pts.max(0) <= v.max(0) + 1e-6)
+    # area-uniform: the share of points above / below the mesh's area median height matches the area share
+    zc = (a[:, 2] + b[:, 2] + c[:, 2]) / 3
+    for z0 in (-0.4, 0.0, 0.4):
+        tri_share = area[zc > z0].sum() / area.sum()
+        assert abs((pts[:, 2] > z0).mean() - tri_share) < 0.01
+    # every point lies on the surface: distance to its nearest triangle plane ~ 0 (checked on a subsample against ALL triangles)
+    sub = pts[:200].astype(np.float64)
+    n = np.cross(b - a, c - a); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    d = np.abs(((sub[:, None, :] - a[None]) * n[None]).sum(-1))
+    assert d.min(1).max() < 1e-6
+    cl = synth.init_cloud(1000, 0, "mid", seed=0)
+    assert np.array_equal(cl.means3D.numpy(), synth.human_points(1000, 0))
+    assert not np.array_equal(synth.init_cloud(1000, 0, "mid", seed=0, source="capsule").means3D.numpy(), cl.means3D.numpy())
