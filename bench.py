@@ -16,6 +16,9 @@ value = P * V * N * K / t, t = max over ranks of the barrier-bracketed wall time
 HGS_DIST_BACKEND=gloo + HGS_BENCH_SHARE_DEVICE=1 run the N > 1 branch with all ranks on ONE device (gloo stages the
 packs through the host): the configuration of tests/test_gpu_multirank_one_gpu.py, not a measurement.
 
+`--forward-only` is the animation leg (configs[4]): a step = one FRAME per rank (re-anchor on the posed mesh + no-grad render,
+frame k on rank k mod N; N > 1: one image all-gather per step, in flight under the next frame's render); value = P * frames / t.
+
 Extra objects on the JSON line:
   roofline      dominant kernel, timed live with HIP events recorded by the library on its launch stream
   cpu_baseline  the PyTorch CPU oracle, full fwd+bwd of the same view on the host cores (rank 0, N=1)
@@ -107,7 +110,8 @@ def main():
                     help="N > 1: how the per-rank gradient packs are reduced (view_parallel.allgather_reduce); auto times "
                          "both outside the timed region and uses the faster one")
     ap.add_argument("--forward-only", action="store_true",
-                    help="extra measurement (animation path, configs[4]): no-grad forward only")
+                    help="the animation leg (configs[4]): a step = one frame per rank - re-anchor on the posed mesh + no-grad render - "
+                         "frames sharded over the ranks, + one image all-gather per step for N > 1; reports frames/s")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -272,7 +276,93 @@ def main():
             _rast.set_stage_events(None, None)
             return {k: v / nprof * 1e3 for k, v in acc.items()}
 
+    class AnimationWorkload:
+        """configs[4] (animation.py:384-403,477-484,966-1004): per frame re-anchor the Gaussians on the posed body mesh
+        (hgs_reanchor; the 136 AMASS poses of content/amass_test_17.npz drive a toy articulation of the human.obj mesh,
+        vertices precomputed), render forward-only through `Renderer.render` (incl. its clamp), frame k on rank k mod N;
+        with `gather` one asynchronous image all-gather per round of N frames, in flight under the next round's render."""
+
+        def __init__(self, P, gather):
+            import numpy as np
+            from humangaussian_amd import animation as an
+            from humangaussian_amd.renderer import cameras_from_c2w
+            self.P, self.gather, self.an = P, gather, an
+            verts, anchors = an.human_mesh_anchors(P, seed=0, device=dev)
+            driver = an.MotionDriver(verts, device=dev)
+            self.num_poses = driver.num_poses
+            self.verts = torch.stack([driver.vertices(i) for i in range(driver.num_poses)]).contiguous()
+            self.motion = "content/amass_test_17.npz poses (committed fixture)" if driver.poses is not None else "synthetic sway"
+            cloud = synth.init_cloud(P, 0, "mid", seed=0, source=args.cloud)
+
+            class Model:
+                active_sh_degree = max_sh_degree = 0
+                _xyz = None
+                get_xyz = property(lambda m: m._xyz)
+                get_features = property(lambda m: m._f)
+                get_opacity = property(lambda m: m._o)
+                get_scaling = property(lambda m: m._s)
+                get_rotation = property(lambda m: m._r)
+            model = Model()
+            model._f, model._o, model._s, model._r = (getattr(cloud, k).to(dev) for k in ("shs", "opacities", "scales", "rotations"))
+            self.anim = an.AvatarAnimator(model, anchors, white_background=True, device=dev)
+            # the save loop's cameras (animation.py:936-945,993-1000): elevation 0, azimuth i mod 360, radius 2, fovy 50
+            self.cams = cameras_from_c2w(np.stack([synth.c2w_orbit(0.0, float(a), 2.0) for a in range(360)]), math.radians(50.0),
+                                         RES, RES, device=dev)
+
+        def frame(self, i):
+            return self.anim.render_frame(self.verts[i % self.num_poses], self.cams[i % 360])
+
+        def run(self, rounds, first=0):
+            n = 0
+            for _ in self.an.render_frames_parallel(range(first, first + rounds * world), self.frame, gather=self.gather):
+                n += 1
+            return n
+
+        def timed(self, steps, warmup, init_steps=None):
+            self.run(args.init_steps if init_steps is None else init_steps)
+            fence()
+            self.run(warmup)
+            fence()
+            t0 = time.perf_counter()
+            self.run(steps, first=7)
+            fence()
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                elapsed = max_over_ranks([elapsed])[0]
+            return elapsed
+
     P, sh_degree = args.points, args.sh_degree
+    if args.forward_only:
+        # ---------------- the animation leg (configs[4]): frames/s of re-anchor + forward (+ the image gather for N > 1)
+        wl = AnimationWorkload(P, gather=world > 1)
+        elapsed = wl.timed(args.steps, args.warmup)
+        frames = args.steps * world
+        line = None
+        without = None
+        if world > 1:
+            wl2 = AnimationWorkload(P, gather=False)
+            without = wl2.timed(args.steps, args.warmup, init_steps=min(args.init_steps, 20))
+        if rank == 0:
+            line = {
+                "metric": "rasterize fwd-only Gaussians/sec @1024^2 (animation frames; extra measurement)",
+                "value": P * frames / elapsed, "unit": "Gaussians/s", "frames_per_s": frames / elapsed,
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": args.init_steps,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"configs[4]: {P} Gaussians anchored on the human.obj mesh, one frame per rank per step: re-anchor "
+                                       f"on the posed mesh (hgs_reanchor; motion = {wl.motion}, pose i mod {wl.num_poses}) + no-grad "
+                                       "Renderer.render @1024^2 (elevation 0, azimuth i mod 360, radius 2, fovy 50: animation.py:936-1004), "
+                                       "frame k on rank k mod N" + ("; ONE asynchronous all-gather of the round's (3,H,W) images per step, "
+                                       "in flight under the next frame's render" if world > 1 else ""),
+                           "frames_per_step": world, "parallelism": f"frame-parallel x{world}"},
+                "animation": {"frames": frames, "image_gather": world > 1, "backend": backend if world > 1 else None,
+                              "ms_per_step_without_gather": None if without is None else without / args.steps * 1e3,
+                              "exposed_gather_us": None if without is None else (elapsed - without) / args.steps * 1e6},
+            }
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     collective_mode = [args.collective if args.collective != "auto" else "allgather"]
     main_wl = Workload(P, sh_degree, args.variant, args.views, args.forward_only, first_view=rank * args.views, seq_views=VPR)
 
@@ -394,7 +484,7 @@ def main():
             # both are recorded: these side measurements share the process with everything before them
             ts = [wl.timed(steps, warmup), wl.timed(steps, warmup, init_steps=0)]
             t = min(ts)
-            su = wl.stage_times(10)
+            su = wl.stage_times(10) if hasattr(wl, "stage_times") else None
             extra[name] = {"value": units * steps / t, "unit": "Gaussians/s", "ms_per_step": t / steps * 1e3,
                            "ms_per_step_runs": [x / steps * 1e3 for x in ts],
                            "steps": steps, "warmup": warmup, "init_steps": INIT_STEPS,
@@ -408,6 +498,10 @@ def main():
                 P, "configs[1] with the step-0 cloud (opacity 0.1, isotropic scales, identity rotations: no early termination)")
         measure("forward_only", Workload(P, sh_degree, "mid", 1, True, 0), max(20, args.steps // 3), max(5, args.warmup // 2),
                 P, "configs[4] shape: no-grad forward of one 1024^2 view (animation path), per GPU")
+        measure("animation_frames", AnimationWorkload(P, gather=False), max(20, args.steps // 3), max(5, args.warmup // 2), P,
+                "configs[4]: per frame re-anchor on the posed human.obj mesh (hgs_reanchor, AMASS-driven toy articulation) + no-grad "
+                "Renderer.render @1024^2, camera and pose change every frame (animation.py:384-403,477-484,966-1004); one GPU: "
+                "`bench.py --forward-only --gpus N` shards the frames")
         measure("config4_500k_sh3", Workload(500_000, 3, "mid", 1, False, 0), max(20, args.steps // 6), max(5, args.warmup // 5),
                 500_000, "configs[3]: 500k Gaussians, SH degree 3, one 1024^2 view, fwd+bwd")
 

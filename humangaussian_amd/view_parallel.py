@@ -166,7 +166,8 @@ def allgather_reduce(pack: torch.Tensor, group=None, mode: str = "allgather") ->
 def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg: torch.Tensor,
                           sh_degree: int, loss_grad_fn: Callable, render_fn: Optional[Callable] = None,
                           group=None, gather_images: bool = False, collective: str = "allgather",
-                          pipeline: Optional[bool] = None):
+                          pipeline: Optional[bool] = None, batched: bool = False,
+                          render_batch_fn: Optional[Callable] = None):
     """One training-style step over `cameras` (the global list, identical on every rank).
 
     params        replicated leaf tensors: means3D, shs, opacities, scales, rotations
@@ -174,9 +175,18 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
     render_fn     (camera, params, means2D, bg, sh_degree) -> (color, radii, depth, alpha);
                   defaults to the HIP rasterizer.
     pipeline      True: one asynchronous all-gather per ROUND of views (one view per rank), overlapped with
-                  the render of the next round, rounds chained in view order (module docstring);
+                  the render of the next round, rounds chained in view order (module docstring) - the BITS of the
+                  reference's serial loop;
                   False: the rank's views are summed locally and ONE collective ends the step
-                  (`collective` = "allgather" | "scatter"); None: pipeline iff a rank renders > 1 view.
+                  (`collective` = "allgather" | "scatter"); None: pipeline iff a rank renders > 1 view (and the
+                  collective is the default all-gather).
+    batched       True (excludes pipeline): the rank's views go through ONE batched rasterize call
+                  (`rasterize_gaussians_batch`: one launch set, 124 instead of 171 us per view at configs[1]; the kernel
+                  sums the rank's parameter gradients in view order) and ONE collective ends the step.  Deterministic and
+                  identical on every rank, but the sum is associated per rank first - (v0 + vG + ..) + (v1 + ..) + .. -
+                  so it agrees with the serial loop to rounding, not bit for bit; `pipeline=True` keeps the bits.
+    render_batch_fn  (cameras, params, means2D (B,P,3), bg, sh_degree) -> (color (B,..), radii (B,P), depth, alpha);
+                  defaults to the batched HIP call.
     Returns (grads dict summed over ALL views, radii max over all views, local outputs).
     """
     if render_fn is None:
@@ -185,8 +195,13 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_views(len(cameras), rank, world)
     rounds = (len(cameras) + world - 1) // world
-    if pipeline is None:
-        pipeline = rounds > 1
+    if batched and pipeline:
+        raise ValueError("batched=True renders the rank's views in one call: there are no rounds to pipeline")
+    if pipeline is None:                                    # (an explicit collective mode is honoured: it needs the one-collective form)
+        pipeline = rounds > 1 and not batched and collective == "allgather"
+    if pipeline and collective != "allgather":
+        raise ValueError(f"pipeline=True gathers one pack per round with all_gather; collective={collective!r} applies to "
+                         f"pipeline=False only")
     leaves = {k: params[k].detach().requires_grad_(True) for k in
               ("means3D", "shs", "opacities", "scales", "rotations")}
     P = leaves["means3D"].shape[0]
@@ -210,7 +225,31 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
         return {k: (g if g is not None else torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev))
                 for k, g in zip(names, gl)}, radii
 
-    if not pipeline:
+    if batched:
+        acc = {k: torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev) for k in names}
+        radii_max = torch.zeros(P, dtype=torch.int32, device=dev)
+        if mine:
+            fn = render_batch_fn if render_batch_fn is not None else hip_render_batch_fn
+            means2D = torch.zeros((len(mine),) + tuple(leaves["means3D"].shape), dtype=leaves["means3D"].dtype, device=dev,
+                                  requires_grad=True)
+            color, radii, depth, alpha = fn([cameras[v] for v in mine], leaves, means2D, bg, sh_degree)
+            outs, gouts = [], []
+            per_view = [loss_grad_fn(v, color[i].detach(), depth[i].detach(), alpha[i].detach()) for i, v in enumerate(mine)]
+            for o, col in ((color, 0), (depth, 1), (alpha, 2)):
+                if any(pv[col] is not None for pv in per_view):
+                    outs.append(o)
+                    gouts.append(torch.stack([pv[col] if pv[col] is not None else torch.zeros_like(o[i])
+                                              for i, pv in enumerate(per_view)]))
+            tens = [leaves[k] for k in names[:-1]] + [means2D]
+            gl = torch.autograd.grad(outs, tens, gouts, allow_unused=True)
+            for k, g in zip(names, gl):
+                if g is not None:
+                    acc[k] = g if k != "means2D" else g.sum(0)       # (screen-space gradients: summed over the rank's views)
+            radii_max = radii.max(dim=0).values.to(torch.int32)
+            for i, v in enumerate(mine):
+                outputs.append((v, color[i].detach(), depth[i].detach(), alpha[i].detach()))
+        total = allgather_reduce(pack_contribution(acc, radii_max), group, mode=collective)
+    elif not pipeline:
         acc = {k: torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev) for k in names}
         radii_max = torch.zeros(P, dtype=torch.int32, device=dev)
         for v in mine:
@@ -243,6 +282,9 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
                 total = pack.clone() if total is None else reduce_gathered(pack[None], total)
         if pending is not None:
             total = reduce_gathered(pending.result(), total)
+        if total is None:                                   # no view at all: the zero contribution
+            F = sum(int(torch.Size(shapes[k]).numel() // max(P, 1)) for k in GRAD_KEYS) + 1
+            total = torch.zeros((P, F), dtype=torch.float32, device=dev)
     grads, radii_all = unpack_contribution(total, {k: shapes[k] for k in GRAD_KEYS})
     if gather_images and world > 1:
         outputs = gather_view_images(outputs, len(cameras), group)
@@ -255,6 +297,8 @@ def gather_view_images(outputs, num_views: int, group=None):
     view-separable; the SDS loss is)."""
     world = dist.get_world_size(group)
     per_rank = (num_views + world - 1) // world
+    if not outputs:
+        raise ValueError("gather_view_images: this rank rendered no view (fewer views than ranks): it cannot size its slab")
     v0, c0, d0, a0 = outputs[0]
     slab = torch.zeros((per_rank, 5) + tuple(c0.shape[1:]), dtype=c0.dtype, device=c0.device)
     for i, (_, c, d, a) in enumerate(outputs):
@@ -271,6 +315,17 @@ def gather_view_images(outputs, num_views: int, group=None):
         s = allslab[v % world, v // world]
         res.append((v, s[:3], s[3:4], s[4:5]))
     return res
+
+
+def hip_render_batch_fn(cams, leaves, means2D, bg, sh_degree):
+    """Default render_batch_fn: the views of one rank in ONE batched HIP call (hgs_forward_batch / hgs_backward_batch)."""
+    import math
+    from .rasterizer import GaussianRasterizationSettings, rasterize_gaussians_batch
+    rsl = [GaussianRasterizationSettings(
+        int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg, 1.0,
+        cam.world_view_transform, cam.full_proj_transform, sh_degree, cam.camera_center, False, False) for cam in cams]
+    return rasterize_gaussians_batch(leaves["means3D"], means2D, leaves["shs"], None, leaves["opacities"], leaves["scales"],
+                                     leaves["rotations"], None, rsl)
 
 
 def hip_render_fn(cam, leaves, means2D, bg, sh_degree):

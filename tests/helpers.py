@@ -80,6 +80,7 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
     * gradients, per tensor and per Gaussian, relative to max |g64|:
         A. vs the fp32 oracle <= grad_tol          (parity in the arithmetic the reference uses)
         B. vs the fp64 oracle <= max(grad_tol, 1.25 x the fp32 oracle's own distance to fp64)
+           (flagged flip Gaussians: max(10 x that, 1.25 x the fp32 oracle's own distance on the flagged ones))
       and cosine(g, g64) >= 1 - max(cos_tol, 2 x (1 - cosine(g32, g64))).  B's second term exists
       because fp32 itself - the oracle included, and upstream's fp32 CUDA kernels with it - is not
       within 1e-3 of the exact gradient on every workload: at configs[3] (500k sub-pixel Gaussians,
@@ -159,6 +160,7 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
                    "vs_fp32oracle_nonflip": float(eA[nf].max()) / scale,
                    "vs_fp32oracle_flip": float(eA[flipg].max()) / scale if has_flip else 0.0,
                    "fp32oracle_vs_fp64_nonflip": float(e32[nf].max()) / scale,
+                   "fp32oracle_vs_fp64_flip": float(e32[flipg].max()) / scale if has_flip else 0.0,
                    "flip_gaussians_above_tol": int((err[flipg] > grad_tol * scale).sum()),
                    "1-cos": 1.0 - cos, "fp32oracle_1-cos": 1.0 - cos32}
             for kk, vv in st_.items():
@@ -167,7 +169,11 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
             gate(st_["vs_fp32oracle_nonflip"] <= grad_tol, k, "A: vs fp32 oracle", st_["vs_fp32oracle_nonflip"])
             gate(st_["vs_fp32oracle_flip"] <= 10 * grad_tol, k, "A: vs fp32 oracle (flip Gaussians)", st_["vs_fp32oracle_flip"])
             gate(st_["vs_fp64_nonflip"] <= boundB, k, "B: vs fp64 oracle", st_["vs_fp64_nonflip"], boundB)
-            gate(st_["vs_fp64_flip"] <= 10 * boundB, k, "B: vs fp64 oracle (flip Gaussians)", st_["vs_fp64_flip"])
+            # (a flipped threshold decision moves a Gaussian's gradient by a finite step: where the fp32 ORACLE's own step
+            #  against fp64 exceeds ten bounds - 1.14e-2 on one Gaussian of configs[2]'s view 5 on the human.obj cloud - the
+            #  gate is 1.25 x that step, as for the non-flip Gaussians; gate A above still pins us to the fp32 oracle)
+            gate(st_["vs_fp64_flip"] <= max(10 * boundB, 1.25 * st_["fp32oracle_vs_fp64_flip"]), k,
+                 "B: vs fp64 oracle (flip Gaussians)", st_["vs_fp64_flip"], st_["fp32oracle_vs_fp64_flip"])
             gate(1.0 - cos <= max(cos_tol, 2.0 * (1.0 - cos32)), k, "cosine", cos, cos32)
     stats["failures"] = [list(map(str, f)) for f in failures]
     PARITY_LOG.append(stats)

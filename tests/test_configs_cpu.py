@@ -152,3 +152,35 @@ def test_human_obj_cloud_is_the_surveys_normalised_mesh_sampled_area_uniformly()
     cl = synth.init_cloud(1000, 0, "mid", seed=0)
     assert np.array_equal(cl.means3D.numpy(), synth.human_points(1000, 0))
     assert not np.array_equal(synth.init_cloud(1000, 0, "mid", seed=0, source="capsule").means3D.numpy(), cl.means3D.numpy())
+
+
+def test_motion_driver_is_driven_by_the_amass_fixture_and_anchors_follow_the_mesh():
+    """configs[4] host pieces: the committed pose fixture is the reference's content/amass_test_17.npz (136 x 55 x 3), the
+    toy articulation is the identity at gain 0, moves limbs but leaves the torso (no joint there) in place, and the anchor
+    mapping reproduces animation.py:384-403's formula: points = barycentre + dist * face normal."""
+    import os
+    from humangaussian_amd import animation as an
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    poses = np.load(os.path.join(g, "amass_test_17_poses.npz"))["poses"]
+    assert poses.shape == (136, 55, 3) and poses.dtype == np.float32 and float(np.abs(poses).max()) < 2 * np.pi
+    mesh = np.load(os.path.join(g, "human_mesh.npz"))
+    d = an.MotionDriver(mesh["vertices"], device="cpu")
+    assert d.poses is not None and d.num_poses == 136
+    rest = d.rest
+    assert torch.equal(an.MotionDriver(mesh["vertices"], device="cpu", gain=0.0).vertices(17), rest)
+    v5, v60 = d.vertices(5), d.vertices(60)
+    assert torch.equal(d.vertices(5 + 136), v5)                                     # pose i mod 136
+    moved = (v60 - v5).norm(dim=1)
+    torso = (rest[:, 0].abs() < 0.12) & (rest[:, 2] > 0.05) & (rest[:, 2] < 0.5)
+    hands = rest[:, 0].abs() > 0.5
+    assert float(moved[torso].max()) < 1e-6 < 0.02 < float(moved[hands].mean())
+    assert float((v60 - rest).norm(dim=1).max()) < 0.8                               # stays a body, not an explosion
+    verts, anchors = an.human_mesh_anchors(500, seed=4, device="cpu", max_dist=0.004)
+    f = anchors.faces.numpy()[anchors.mapping_face.numpy()]
+    v0, v1, v2 = (verts[f[:, k]].astype(np.float64) for k in range(3))
+    n = np.cross(v1 - v0, v2 - v0)
+    n /= np.linalg.norm(n, axis=1, keepdims=True) + 1e-20
+    uvw = anchors.mapping_uvw.numpy().astype(np.float64)
+    assert np.allclose(uvw.sum(1), 1.0, atol=1e-6) and uvw.min() >= 0
+    pts = v0 * uvw[:, [0]] + v1 * uvw[:, [1]] + v2 * uvw[:, [2]] + anchors.mapping_dist.numpy()[:, None] * n
+    assert np.abs(pts).max(0)[2] < 0.79 and float(np.abs(anchors.mapping_dist.numpy()).max()) <= 0.004

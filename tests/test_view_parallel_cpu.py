@@ -177,3 +177,134 @@ def test_scatter_collective_equals_allgather_bitwise(world):
         pk[:, -1] = torch.randint(0, 40, (1001,), generator=g).float()
         packs.append(pk)
     assert torch.equal(ref, vp.reduce_gathered(torch.stack(packs)))
+
+
+# ------------------------------------------------------------------ a rank's views in ONE batched call (batched=True)
+
+def _oracle_render_batch_fn(cams, leaves, means2D, bg, sh_degree):
+    outs = [_oracle_render_fn(c, leaves, means2D[i], bg, sh_degree) for i, c in enumerate(cams)]
+    return tuple(torch.stack([o[k] for o in outs]) for k in range(4))
+
+
+def _batched_worker(rank, world, port, q, num_views):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sc, cams, params = _scene_and_cams()
+    cams = (cams * 2)[:num_views]
+    res = {}
+    for mode in ("allgather", "scatter"):
+        grads, radii, outs = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad, render_fn=_oracle_render_fn,
+                                                      render_batch_fn=_oracle_render_batch_fn, batched=True, collective=mode,
+                                                      gather_images=True)
+        # (numpy: pickled by value - a tensor travels as a file descriptor the parent may open after this process has gone)
+        res[mode] = ({k: v.numpy().copy() for k, v in grads.items()}, radii.numpy().copy(), [(v, c.numpy().copy()) for v, c, _, _ in outs])
+    q.put((rank, res))
+    dist.barrier()
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,num_views", [(2, 4), (2, 5)])
+def test_batched_rank_views_one_collective_matches_the_serial_loop_to_rounding(world, num_views):
+    """batched=True: every rank renders ITS views in one batched call and one collective ends the step.  Same values as the
+    serial loop to rounding (the sum is associated per rank first), the SAME BITS on every rank and in both collective
+    modes, radii max exact, all images on every rank in view order - also with a ragged shard (5 views on 2 ranks)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, q, num_views)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+    sc, cams, params = _scene_and_cams()
+    cams = (cams * 2)[:num_views]
+    ref, rref, _ = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad, render_fn=_oracle_render_fn, pipeline=True)
+    tt = torch.from_numpy
+    res = [(rank, {m: ({k: tt(v) for k, v in g.items()}, tt(r), [(v, tt(c)) for v, c in o]) for m, (g, r, o) in modes.items()})
+           for rank, modes in res]
+    g0, r0, o0 = res[0][1]["allgather"]
+    for rank, modes in res:
+        for mode, (grads, radii, outs) in modes.items():
+            assert torch.equal(radii, rref)
+            for k in ref:
+                assert torch.equal(grads[k], g0[k]), (rank, mode, k)                       # same bits everywhere
+                scale = max(float(ref[k].abs().max()), 1e-30)
+                assert float((grads[k].double() - ref[k].double()).abs().max()) <= 1e-5 * scale, (rank, mode, k)
+            assert [v for v, _ in outs] == list(range(num_views))
+            for (v, c), (v2, c2) in zip(outs, o0):
+                assert v == v2 and torch.equal(c, c2)
+
+
+def test_explicit_pipeline_with_scatter_is_refused_and_an_empty_view_list_gives_zeros():
+    sc, cams, params = _scene_and_cams()
+    with pytest.raises(ValueError):
+        vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad, render_fn=_oracle_render_fn, pipeline=True,
+                                 collective="scatter")
+    with pytest.raises(ValueError):
+        vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad, render_fn=_oracle_render_fn, pipeline=True, batched=True)
+    grads, radii, outs = vp.render_views_parallel([], params, sc["bg"].double(), 1, _loss_grad, render_fn=_oracle_render_fn, pipeline=True)
+    assert outs == [] and int(radii.abs().max()) == 0 and all(float(g.abs().max()) == 0 for g in grads.values())
+
+
+# ------------------------------------------------------------------ animation frames sharded over ranks
+
+def _frame_image(i):
+    g = torch.Generator().manual_seed(1000 + i)
+    return torch.rand(3, 8, 12, generator=g)
+
+
+def _frames_worker(rank, world, port, q, frames, gather):
+    from humangaussian_amd import animation as an
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rendered = []
+
+    def render(i):
+        rendered.append(i)
+        return _frame_image(i)
+    got = [(i, img.numpy().copy()) for i, img in an.render_frames_parallel(frames, render, gather=gather)]
+    q.put((rank, rendered, got))
+    dist.barrier()
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,nframes,gather", [(2, 7, True), (3, 7, True), (2, 6, False)])
+def test_animation_frames_are_sharded_round_robin_and_come_back_in_frame_order(world, nframes, gather):
+    """configs[4]: frame k of the sequence belongs to rank k mod G (animation.py:966-1004 loops over them on one GPU); with
+    the image gather every rank yields EVERY frame, in order, bit-identical to what its owner rendered - also when the
+    last round is ragged; without it a rank yields only its own frames and no collective runs."""
+    frames = [10 + 3 * k for k in range(nframes)]                    # (frame ids are arbitrary, not 0..n-1)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, q, frames, gather)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, rendered, got in res:
+        mine = [frames[k] for k in vp.shard_views(nframes, rank, world)]
+        assert rendered == mine                                       # every rank renders only its own frames, in order
+        want = frames if gather else mine
+        assert [i for i, _ in got] == want
+        for i, img in got:
+            assert torch.equal(torch.from_numpy(img), _frame_image(i))
+
+
+def test_animation_frames_without_a_process_group_is_the_plain_loop():
+    from humangaussian_amd import animation as an
+    got = list(an.render_frames_parallel(range(5), _frame_image))
+    assert [i for i, _ in got] == list(range(5)) and all(torch.equal(img, _frame_image(i)) for i, img in got)

@@ -29,7 +29,7 @@ PY
 
 mode_suite() {
   cd $R
-  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/suite_gpu.log
+  HGS_PARITY_STATS=$O/parity_fullsize.json timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/suite_gpu.log
   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $O/suite_smoke.log
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json
 }
