@@ -74,6 +74,8 @@ EXPORTS = {
     "hgs_mark_visible": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_void_p, c_void_p,
                                         c_void_p]),
     "hgs_knn_mean_dist2": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
+    "hgs_knn_scratch_bytes": (c_size_t, [c_int32]),
+    "hgs_knn_mean_dist2_grid": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hgs_reduce_view_packs": (ctypes.c_int, [c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "hgs_reduce_view_packs_acc": (ctypes.c_int, [c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hgs_pack_view_contribution": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 9),

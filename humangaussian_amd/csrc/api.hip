@@ -262,7 +262,64 @@ int hgs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, void* 
   if (P == 0) return HGS_OK;
   if (!points || !mean_dist2) return HGS_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  hipLaunchKernelGGL(hgs_k_knn3, dim3((P + 255) / 256), dim3(256), 0, stream, (int)P, points, mean_dist2);
+  hipLaunchKernelGGL(hgs_k_knn3, dim3((P + 255) / 256), dim3(256), 0, stream, (int)P, points, mean_dist2,
+                     static_cast<const KnnGrid*>(nullptr));
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
+namespace {
+struct KnnCarve { size_t grid, cell_of, count, cursor, bsum, sorted, total; uint32_t nc_max; };
+KnnCarve carve_knn(int32_t P) {
+  KnnCarve c;
+  const size_t n = (size_t)(P > 0 ? P : 0);
+  const size_t want = std::max<size_t>(64, 2 * n);
+  c.nc_max = (uint32_t)std::min<size_t>(want, HGS_KNN_MAX_CELLS);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = hgs_align_up(off + bytes, ALIGN); return o; };
+  c.grid = take(sizeof(KnnGrid));
+  c.cell_of = take(n * 4);
+  c.count = take(((size_t)c.nc_max + 1) * 4);
+  c.cursor = take((size_t)c.nc_max * 4);
+  c.bsum = take(((size_t)c.nc_max / 1024 + 2) * 4);
+  c.sorted = take(n * 16);
+  c.total = off;
+  return c;
+}
+}  // namespace
+
+size_t hgs_knn_scratch_bytes(int32_t P) { return carve_knn(P).total; }
+
+int hgs_knn_mean_dist2_grid(int32_t P, const float* points, float* mean_dist2, void* scratch, void* stream_) {
+  if (P < 0) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!points || !mean_dist2 || !scratch) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const KnnCarve c = carve_knn(P);
+  char* sp = static_cast<char*>(scratch);
+  KnnGrid* G = reinterpret_cast<KnnGrid*>(sp + c.grid);
+  uint32_t* cell_of = reinterpret_cast<uint32_t*>(sp + c.cell_of);
+  uint32_t* count = reinterpret_cast<uint32_t*>(sp + c.count);
+  uint32_t* cursor = reinterpret_cast<uint32_t*>(sp + c.cursor);
+  uint32_t* bsum = reinterpret_cast<uint32_t*>(sp + c.bsum);
+  float4* sorted = reinterpret_cast<float4*>(sp + c.sorted);
+  // box images: min = all ones, max = zero; cell counters zero
+  hipError_t e = hipMemsetAsync(&G->bmin[0], 0xff, 12, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(&G->bmax[0], 0, 12, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(count, 0, ((size_t)c.nc_max + 1) * 4, stream);
+  if (e != hipSuccess) return hip_rc(e);
+  const unsigned gp = (unsigned)((P + 255) / 256), gc = (unsigned)((c.nc_max + 1023u) / 1024u);
+  hipLaunchKernelGGL(hgs_k_knn_bbox, dim3(gp), dim3(256), 0, stream, (int)P, points, G);
+  hipLaunchKernelGGL(hgs_k_knn_grid_setup, dim3(1), dim3(64), 0, stream, (int)P, c.nc_max, G);
+  hipLaunchKernelGGL(hgs_k_knn_count, dim3(gp), dim3(256), 0, stream, (int)P, points, (const KnnGrid*)G, cell_of, count);
+  hipLaunchKernelGGL(hgs_k_knn_scan1, dim3(gc), dim3(1024), 0, stream, (const KnnGrid*)G, (const uint32_t*)count, bsum);
+  hipLaunchKernelGGL(hgs_k_knn_scan2, dim3(1), dim3(1024), 0, stream, G, bsum);
+  hipLaunchKernelGGL(hgs_k_knn_scan3, dim3(gc), dim3(1024), 0, stream, (int)P, G, count, cursor, (const uint32_t*)bsum);
+  hipLaunchKernelGGL(hgs_k_knn_scatter, dim3(gp), dim3(256), 0, stream, (int)P, points, (const uint32_t*)cell_of, cursor, sorted);
+  hipLaunchKernelGGL(hgs_k_knn_search, dim3(gp), dim3(256), 0, stream, (int)P, (const KnnGrid*)G, (const uint32_t*)count,
+                     (const float4*)sorted, mean_dist2);
+  // degenerate clouds (decided on the device: KnnGrid::brute): the exact brute force; returns at once otherwise
+  hipLaunchKernelGGL(hgs_k_knn3, dim3(gp), dim3(256), 0, stream, (int)P, points, mean_dist2, (const KnnGrid*)G);
   HGS_LAUNCH_CHECK();
   return HGS_OK;
 }

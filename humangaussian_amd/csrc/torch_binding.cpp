@@ -519,7 +519,7 @@ Tensor mark_visible(const Tensor& positions, const Tensor& bg, const Tensor& vie
 }
 
 // replaces simple_knn._C.distCUDA2: mean squared distance to the 3 nearest neighbours
-Tensor knn_mean_dist2(const Tensor& points) {
+Tensor knn_mean_dist2(const Tensor& points, bool brute_force) {
   at::NoGradGuard ng;
   const c10::Device dev = points.device();
   if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
@@ -528,10 +528,16 @@ Tensor knn_mean_dist2(const Tensor& points) {
   const Tensor pts = f32c(points, dev, "points");
   const int64_t P = pts.size(0);
   Tensor out = at::empty({P}, at::TensorOptions().dtype(at::kFloat).device(dev));
-  if (P > 0) {
+  if (P > 0x7fffffffll / 4) throw std::runtime_error("too many points");
+  if (P > 0 && brute_force) {
     const int rc = hgs_knn_mean_dist2((int32_t)P, pts.data_ptr<float>(), out.data_ptr<float>(),
                                       c10::hip::getCurrentHIPStream(dev.index()).stream());
     check_rc(rc, "hgs_knn_mean_dist2");
+  } else if (P > 0) {      // the grid form (near-linear); its scratch lives for the duration of the call's stream work
+    Tensor scratch = at::empty({(int64_t)hgs_knn_scratch_bytes((int32_t)P)}, at::TensorOptions().dtype(at::kByte).device(dev));
+    const int rc = hgs_knn_mean_dist2_grid((int32_t)P, pts.data_ptr<float>(), out.data_ptr<float>(), scratch.data_ptr(),
+                                           c10::hip::getCurrentHIPStream(dev.index()).stream());
+    check_rc(rc, "hgs_knn_mean_dist2_grid");
   }
   return out;
 }
@@ -758,7 +764,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize, py::call_guard<py::gil_scoped_release>());
   m.def("rasterize_batch", &rasterize_batch, py::call_guard<py::gil_scoped_release>());
   m.def("mark_visible", &mark_visible, py::call_guard<py::gil_scoped_release>());
-  m.def("knn_mean_dist2", &knn_mean_dist2, py::call_guard<py::gil_scoped_release>());
+  m.def("knn_mean_dist2", &knn_mean_dist2, py::arg("points"), py::arg("brute_force") = false,
+        py::call_guard<py::gil_scoped_release>());
   m.def("reduce_view_packs", &reduce_view_packs, py::arg("gathered"), py::arg("acc_in") = py::none(),
         py::call_guard<py::gil_scoped_release>());
   m.def("pack_view_contribution", &pack_view_contribution, py::call_guard<py::gil_scoped_release>());

@@ -213,6 +213,49 @@ def test_dist_cuda2_matches_kdtree_reference():
 
 
 @pytest.mark.gpu
+def test_dist_cuda2_grid_search_equals_the_brute_force_bit_for_bit():
+    """The near-linear form (uniform grid + ring search, csrc/knn.hip; what upstream's Morton sort + box pruning is for,
+    simple_knn.cu:63-221) returns the SAME three distances as the exact O(P^2) kernel on every kind of cloud: the avatar
+    surface at the benchmark sizes, planar / collinear sets, duplicates, a box stretched by outliers, a cloud so
+    degenerate (everything in one cell) that the device falls back to the brute force by itself."""
+    import time
+    import numpy as np
+    from humangaussian_amd import synth
+    from humangaussian_amd.knn import distCUDA2
+    rng = np.random.default_rng(5)
+    clouds = {
+        "human_100k": synth.human_points(100_000, seed=0),
+        "gauss": rng.normal(0, 0.4, (20_000, 3)),
+        "planar": np.concatenate([rng.uniform(-1, 1, (5000, 2)), np.zeros((5000, 1))], 1),
+        "collinear": np.stack([rng.uniform(-3, 3, 3000), np.zeros(3000), np.zeros(3000)], 1),
+        "outliers": np.concatenate([rng.normal(0, 0.01, (6000, 3)), [[50.0, 0, 0], [-50.0, 0.3, 0]]]),
+        "all_equal": np.full((6000, 3), 0.25),          # > 4096 points in one cell: the device picks the brute force
+        "tiny": rng.normal(0, 1, (5, 3)),
+        "two_scales": np.concatenate([rng.normal((0, 0, 0), 0.002, (4000, 3)), rng.normal((1, 1, 1), 0.3, (4000, 3))]),
+    }
+    dup = rng.normal(0, 0.2, (3000, 3))
+    dup[5] = dup[6]
+    dup[50] = dup[51] = dup[52] = dup[53]
+    clouds["duplicates"] = dup
+    for name, pts in clouds.items():
+        p = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float32)).cuda()
+        grid, brute = distCUDA2(p), distCUDA2(p, brute_force=True)
+        assert torch.equal(grid.view(torch.int32), brute.view(torch.int32)), (name, float((grid - brute).abs().max()))
+    # configs[3]-sized cloud against the k-d tree, and the point of it: time
+    pts = synth.human_points(500_000, seed=0)
+    p = torch.from_numpy(pts).cuda()
+    distCUDA2(p)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = distCUDA2(p)
+    torch.cuda.synchronize()
+    t_grid = time.perf_counter() - t0
+    assert np.allclose(got.cpu().numpy(), synth.mean_knn_dist2(pts), rtol=2e-5, atol=1e-12)
+    print(f"KNN 500k points: grid {t_grid * 1e3:.2f} ms")
+    assert t_grid < 0.02                                  # (the brute force takes ~60 ms here)
+
+
+@pytest.mark.gpu
 def test_view_pack_reduction_kernel_equals_rank_order_loop():
     """hgs_reduce_view_packs (what allgather_reduce runs on HIP tensors) against the rank-order
     torch loop the CPU/gloo tests exercise: sums bit-identical, radii column = max."""

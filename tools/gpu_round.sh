@@ -1,8 +1,9 @@
 #!/bin/bash
 # tools/gpu_round.sh MODE ...   - what a gpurun call runs on the GPU box (the repo root is taken from this file's place).
-#   suite                 the whole `-m gpu` suite, smoke(), the default bench line           -> gpurun_out/suite_*.log, bench_default.json
-#   ab NAME ...           short benches (one view, 8 views batched, configs[3]) of the in-tree build and of every
-#                         variants/NAME/libhgs_rast.so (tools/mkvariant.sh; LD_PRELOAD)          -> gpurun_out/ab_*.json + one line each
+#   tests                 the whole `-m gpu` suite + smoke()                                    -> gpurun_out/suite_*.log, parity_fullsize.json
+#   suite                 tests + the default bench line                                        -> ... + bench_default.json
+#   ab NAME ...           short benches (AB_CONFIGS, default "1v 8v cfg3": one view, 8 views batched, configs[3]) of the in-tree
+#                         build and of every variants/NAME/libhgs_rast.so (tools/mkvariant.sh; LD_PRELOAD) -> gpurun_out/ab_*.json
 #   quick                 parity + batch suites only (fast gate for a kernel change)
 #   profile COMMIT        the round's artifacts: rocprofv3 --kernel-trace --stats, PMC FETCH/WRITE traffic (their own passes),
 #                         for configs[1], configs[3] and the 8-view batched call; three SQ-counter passes for configs[1]
@@ -27,10 +28,15 @@ except Exception as e:
 PY
 }
 
-mode_suite() {
+mode_tests() {
   cd $R
-  HGS_PARITY_STATS=$O/parity_fullsize.json timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/suite_gpu.log
+  HGS_PARITY_STATS=$O/parity_fullsize.json timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee $O/suite_gpu.log
   timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $O/suite_smoke.log
+}
+
+mode_suite() {
+  mode_tests
+  cd $R
   timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json
 }
 
@@ -43,9 +49,13 @@ mode_ab() {
   local names=("base" "$@")
   for N in "${names[@]}"; do
     local PRE=""; [ "$N" != base ] && PRE=$R/variants/$N/libhgs_rast.so
-    bench_line ${N}_1v "$PRE"
-    bench_line ${N}_8v "$PRE" --views 8 --steps 40
-    bench_line ${N}_cfg3 "$PRE" --points 500000 --sh-degree 3 --steps 40
+    for cfg in ${AB_CONFIGS:-1v 8v cfg3}; do
+      case $cfg in
+        1v) bench_line ${N}_1v "$PRE" ;;
+        8v) bench_line ${N}_8v "$PRE" --views 8 --steps 40 ;;
+        cfg3) bench_line ${N}_cfg3 "$PRE" --points 500000 --sh-degree 3 --steps 40 ;;
+      esac
+    done
   done
 }
 
