@@ -64,8 +64,8 @@ inline int cu_count(hipStream_t stream) {
 constexpr size_t ALIGN = 256;
 constexpr size_t HGS_LDS_BINS_MAX = 16384;   // T*4 bytes of LDS <= 64 KB
 #ifndef HGS_BIN_WGS_PER_VIEW_MAX
-#define HGS_BIN_WGS_PER_VIEW_MAX 256
-#endif
+#define HGS_BIN_WGS_PER_VIEW_MAX 512   // (256 until round 5: at 500k Gaussians a workgroup then walked 8 chunks one after the other -
+#endif                                 //  preprocess_fwd 70 -> 54 us with 512, +2 us in `tiles` (twice the histogram rows); 100k: +-0)
 #ifndef HGS_BIN_WGS_TOTAL_MAX
 #define HGS_BIN_WGS_TOTAL_MAX 1024
 #endif
@@ -424,11 +424,26 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     if (e != hipSuccess) return hip_rc(e);
   }
   if (v.nblk > 0) {
-    if (v.lds_bins)
-      hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.B * v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v,
+    if (v.lds_bins) {
+      // SH blocks of 48+ bytes go through LDS (preprocess.hip::stage_sh_chunk): 256 rows behind the tile histogram; beyond
+      // 64 KB of dynamic LDS the kernel's limit is raised first (if that fails: the per-thread loads, same results)
+      size_t lds_pre = lds_bytes;
+      int stage_sh = 0;
+      if (shs && hgs_sh_staged(M)) {
+        const size_t want = hgs_align_up(lds_bytes, 16) + (size_t)HGS_BLOCK * hgs_sh_row_f4(M) * 16;
+        bool ok = want <= 160 * 1024;
+        if (ok && want > 65536 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(hgs_k_preprocess_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)want) != hipSuccess) {
+          (void)hipGetLastError();
+          ok = false;
+        }
+        if (ok) { lds_pre = want; stage_sh = 1; }
+      }
+      hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.B * v.nwg), dim3(HGS_BLOCK), lds_pre, stream, v,
                          L, means3D, shs, colors_precomp, opacities, scales, rotations,
-                         cov3D_precomp, radii);
-    else
+                         cov3D_precomp, radii, stage_sh);
+    } else
       hipLaunchKernelGGL(hgs_k_preprocess_fwd_ga, dim3(v.B * v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
                          means3D, shs, colors_precomp, opacities, scales, rotations,
                          cov3D_precomp, radii);
@@ -615,18 +630,32 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   const int nc = (deg + 1) * (deg + 1);
   const unsigned thr_p = 64u * (unsigned)v.B, grid_p = (unsigned)((v.P + 63) / 64);
   const size_t lds_p = (size_t)(20 + 3 * nc) * thr_p * sizeof(float);
-  // (the exchange buffer is kept within 64 KB of dynamic LDS: 11 views at SH degree 0, 8 at degree 1, 5 / 3 at degrees 2 / 3)
-  const bool vpar_ok = v.B >= HGS_PRE_BWD_VPAR_MIN_VIEWS && v.B <= (deg >= 2 ? 8 : 16) && lds_p <= 65536;
+  // The exchange buffer may take the CU's whole LDS (160 KB on gfx950; beyond 64 KB the kernel's dynamic-LDS limit is raised
+  // first): 16 views at SH degrees 0 / 1, 8 at degrees 2 / 3 (139 KB at degree 3) - the thread-per-(Gaussian, view) form
+  // then covers every batch a training step makes; the loop form (d*: 256 VGPRs at degree 3, one wave per SIMD) remains
+  // for what does not fit or when the limit cannot be raised.
+  bool vpar_ok = v.B >= HGS_PRE_BWD_VPAR_MIN_VIEWS && v.B <= (deg >= 2 ? 8 : 16) && lds_p <= 160 * 1024;
+  if (vpar_ok && lds_p > 65536) {
+    const void* kfn = deg == 0 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p0)
+                    : deg == 1 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p1)
+                    : deg == 2 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p2)
+                               : reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p3);
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) {
+      (void)hipGetLastError();
+      vpar_ok = false;
+    }
+  }
   const int mode = v.B == 1 ? 1 : (vpar_ok ? 2 : 0);
+  const size_t lds_s = hgs_pre_bwd_stage_bytes(M, deg, shs != nullptr && dL_dshs != nullptr);      // (<= 53 KB)
   switch (deg + 4 * mode) {
     case 0: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d0, v.nblk, HGS_BLOCK, 0); break;
     case 1: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d1, v.nblk, HGS_BLOCK, 0); break;
     case 2: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d2, v.nblk, HGS_BLOCK, 0); break;
     case 3: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_d3, v.nblk, HGS_BLOCK, 0); break;
     case 4: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s0, v.nblk, HGS_BLOCK, 0); break;
-    case 5: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s1, v.nblk, HGS_BLOCK, 0); break;
-    case 6: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s2, v.nblk, HGS_BLOCK, 0); break;
-    case 7: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s3, v.nblk, HGS_BLOCK, 0); break;
+    case 5: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s1, v.nblk, HGS_BLOCK, lds_s); break;      // (SH blocks through LDS)
+    case 6: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s2, v.nblk, HGS_BLOCK, lds_s); break;
+    case 7: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_s3, v.nblk, HGS_BLOCK, lds_s); break;
     case 8: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_p0, grid_p, thr_p, lds_p); break;
     case 9: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_p1, grid_p, thr_p, lds_p); break;
     case 10: HGS_LAUNCH_PRE_BWD(hgs_k_preprocess_bwd_p2, grid_p, thr_p, lds_p); break;

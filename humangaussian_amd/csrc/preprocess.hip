@@ -153,6 +153,71 @@ __device__ __forceinline__ void load_sh_block(const float* __restrict__ src, int
   }
 }
 
+// ---- SH blocks through LDS (M >= 4).  A thread's (M,3) block is 12 M contiguous bytes, so the per-thread loads above touch
+// 64 different cache lines per wave instruction and every line is requested again for each 16 B piece of it: at SH degree 3
+// the forward moved 8x the SH bytes between L2 and L1 (hgs_k_preprocess_fwd: 65 us for 156 MB at 500k Gaussians).  The 256
+// blocks of a chunk are ONE contiguous, 16 B-aligned range: the workgroup loads it with fully coalesced dwordx4 loads,
+// spreads it into LDS rows of an ODD number of float4 (conflict-free b128 reads at row stride) and every thread picks
+// its row up from there.  Same values, same arithmetic: results are bit-identical.
+__host__ __device__ __forceinline__ int hgs_sh_row_f4(int M) { const int q = (3 * M + 3) / 4; return (q & 1) ? q : q + 1; }
+__host__ __device__ __forceinline__ bool hgs_sh_staged(int M) { return M >= 4 && M <= 16; }
+
+// stage the SH blocks of Gaussians [i0, i0 + cnt) of one view-independent tensor into `stage` ([256][row_f4 * 4] floats)
+__device__ __forceinline__ void stage_sh_chunk(const float* __restrict__ shs, int M, int i0, int cnt, float* __restrict__ stage) {
+  const int m3 = 3 * M, rowf = hgs_sh_row_f4(M) * 4;
+  const float* __restrict__ src = shs + (size_t)i0 * m3;                 // (i0 is a multiple of 256: 16 B aligned for every M)
+  const int nfl = cnt * m3, nfull = nfl >> 2;
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+  for (int f = (int)threadIdx.x; f < nfull; f += HGS_BLOCK) {
+    const float4 t = s4[f];
+    int g = (4 * f) / m3, c = 4 * f - g * m3;
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      stage[g * rowf + c] = tv[j];
+      if (++c == m3) { c = 0; ++g; }
+    }
+  }
+  if ((int)threadIdx.x < (nfl & 3)) {                                    // the last 1-3 floats of the tensor's last chunk
+    const int e = 4 * nfull + (int)threadIdx.x;
+    stage[(e / m3) * rowf + (e % m3)] = src[e];
+  }
+}
+
+// a thread's staged row -> registers (`sh48` must be indexed with constants only)
+__device__ __forceinline__ void load_sh_row_lds(const float* __restrict__ row, int M, float (&sh48)[48]) {
+  const float4* r4 = reinterpret_cast<const float4*>(row);
+  const int nq = (3 * M + 3) >> 2;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < nq) t = r4[q];
+    sh48[4 * q + 0] = t.x; sh48[4 * q + 1] = t.y; sh48[4 * q + 2] = t.z; sh48[4 * q + 3] = t.w;
+  }
+}
+
+// the inverse of stage_sh_chunk: the rows of a FULL chunk (256 Gaussians) leave LDS as one contiguous, coalesced block
+__device__ __forceinline__ void unstage_sh_chunk(float* __restrict__ dst_all, int M, int i0, const float* __restrict__ stage) {
+  const int m3 = 3 * M, rowf = hgs_sh_row_f4(M) * 4;
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(dst_all + (size_t)i0 * m3);
+  const int nfull = (HGS_BLOCK * m3) >> 2;                                // (256 * 3 M is a multiple of 4)
+  for (int f = (int)threadIdx.x; f < nfull; f += HGS_BLOCK) {
+    int g = (4 * f) / m3, c = 4 * f - g * m3;
+    float tv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tv[j] = stage[g * rowf + c];
+      if (++c == m3) { c = 0; ++g; }
+    }
+    d4[f] = make_float4(tv[0], tv[1], tv[2], tv[3]);
+  }
+}
+// does the single-view per-Gaussian backward of this workgroup move its SH blocks through LDS?  (host: LDS size; device:
+// workgroup-uniform - full chunks only, so that no thread of a staging workgroup is idle)
+__host__ __device__ __forceinline__ size_t hgs_pre_bwd_stage_bytes(int M, int deg, bool has_sh) {
+  return (deg > 0 && has_sh && hgs_sh_staged(M)) ? (size_t)HGS_BLOCK * hgs_sh_row_f4(M) * 16 : 0;
+}
+
 // SH basis evaluation for one Gaussian; sh points at its (M,3) block.
 __device__ __forceinline__ void eval_sh(int deg, const float* __restrict__ sh, float x,
                                         float y, float z, float out[3]) {
@@ -192,7 +257,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const View& v, const Cam& cam, int i, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ cov3D_precomp, GeomRec& rec) {
+    const float* __restrict__ cov3D_precomp, GeomRec& rec, const float* __restrict__ sh_row = nullptr) {
   const float* __restrict__ V = cam.viewmatrix;
   const float* __restrict__ PM = cam.projmatrix;
   rec.mx = rec.my = rec.ca = rec.cb = rec.cc = rec.op = 0.f;
@@ -254,7 +319,11 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float ddx = x - cp[0], ddy = y - cp[1], ddz = z - cp[2];
     const float n = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
     float col[3];
-    if (sh_block_vectorisable(v.M)) {
+    if (sh_row) {                                          // (the chunk's blocks were staged in LDS: stage_sh_chunk)
+      float sh48[48];
+      load_sh_row_lds(sh_row, v.M, sh48);
+      eval_sh(v.D, sh48, ddx / n, ddy / n, ddz / n, col);
+    } else if (sh_block_vectorisable(v.M)) {
       float sh48[48];
       load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
       eval_sh(v.D, sh48, ddx / n, ddy / n, ddz / n, col);
@@ -306,7 +375,7 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
                      const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                      const float* __restrict__ opacities, const float* __restrict__ scales,
                      const float* __restrict__ rotations,
-                     const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
+                     const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii, int stage_sh) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
   zero_counters(L);
@@ -315,15 +384,23 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
   for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_hist[t] = 0u;
   __syncthreads();
   const int gxm = v.grid_x;
+  // (stage_sh: the launch reserved [256][hgs_sh_row_f4(M) * 4] floats of LDS behind the histogram)
+  float* __restrict__ sh_stage = reinterpret_cast<float*>(lds_hist + ((v.T + 3) & ~3));
+  const int sh_rowf = hgs_sh_row_f4(v.M) * 4;
   for (int c = 0; c < v.cpw; ++c) {
     const int chunk = lw * v.cpw + c;
     if (chunk >= v.nblk) break;
     const int i = chunk * HGS_BLOCK + threadIdx.x;
+    if (stage_sh) {
+      if (c) __syncthreads();                              // the previous chunk's rows have been read
+      stage_sh_chunk(shs, v.M, chunk * HGS_BLOCK, min(HGS_BLOCK, v.P - chunk * HGS_BLOCK), sh_stage);
+      __syncthreads();
+    }
     uint32_t tt = 0;
     if (i < v.P) {
       GeomRec rec;
       tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
-                          cov3D_precomp, rec);
+                          cov3D_precomp, rec, stage_sh ? sh_stage + (int)threadIdx.x * sh_rowf : nullptr);
       radii[(size_t)b * v.P + i] = rec.radius;
       store_geom(&L.geom[(size_t)b * v.P + i], rec);      // the record leaves the registers now ...
       if (tt) {
@@ -411,6 +488,14 @@ __device__ __forceinline__ void preprocess_bwd_body(
     i = blockIdx.x * 64 + il;
   }
   const bool mine = (i < v.P) && (bview < v.B);
+  // single view, SH degree >= 1: the chunk's SH blocks come in (and the gradient blocks go out) through LDS as coalesced
+  // ranges (stage_sh_chunk: per-thread 16 B pieces at a 12 M byte stride cost 8x the L2 <-> L1 traffic).  Full chunks only.
+  const bool staged = MODE == 1 && DEG > 0 && dL_dshs != nullptr && shs != nullptr && hgs_sh_staged(v.M) &&
+                      (int)(blockIdx.x + 1) * HGS_BLOCK <= v.P;
+  if (staged) {
+    stage_sh_chunk(shs, v.M, (int)blockIdx.x * HGS_BLOCK, HGS_BLOCK, red);
+    __syncthreads();
+  }
   if (!VPAR && !mine) return;
   if (!mine) i = 0;                               // mode 2: idle threads stay for the barrier; they read Gaussian 0 of
   if (bview >= v.B) bview = 0;                    // view 0 (the view stays wave-uniform) and write nothing
@@ -438,7 +523,9 @@ __device__ __forceinline__ void preprocess_bwd_body(
       q = act_rotation(rotations, i, v.act, q_inv_norm);
     }
     if (DEG > 0 && want_sh) {
-      if (sh_block_vectorisable(v.M)) {
+      if (staged) {
+        load_sh_row_lds(red + (int)threadIdx.x * (hgs_sh_row_f4(v.M) * 4), v.M, sh48);
+      } else if (sh_block_vectorisable(v.M)) {
         load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
       } else {
         const float* shp = shs + (size_t)i * v.M * 3;
@@ -731,7 +818,15 @@ __device__ __forceinline__ void preprocess_bwd_body(
   }
 
   // ---- one write per output element
-  if (dL_dshs) {
+  if (dL_dshs && staged) {                       // the thread's row -> LDS, the chunk's rows -> one coalesced block
+    float* row = red + (int)threadIdx.x * (hgs_sh_row_f4(v.M) * 4);
+#pragma unroll
+    for (int k = 0; k < 3 * NC; ++k)
+      if (k < 3 * v.M) row[k] = a_sh[k];
+    for (int k = 3 * NC; k < 3 * v.M; ++k) row[k] = 0.f;
+    __syncthreads();
+    unstage_sh_chunk(dL_dshs, v.M, (int)blockIdx.x * HGS_BLOCK, red);
+  } else if (dL_dshs) {
     float* out = dL_dshs + (size_t)i * v.M * 3;
     if (sh_block_vectorisable(v.M)) {            // 16 B stores of the (M,3) gradient block
       float4* o4 = reinterpret_cast<float4*>(out);
