@@ -424,26 +424,11 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     if (e != hipSuccess) return hip_rc(e);
   }
   if (v.nblk > 0) {
-    if (v.lds_bins) {
-      // SH blocks of 48+ bytes go through LDS (preprocess.hip::stage_sh_chunk): 256 rows behind the tile histogram; beyond
-      // 64 KB of dynamic LDS the kernel's limit is raised first (if that fails: the per-thread loads, same results)
-      size_t lds_pre = lds_bytes;
-      int stage_sh = 0;
-      if (shs && hgs_sh_staged(M)) {
-        const size_t want = hgs_align_up(lds_bytes, 16) + (size_t)HGS_BLOCK * hgs_sh_row_f4(M) * 16;
-        bool ok = want <= 160 * 1024;
-        if (ok && want > 65536 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(hgs_k_preprocess_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)want) != hipSuccess) {
-          (void)hipGetLastError();
-          ok = false;
-        }
-        if (ok) { lds_pre = want; stage_sh = 1; }
-      }
-      hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.B * v.nwg), dim3(HGS_BLOCK), lds_pre, stream, v,
+    if (v.lds_bins)
+      hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.B * v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v,
                          L, means3D, shs, colors_precomp, opacities, scales, rotations,
-                         cov3D_precomp, radii, stage_sh);
-    } else
+                         cov3D_precomp, radii);
+    else
       hipLaunchKernelGGL(hgs_k_preprocess_fwd_ga, dim3(v.B * v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
                          means3D, shs, colors_precomp, opacities, scales, rotations,
                          cov3D_precomp, radii);

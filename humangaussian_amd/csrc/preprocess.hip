@@ -153,12 +153,13 @@ __device__ __forceinline__ void load_sh_block(const float* __restrict__ src, int
   }
 }
 
-// ---- SH blocks through LDS (M >= 4).  A thread's (M,3) block is 12 M contiguous bytes, so the per-thread loads above touch
-// 64 different cache lines per wave instruction and every line is requested again for each 16 B piece of it: at SH degree 3
-// the forward moved 8x the SH bytes between L2 and L1 (hgs_k_preprocess_fwd: 65 us for 156 MB at 500k Gaussians).  The 256
-// blocks of a chunk are ONE contiguous, 16 B-aligned range: the workgroup loads it with fully coalesced dwordx4 loads,
-// spreads it into LDS rows of an ODD number of float4 (conflict-free b128 reads at row stride) and every thread picks
-// its row up from there.  Same values, same arithmetic: results are bit-identical.
+// ---- SH blocks through LDS (M >= 4) in the single-view per-Gaussian BACKWARD.  A thread's (M,3) block is 12 M contiguous
+// bytes, so per-thread 16 B accesses touch 64 different cache lines per wave instruction - for the gradient block that
+// is 12 partial-line stores per line.  The 256 blocks of a chunk are ONE contiguous, 16 B-aligned range: the workgroup
+// moves it with fully coalesced dwordx4 accesses through LDS rows of an ODD number of float4 (conflict-free b128 row
+// accesses), in (shs) and out (dL_dshs): hgs_k_preprocess_bwd_s3 96 -> 77 us at 500k Gaussians, bit-identical results.
+// (The same staging of the FORWARD's SH loads lost - preprocess_fwd 54 -> 68 us at 500k: its loads were not what it
+// waits for, the LDS round trip and two more barriers per chunk were pure cost.  EXPERIMENTS.md, round 5.)
 __host__ __device__ __forceinline__ int hgs_sh_row_f4(int M) { const int q = (3 * M + 3) / 4; return (q & 1) ? q : q + 1; }
 __host__ __device__ __forceinline__ bool hgs_sh_staged(int M) { return M >= 4 && M <= 16; }
 
@@ -257,7 +258,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const View& v, const Cam& cam, int i, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
     const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ cov3D_precomp, GeomRec& rec, const float* __restrict__ sh_row = nullptr) {
+    const float* __restrict__ cov3D_precomp, GeomRec& rec) {
   const float* __restrict__ V = cam.viewmatrix;
   const float* __restrict__ PM = cam.projmatrix;
   rec.mx = rec.my = rec.ca = rec.cb = rec.cc = rec.op = 0.f;
@@ -319,11 +320,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     const float ddx = x - cp[0], ddy = y - cp[1], ddz = z - cp[2];
     const float n = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
     float col[3];
-    if (sh_row) {                                          // (the chunk's blocks were staged in LDS: stage_sh_chunk)
-      float sh48[48];
-      load_sh_row_lds(sh_row, v.M, sh48);
-      eval_sh(v.D, sh48, ddx / n, ddy / n, ddz / n, col);
-    } else if (sh_block_vectorisable(v.M)) {
+    if (sh_block_vectorisable(v.M)) {
       float sh48[48];
       load_sh_block(shs + (size_t)i * v.M * 3, v.M, sh48);
       eval_sh(v.D, sh48, ddx / n, ddy / n, ddz / n, col);
@@ -375,7 +372,7 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
                      const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                      const float* __restrict__ opacities, const float* __restrict__ scales,
                      const float* __restrict__ rotations,
-                     const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii, int stage_sh) {
+                     const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
   zero_counters(L);
@@ -384,23 +381,15 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
   for (int t = threadIdx.x; t < v.T; t += HGS_BLOCK) lds_hist[t] = 0u;
   __syncthreads();
   const int gxm = v.grid_x;
-  // (stage_sh: the launch reserved [256][hgs_sh_row_f4(M) * 4] floats of LDS behind the histogram)
-  float* __restrict__ sh_stage = reinterpret_cast<float*>(lds_hist + ((v.T + 3) & ~3));
-  const int sh_rowf = hgs_sh_row_f4(v.M) * 4;
   for (int c = 0; c < v.cpw; ++c) {
     const int chunk = lw * v.cpw + c;
     if (chunk >= v.nblk) break;
     const int i = chunk * HGS_BLOCK + threadIdx.x;
-    if (stage_sh) {
-      if (c) __syncthreads();                              // the previous chunk's rows have been read
-      stage_sh_chunk(shs, v.M, chunk * HGS_BLOCK, min(HGS_BLOCK, v.P - chunk * HGS_BLOCK), sh_stage);
-      __syncthreads();
-    }
     uint32_t tt = 0;
     if (i < v.P) {
       GeomRec rec;
       tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
-                          cov3D_precomp, rec, stage_sh ? sh_stage + (int)threadIdx.x * sh_rowf : nullptr);
+                          cov3D_precomp, rec);
       radii[(size_t)b * v.P + i] = rec.radius;
       store_geom(&L.geom[(size_t)b * v.P + i], rec);      // the record leaves the registers now ...
       if (tt) {

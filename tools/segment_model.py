@@ -12,10 +12,10 @@ EXPERIMENTS.md round 5 ("tile-segment backward: modelled before building").
 
 Both forms are priced with the costs measured on the shipping kernel (profiles/r03_timeline.txt): a group
 of four rows costs START + BATCH x (16-record batches of its longest row); START = 9.6 us, BATCH = 3.4 us when three
-waves share a SIMD (a 1-batch group takes 13 us, an 8-batch group 37 us).  (B) holds 8 waves per CU (LDS: 4 x 8.7 KB
-of MFMA staging + 9 KB of records + 40 B x PMAX of pair slots per workgroup => two workgroups per CU), so its batches
-are priced at 2/3 of (A)'s (issue-bound share) and its start at the same latency; a workgroup ends with its slowest
-wave, its reduction is priced at 2 us.  Usage: python tools/segment_model.py [azim] [PMAX]"""
+waves share a SIMD (a 1-batch group takes 13 us, an 8-batch group 37 us).  (B)'s workgroups per CU follow from its LDS
+(4 x 8.7 KB of MFMA staging + 48 B per record of the segment + 40 B x PMAX of pair slots, of 160 KB), its batches are
+priced by the issue share of the waves that fit (4 or 8 per CU against (A)'s 12) and its start at the same latency; a
+workgroup ends with its slowest wave, its reduction is priced at 2 us.  Usage: python tools/segment_model.py [azim] [PMAX]"""
 import math
 import os
 import sys
@@ -117,9 +117,15 @@ print(f"    wave time {tA / 1e3:.1f} ms -> perfectly balanced over {slotsA} wave
 wb = sum(sum(w) for w, _, _ in wgs_B)
 nw = sum(len(w) for w, _, _ in wgs_B)
 rb = sum(r for _, r, _ in wgs_B)
-tB_wave = nw * START + wb * BATCH * (2.0 / 3.0)                       # wave time if waves were independent
-wg_time = np.array([START + max(w) * BATCH * (2.0 / 3.0) + 2.0 for w, _, _ in wgs_B])      # workgroup = its slowest wave + reduction
-slotsB = 256 * 2
+# workgroups per CU by LDS: 4 waves x 8.7 KB of MFMA staging + the segment's records (48 B x entries) + 40 B x PMAX pair slots
+seg_entries = max(64, int(PMAX / (pairs_total / entries_total) / 64 + 1) * 64)
+lds_wg = 4 * 8.7 * 1024 + 48 * seg_entries + 40 * PMAX
+per_cu = max(1, int(160 * 1024 // lds_wg))
+share = min(1.0, per_cu * 4 / 12.0)                                   # issue share of a batch relative to (A)'s 3 waves per SIMD
+tB_wave = nw * START + wb * BATCH * share
+wg_time = np.array([START + max(w) * BATCH * share + 2.0 for w, _, _ in wgs_B])      # workgroup = its slowest wave + reduction
+slotsB = 256 * per_cu
+print(f"    LDS per workgroup {lds_wg / 1024:.0f} KB -> {per_cu} workgroup(s) = {4 * per_cu} waves per CU")
 print(f"(B) PMAX {PMAX}: workgroups {len(wgs_B)} ({len(wgs_B) / slotsB:.2f} per workgroup slot), waves {nw}, wave-batches {wb}, "
       f"row-batch efficiency {rb / (4 * wb):.3f}")
 print(f"    wave time {tB_wave / 1e3:.1f} ms; workgroup time (slowest wave + reduction) {wg_time.sum() / 1e3:.1f} ms -> perfectly "
