@@ -88,6 +88,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   __shared__ __attribute__((aligned(16))) float stage_k_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];   // [iteration][pixel lane]
   __shared__ __attribute__((aligned(16))) float stage_w_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];
   __shared__ uint32_t s_ticket;
+  __shared__ __attribute__((aligned(16))) float s_tabA[4][32];      // MFMA operand A of the two moment chains: [l & 3][A1 16 | A2 16]
   if (status->overflow) return;
   // the caller sized the scratch for pair_cap pair rows (hgs_backward*: status->num_pairs, or 16 per entry); a count the
   // device does not confirm writes nothing here and poisons the gradient rows in the reduction (NaN: loud, in bounds)
@@ -98,6 +99,12 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   float* __restrict__ stage_k = stage_k_all[wv];
   float* __restrict__ stage_w = stage_w_all[wv];
   if (threadIdx.x == 0) s_ticket = HGS_BWD_BLOCK_WAVES;      // tickets 0 .. waves - 1: every wave's first group
+  if (threadIdx.x < 128) {
+    const int qs = (int)threadIdx.x >> 5, e = (int)threadIdx.x & 31, t = e & 15;
+    const float u = (float)(t & 3) - 1.5f, w_ = (float)(t >> 2) - 1.5f;
+    s_tabA[qs][e] = e < 16 ? (qs == 0 ? 1.0f : (qs == 1 ? u : (qs == 2 ? w_ : u * u)))
+                           : (qs == 0 ? u * w_ : (qs == 1 ? w_ * w_ : 0.0f));
+  }
   __syncthreads();
   const int j = lane >> 4, i = lane & 15;
   // the work tables are per die: this workgroup draws from those of the die the dispatcher puts it on (Counters::sched)
@@ -112,16 +119,12 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   const float4* __restrict__ recs = reinterpret_cast<const float4*>(recs_all);
   float4* __restrict__ srow = s_rec + j * HGS_ROW_F4;
 
-  // ---- MFMA operand A of the two moment chains: constants of the lane.  Lane l supplies A[q = l & 3] of block l >> 2
-  // (its cell: l >> 4); instruction t: in-cell pixel t.
+  // ---- MFMA operand A of the two moment chains: constants of the lane - lane l supplies A[q = l & 3] of block l >> 2 (its
+  // cell: l >> 4); instruction t: in-cell pixel t.  They live in a 512 B LDS table (s_tabA) and are read four at a time
+  // beside the B operands: as 32 registers per lane they were parked in AGPRs and copied back before every use
+  // (93 v_accvgpr_read per 16-record batch in a kernel that is VALU-issue bound).
   const int qsel = lane & 3;
-  float A1[16], A2[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const float u = (float)(t & 3) - 1.5f, w_ = (float)(t >> 2) - 1.5f;
-    A1[t] = qsel == 0 ? 1.0f : (qsel == 1 ? u : (qsel == 2 ? w_ : u * u));
-    A2[t] = qsel == 0 ? u * w_ : (qsel == 1 ? w_ * w_ : 0.0f);
-  }
+  const float* __restrict__ tabA = s_tabA[qsel];
 
 #ifdef HGS_TIMELINE
   // per group: wall start | end | batches  (into L.keys: free after the sort)
@@ -250,11 +253,8 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       if (!(have && nc >= first)) { T = 1.0f; F = 0.0f; nc = 0; }
     }
 
-    // the MFMA chains of batch b run while the wave evaluates batch b + 1; their results are picked up after that
-    hgs_f32x4 pa1 = {0.f, 0.f, 0.f, 0.f}, pa2 = {0.f, 0.f, 0.f, 0.f}, pa3 = {0.f, 0.f, 0.f, 0.f};
-    float pmx = 0.f, pmy = 0.f, pqa = 0.f, pqb = 0.f, pqc = 0.f, pop = 0.f;      // the lane's record of the pending batch
-    uint32_t pit = 0, ppid = 0;
-    bool pending = false;
+    float pmx = 0.f, pmy = 0.f, pqa = 0.f, pqb = 0.f, pqc = 0.f, pop = 0.f;      // the lane's record of the batch being finished
+    uint32_t ppid = 0;
     // moments -> gradient sums of (this row, record i of the batch), written to the pair's slot
     auto finish = [&](const hgs_f32x4& a1, const hgs_f32x4& a2, const hgs_f32x4& a3, uint32_t it0) {
       if (it0 + (uint32_t)i >= cnt) return;
@@ -297,7 +297,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       gather(le_use, it0 + HGS_RB + (uint32_t)i < cnt, c0, c1, c2);
       if (act == 0ull) {
         // nothing contributes any more (every pixel terminated before): zero pair rows, no evaluation
-        if (pending) { asm volatile("" : "+a"(pa1), "+a"(pa2), "+a"(pa3)); finish(pa1, pa2, pa3, pit); pending = false; }
         if (it0 + (uint32_t)i < cnt) {
           float2* row = reinterpret_cast<float2*>(pair_rows + (size_t)pid_this * HGS_PROW_FLOATS);
           const float2 zero2 = make_float2(0.f, 0.f);
@@ -342,9 +341,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // keep the previous batch's accumulators in AGPRs up to here: read any earlier and the wave
-      // waits for its MFMA chains before evaluating this batch (no overlap)
-      if (pending) { asm volatile("" : "+a"(pa1), "+a"(pa2), "+a"(pa3)); finish(pa1, pa2, pa3, pit); }
       // operand B: lane 16 kk + n reads (iteration n, pixels of row kk): 16 consecutive floats per stage
       hgs_f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
       {
@@ -354,24 +350,28 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         for (int q4 = 0; q4 < 4; ++q4) {
           const float4 bk = *reinterpret_cast<const float4*>(sk + 4 * q4);
           const float4 bw = *reinterpret_cast<const float4*>(sw + 4 * q4);
+          const float4 t1 = *reinterpret_cast<const float4*>(tabA + 4 * q4);
+          const float4 t2 = *reinterpret_cast<const float4*>(tabA + 16 + 4 * q4);
           const float kx[4] = {bk.x, bk.y, bk.z, bk.w};
           const float wx[4] = {bw.x, bw.y, bw.z, bw.w};
+          const float a1x[4] = {t1.x, t1.y, t1.z, t1.w};
+          const float a2x[4] = {t2.x, t2.y, t2.z, t2.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A1[4 * q4 + r], kx[r], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(A2[4 * q4 + r], kx[r], acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1x[r], kx[r], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a2x[r], kx[r], acc2, 0, 0, 0);
             acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(A3[4 * q4 + r], wx[r], acc3, 0, 0, 0);
           }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();                 // the next batch overwrites the stages
-      pa1 = acc1; pa2 = acc2; pa3 = acc3;
-      pmx = mxr; pmy = myr; pqa = qar; pqb = qbr; pqc = qcr; pop = opr;
-      pit = it0; ppid = pid_this;
-      pending = true;
+      // moments -> the batch's pair rows right away: three interleaved chains of 16 x 8 cycles are over a few cycles after
+      // the last issue (the "pending batch" pipeline that picked the results up one batch later dates from the 16x16x4
+      // form, 1536 cycles per chain; it cost 12 AGPRs, 8 VGPRs and their copies in a kernel that is issue-bound)
+      pmx = mxr; pmy = myr; pqa = qar; pqb = qbr; pqc = qcr; pop = opr; ppid = pid_this;
+      finish(acc1, acc2, acc3, it0);
     }
-    if (pending) finish(pa1, pa2, pa3, pit);
 #ifdef HGS_TIMELINE
     if (lane == 0) {
       unsigned long long* o = L.keys + ((size_t)grp * HGS_NXCD + die) * 4;
