@@ -286,7 +286,14 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       const float mxr = c0.x, myr = c0.y, qar = c0.z, qbr = c0.w, qcr = c1.x, opr = c1.y;   // this lane's gathered record
       if (act != 0ull) {
         __builtin_amdgcn_wave_barrier();               // the previous batch's LDS reads are done
-        srow[3 * i + 0] = c0; srow[3 * i + 1] = c1; srow[3 * i + 2] = c2;
+        // PAIRED stage (as in render_fwd.hip, here every field): records 2p and 2p + 1 of the batch share six float4 -
+        //   (mx0 mx1 my0 my1 | qa0 qa1 qb0 qb1 | qc0 qc1 op0 op1 | r0 r1 g0 g1 | b0 b1 d0 d1 | pos0 pos1 - -)
+        // - so that the v_pk_* instructions the compiler forms over two records find their operand pairs in neighbouring
+        // registers (one record per three float4: 4 v_mov per record to shuffle them together)
+        float* pb = reinterpret_cast<float*>(srow + 6 * (i >> 1)) + (i & 1);
+        pb[0] = c0.x; pb[2] = c0.y; pb[4] = c0.z; pb[6] = c0.w;
+        pb[8] = c1.x; pb[10] = c1.y; pb[12] = c1.z; pb[14] = c1.w;
+        pb[16] = c2.x; pb[18] = c2.y; pb[20] = c2.w;
       }
       // the index of the batch after next, then the next batch's records (also when this batch is skipped)
       const uint2 le_use = le_next;
@@ -306,31 +313,19 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // ---- 16 iterations: everything that depends on (pixel, record); T and F are the only carried values
-      // (the LDS reads of record u + HGS_BWD_AHEAD are in flight while record u is evaluated)
-      float4 q0[HGS_BWD_AHEAD], q1[HGS_BWD_AHEAD], q2[HGS_BWD_AHEAD];
-#pragma unroll
-      for (int u = 0; u < HGS_BWD_AHEAD; ++u) { q0[u] = srow[3 * u + 0]; q1[u] = srow[3 * u + 1]; q2[u] = srow[3 * u + 2]; }
-#pragma unroll
-      for (int u = 0; u < HGS_RB; ++u) {
-        const float4 r0 = q0[u % HGS_BWD_AHEAD];    // mx my qa qb
-        const float4 r1 = q1[u % HGS_BWD_AHEAD];    // qc op r g
-        const float4 r2 = q2[u % HGS_BWD_AHEAD];    // b depth - position in the tile list
-        if (u + HGS_BWD_AHEAD < HGS_RB) {
-          q0[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 0]; q1[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 1];
-          q2[u % HGS_BWD_AHEAD] = srow[3 * (u + HGS_BWD_AHEAD) + 2];
-        }
-        __builtin_amdgcn_sched_barrier(0x7f);       // LDS reads stay ahead of the evaluation (the scheduler would sink them to their use)
+      // ---- 16 iterations in 8 pairs: everything that depends on (pixel, record); T and F are the only carried values
+      // (the six LDS reads of pair k + 1 are in flight while pair k is evaluated)
+      auto eval_one = [&](int u, float mx, float my, float qa, float qb, float qc, float op, float cr, float cg, float cb_, float cd,
+                          float pos) {
         // same dx/dy expressions as the forward so skip decisions agree
-        const float dx = r0.x - pxf, dy = r0.y - pyf;
+        const float dx = mx - pxf, dy = my - pyf;
         float G, alpha, m2, m3;
-        const bool keep = hgs_eval_alpha(dx, dy, r0.z, r0.w, r1.x, r1.y, G, alpha, m2, m3);
-        const bool on = keep & (__float_as_uint(r2.w) <= nc);
-        const float am = on ? r1.y * G : 0.0f;    // un-clamped alpha (= op*G), 0 when inactive
+        const bool keep = hgs_eval_alpha(dx, dy, qa, qb, qc, op, G, alpha, m2, m3);
+        const bool on = keep & (__float_as_uint(pos) <= nc);
+        const float am = on ? op * G : 0.0f;      // un-clamped alpha (= op*G), 0 when inactive
         const float a = fminf(HGS_ALPHA_MAX, am);
         const float wgt = a * T;
-        const float S = __builtin_fmaf(r1.z, g0, __builtin_fmaf(r1.w, g1, __builtin_fmaf(r2.x, g2,
-                        __builtin_fmaf(r2.y, gd, ga))));
+        const float S = __builtin_fmaf(cr, g0, __builtin_fmaf(cg, g1, __builtin_fmaf(cb_, g2, __builtin_fmaf(cd, gd, ga))));
         F = __builtin_fmaf(wgt, S, F);
         const float om = 1.0f - a;
         // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
@@ -338,6 +333,23 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         T *= om;
         stage_k[u * HGS_STAGE_STRIDE + lane] = am * dLda;      // k = dL/dG * G
         stage_w[u * HGS_STAGE_STRIDE + lane] = wgt;
+      };
+      float4 P[6], N[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) P[m] = srow[m];
+#pragma unroll
+      for (int u = 0; u < HGS_RB; u += 2) {
+        if (u + 2 < HGS_RB) {
+#pragma unroll
+          for (int m = 0; m < 6; ++m) N[m] = srow[3 * (u + 2) + m];
+        }
+        __builtin_amdgcn_sched_barrier(0x7f);       // LDS reads stay ahead of the evaluation (the scheduler would sink them to their use)
+        eval_one(u, P[0].x, P[0].z, P[1].x, P[1].z, P[2].x, P[2].z, P[3].x, P[3].z, P[4].x, P[4].z, P[5].x);
+        eval_one(u + 1, P[0].y, P[0].w, P[1].y, P[1].w, P[2].y, P[2].w, P[3].y, P[3].w, P[4].y, P[4].w, P[5].y);
+        if (u + 2 < HGS_RB) {
+#pragma unroll
+          for (int m = 0; m < 6; ++m) P[m] = N[m];
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();

@@ -310,36 +310,46 @@ __device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L,
     }
     __builtin_amdgcn_wave_barrier();                 // the previous batch's LDS reads are done
     c1.y = (__float_as_uint(c2.w) == 0xffffffffu) ? 0.0f : c1.y;      // pad record: never blends
-    srow[3 * i + 0] = c0; srow[3 * i + 1] = c1; srow[3 * i + 2] = c2;
+    // PAIRED stage: records 2p and 2p + 1 of the batch share six float4, field by field -
+    //   (mx0 mx1 my0 my1 | qa0 qa1 qb0 qb1 | qc0 qc1 op0 op1 | r0 g0 r1 g1 | b0 d0 b1 d1 | pos0 pos1 - -)
+    // - the geometry fields interleaved ACROSS the two records, the colour fields kept per record: the compiler packs the
+    // alpha arithmetic of two records into v_pk_* instructions (dx0 dx1, ...) and the accumulation of one record's colour
+    // into channel pairs ((C0 C1) += (r g) w, (C2 D) += (b d) w) either way, and with one record per three float4 it first
+    // had to shuffle every geometry operand pair together (7 v_mov per record in a loop of ~28 instructions).
+    {
+      float* pb = reinterpret_cast<float*>(srow + 6 * (i >> 1)) + (i & 1);      // field f of record e: pb[2 f]
+      float* pc = pb + (i & 1);                                                  // colour pair k of record e: pc[..]
+      pb[0] = c0.x; pb[2] = c0.y; pb[4] = c0.z; pb[6] = c0.w;
+      pb[8] = c1.x; pb[10] = c1.y; pc[12] = c1.z; pc[13] = c1.w;
+      pc[16] = c2.x; pc[17] = c2.y; pb[20] = c2.w;
+    }
     c0 = d0; c1 = d1; c2 = d2;
     const uint32_t idx_n = load_idx(it0 + 4 * HGS_RB + (uint32_t)i);
     gather(idx_a, row_on && (it0 + 2 * HGS_RB + (uint32_t)i < len), d0, d1, d2);
     idx_a = idx_b; idx_b = idx_n;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // groups of HGS_FWD_GROUP records; the LDS reads of group k + 1 are in flight while group k is blended
-    float4 ra[HGS_FWD_GROUP], rb[HGS_FWD_GROUP], rc[HGS_FWD_GROUP];
+    // pairs of records; the six LDS reads of pair k + 1 are in flight while pair k is blended
+    float4 P[6], N[6];
 #pragma unroll
-    for (int u = 0; u < HGS_FWD_GROUP; ++u) { ra[u] = srow[3 * u + 0]; rb[u] = srow[3 * u + 1]; rc[u] = srow[3 * u + 2]; }
+    for (int m = 0; m < 6; ++m) P[m] = srow[m];
 #pragma unroll
-    for (int u0 = 0; u0 < HGS_RB; u0 += HGS_FWD_GROUP) {
-      float4 na[HGS_FWD_GROUP], nb[HGS_FWD_GROUP], nc[HGS_FWD_GROUP];
-      if (u0 + HGS_FWD_GROUP < HGS_RB) {
+    for (int u0 = 0; u0 < HGS_RB; u0 += 2) {
+      if (u0 + 2 < HGS_RB) {
 #pragma unroll
-        for (int u = 0; u < HGS_FWD_GROUP; ++u) {
-          na[u] = srow[3 * (u0 + HGS_FWD_GROUP + u) + 0]; nb[u] = srow[3 * (u0 + HGS_FWD_GROUP + u) + 1];
-          nc[u] = srow[3 * (u0 + HGS_FWD_GROUP + u) + 2];
-        }
+        for (int m = 0; m < 6; ++m) N[m] = srow[3 * (u0 + 2) + m];
       }
-      // the machine scheduler would sink those reads to their first use (and expose one LDS round trip per group):
+      // the machine scheduler would sink those reads to their first use (and expose one LDS round trip per pair):
       // LDS instructions may not cross this point, everything else may
       __builtin_amdgcn_sched_barrier(0x7f);
-#pragma unroll
-      for (int u = 0; u < HGS_FWD_GROUP; ++u) blend_one(s, pxf, pyf, ra[u], rb[u], rc[u]);
+      blend_one(s, pxf, pyf, make_float4(P[0].x, P[0].z, P[1].x, P[1].z), make_float4(P[2].x, P[2].z, P[3].x, P[3].y),
+                make_float4(P[4].x, P[4].y, 0.0f, P[5].x));
+      blend_one(s, pxf, pyf, make_float4(P[0].y, P[0].w, P[1].y, P[1].w), make_float4(P[2].y, P[2].w, P[3].z, P[3].w),
+                make_float4(P[4].z, P[4].w, 0.0f, P[5].y));
       __builtin_amdgcn_sched_barrier(0x7f);
-      if (u0 + HGS_FWD_GROUP < HGS_RB) {
+      if (u0 + 2 < HGS_RB) {
 #pragma unroll
-        for (int u = 0; u < HGS_FWD_GROUP; ++u) { ra[u] = na[u]; rb[u] = nb[u]; rc[u] = nc[u]; }
+        for (int m = 0; m < 6; ++m) P[m] = N[m];
       }
     }
   }
