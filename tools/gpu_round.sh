@@ -123,7 +123,7 @@ import json;d=json.load(open('$O/${t}_pmc_traffic.json'));print({k:round(v/1e6,1
 
 mode_timeline() {
   local N=$1
-  (cd $R && LD_PRELOAD=$R/variants/$N/libhgs_rast.so timeout 300 python tools/timeline.py > $O/timeline_$N.txt 2>&1; tail -40 $O/timeline_$N.txt)
+  (cd $R && HGS_LIB=$R/variants/$N/libhgs_rast.so LD_PRELOAD=$R/variants/$N/libhgs_rast.so timeout 300 python tools/timeline.py > $O/timeline_$N.txt 2>&1; tail -40 $O/timeline_$N.txt)
 }
 
 args=()
