@@ -53,13 +53,19 @@ def _worker(rank, world, port, q, pipeline=None, num_views=NUM_VIEWS):
     cams = (cams * 2)[:num_views]
     grads, radii, outs = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
                                                   render_fn=_oracle_render_fn, gather_images=True, pipeline=pipeline)
-    q.put((rank, {k: v.clone() for k, v in grads.items()}, radii.clone(),
-           [(v, c.clone()) for v, c, _, _ in outs]))
+    # (numpy: pickled by value - a tensor travels as a file descriptor the parent may open after this process has gone)
+    q.put((rank, {k: v.numpy().copy() for k, v in grads.items()}, radii.numpy().copy(),
+           [(v, c.numpy().copy()) for v, c, _, _ in outs]))
     dist.barrier()
     try:                      # gloo teardown can race with the peer's exit; results are already out
         dist.destroy_process_group()
     except Exception:
         pass
+
+
+def _from_numpy(r):
+    rank, grads, radii, outs = r
+    return rank, {k: torch.from_numpy(v) for k, v in grads.items()}, torch.from_numpy(radii), [(v, torch.from_numpy(c)) for v, c in outs]
 
 
 def test_shard_views_round_robin():
@@ -95,6 +101,7 @@ def test_pipelined_rounds_equal_the_serial_accumulation_bitwise(world, num_views
     res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
+    res = [_from_numpy(r) for r in res]
     sc, cams, params = _scene_and_cams()
     cams = (cams * 2)[:num_views]
     ref, rref, _ = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
@@ -118,6 +125,7 @@ def test_two_ranks_reproduce_the_serial_accumulation():
     res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
+    res = [_from_numpy(r) for r in res]
     # serial reference = what the single-GPU loop accumulates (GaussianDreamer.py:244-266,385-391)
     sc, cams, params = _scene_and_cams()
     ref, rref, _ = vp.render_views_parallel(cams, params, sc["bg"].double(), 1, _loss_grad,
@@ -145,7 +153,7 @@ def _collective_worker(rank, world, port, q):
     pack[:, -1] = torch.randint(0, 40, (P,), generator=g).float()
     a = vp.allgather_reduce(pack, mode="allgather")
     b = vp.allgather_reduce(pack, mode="scatter")
-    q.put((rank, a.clone(), b.clone()))
+    q.put((rank, a.numpy().copy(), b.numpy().copy()))
     dist.barrier()
     try:
         dist.destroy_process_group()
@@ -166,6 +174,7 @@ def test_scatter_collective_equals_allgather_bitwise(world):
     res = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(60)
+    res = [(rank, torch.from_numpy(a), torch.from_numpy(b)) for rank, a, b in res]
     ref = res[0][1]
     for rank, a, b in res:
         assert torch.equal(a, ref) and torch.equal(b, ref), rank
