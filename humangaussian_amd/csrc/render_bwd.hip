@@ -88,7 +88,8 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   __shared__ __attribute__((aligned(16))) float stage_k_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];   // [iteration][pixel lane]
   __shared__ __attribute__((aligned(16))) float stage_w_all[HGS_BWD_BLOCK_WAVES][HGS_RB * HGS_STAGE_STRIDE];
   __shared__ uint32_t s_ticket;
-  __shared__ __attribute__((aligned(16))) float s_tabA[4][32];      // MFMA operand A of the two moment chains: [l & 3][A1 16 | A2 16]
+  __shared__ __attribute__((aligned(16))) float s_tabA[4][36];      // MFMA operand A of the two moment chains: [l & 3][A1 16 | A2 16 | pad:
+                                                                    // rows 36 floats apart keep the four rows' b128 reads on disjoint banks]
   if (status->overflow) return;
   // the caller sized the scratch for pair_cap pair rows (hgs_backward*: status->num_pairs, or 16 per entry); a count the
   // device does not confirm writes nothing here and poisons the gradient rows in the reduction (NaN: loud, in bounds)

@@ -188,9 +188,13 @@ __device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L,
       tmin = upd ? test_T : tmin;
       last = upd ? __float_as_uint(rc.w) : last;
       // the pixel goes on iff all four rows passed (a skipped record passes with a = 1)
+      // (on the scalar unit: AND of the four rows' masks, replicated to the four rows, used as the select mask directly -
+      //  `(all4 >> (lane & 15)) & 1` cost four v_and and a 64-bit compare per iteration)
       const unsigned long long okm = __ballot(ok);
-      const unsigned long long all4 = okm & (okm >> 16) & (okm >> 32) & (okm >> 48);     // bit px: scalar unit
-      T = ((all4 >> (lane & 15)) & 1ull) ? T * (p01 * q) : 0.0f;
+      const uint32_t ok2 = (uint32_t)okm & (uint32_t)(okm >> 32);          // rows 0 & 2 | rows 1 & 3
+      const uint32_t ok4 = (ok2 & (ok2 >> 16) & 0xffffu) * 0x10001u;       // all four rows, in both halves
+      const bool go = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)ok4 << 32) | ok4);
+      T = go ? T * (p01 * q) : 0.0f;
       ra = na; rb = nb; rc = nc;
     }
   }
