@@ -32,7 +32,7 @@ extern "C" __global__ void hgs_k_pair_reduce_ch(View, Layout, const hgs_status*,
 
 namespace {
 
-// Experiment knobs (tools/abenv.sh) exist only in -DHGS_KNOBS builds; the product library never reads the environment.
+// Experiment knobs (environment variables, rounds 3-4) exist only in -DHGS_KNOBS builds; the product library never reads the environment.
 #ifdef HGS_KNOBS
 inline int hgs_knob(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
 #else

@@ -10,9 +10,9 @@
 //   ---------------------------------           --------------------------------------------
 //   GeomRec  geom[B*P]           64 B each      uint64  keys[C]        (depth_bits<<32 | idx)
 //   uint32   tile_n[B*T]         list length    SortRec recs[C]        48 B, depth-sorted per tile
-//   uint32   tile_start[B*T]     first entry    uint2   cell_list[16C] (record index, pair id), CELL-major per tile
+//   uint32   tile_start[B*T]     first entry    uint2   cell_list[16C] (record index, pair-row id), CELL-major per tile
 //   uint32   tile_order[B*T]     heavy first (+ uint4 tile_rec[B*T]: tile, entries, first entry)
-//                                                   pair ids are ENTRY-major: the pairs of an entry are neighbours
+//                                                   pair-row ids: ENTRY-major (1-2 views) or chunk-cell-major (hgs_rec_tag)
 //   CellInfo cell_info[B*T][16]  the 16 cell    float   cstate[16C/SEGLEN][6][16]  pixel state every HGS_SEGLEN (128) cell-list entries
 //            lists of a tile                    uint4   items_full[16C/SEGLEN] backward work items (full segments)
 //   uint4    items_part[2][16 B*T] backward work items (last, partial segment of every cell list)
@@ -22,7 +22,7 @@
 //   uint32   chunk_sums/base[B*P/256]  entry-id ranges of the 256-Gaussian chunks
 //   Counters ctr                 bump allocators, class histogram, tickets
 //   hgs_status                                  img buffer:  uint32 n_contrib[B][H*W]
-//                                               bwd scratch: float grad_rows[R][12], pair_rows[16R][10]
+//                                               bwd scratch: float grad_rows[R][12], pair_rows[num_pairs (<= 16R)][10]
 //
 // A 16x16 tile is cut into 16 CELLS of 4x4 pixels.  The sort kernel gives every entry a 16-bit cell
 // mask (cellmask.h: the exact ellipse-vs-rectangle test of alpha >= 1/255) and writes, per tile, 16
