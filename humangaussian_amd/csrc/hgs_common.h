@@ -226,8 +226,12 @@ __device__ __forceinline__ bool hgs_eval_alpha(float dx, float dy, float qa, flo
   m3 = qc * dy;
   const float p2 = __builtin_fmaf(dx, m2, m3 * dy);
   G = __builtin_amdgcn_exp2f(p2);
-  alpha = fminf(HGS_ALPHA_MAX, op * G);
-  return (p2 <= 0.0f) && (alpha >= HGS_ALPHA_MIN);
+  const float og = op * G;
+  alpha = fminf(HGS_ALPHA_MAX, og);
+  // (the threshold test on the UN-clamped value: min(0.99, x) >= 1/255 <=> x >= 1/255 for every non-NaN x, and the
+  //  backward - which needs op G, not alpha - saves the clamp in front of its test; render_bwd.hip restates this
+  //  function on float2 with the same operations)
+  return (p2 <= 0.0f) && (og >= HGS_ALPHA_MIN);
 }
 
 // ---- wave-level primitives on DPP (no LDS round trips) ---------------------------------------

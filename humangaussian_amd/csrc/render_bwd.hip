@@ -52,6 +52,7 @@
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hgs_f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -315,25 +316,46 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // ---- 16 iterations in 8 pairs: everything that depends on (pixel, record); T and F are the only carried values
-      // (the six LDS reads of pair k + 1 are in flight while pair k is evaluated)
-      auto eval_one = [&](int u, float mx, float my, float qa, float qb, float qc, float op, float cr, float cg, float cb_, float cd,
-                          float pos) {
-        // same dx/dy expressions as the forward so skip decisions agree
-        const float dx = mx - pxf, dy = my - pyf;
-        float G, alpha, m2, m3;
-        const bool keep = hgs_eval_alpha(dx, dy, qa, qb, qc, op, G, alpha, m2, m3);
-        const bool on = keep & (__float_as_uint(pos) <= nc);
-        const float am = on ? op * G : 0.0f;      // un-clamped alpha (= op*G), 0 when inactive
-        const float a = fminf(HGS_ALPHA_MAX, am);
-        const float wgt = a * T;
-        const float S = __builtin_fmaf(cr, g0, __builtin_fmaf(cg, g1, __builtin_fmaf(cb_, g2, __builtin_fmaf(cd, gd, ga))));
-        F = __builtin_fmaf(wgt, S, F);
-        const float om = 1.0f - a;
+      // (the six LDS reads of pair k + 1 are in flight while pair k is evaluated).  Everything that is not on the T / F
+      // chains is written on float2 (records 2p, 2p + 1): v_pk_add / mul / fma_f32 do two records per issue slot, and
+      // the kernel is issue-bound.  The SAME IEEE operations in the same order as the scalar form (and as the forward's
+      // hgs_eval_alpha: skip decisions must agree): results are bit-identical.
+      auto eval_pair = [&](int u, const float4& P0, const float4& P1, const float4& P2, const float4& P3, const float4& P4,
+                           const float4& P5) {
+        const hgs_f32x2 mx2 = {P0.x, P0.y}, my2 = {P0.z, P0.w}, qa2 = {P1.x, P1.y}, qb2 = {P1.z, P1.w};
+        const hgs_f32x2 qc2 = {P2.x, P2.y}, op2 = {P2.z, P2.w}, cr2 = {P3.x, P3.y}, cg2 = {P3.z, P3.w};
+        const hgs_f32x2 cb2 = {P4.x, P4.y}, cd2 = {P4.z, P4.w};
+        // same dx/dy expressions as the forward
+        const hgs_f32x2 dx2 = mx2 - pxf, dy2 = my2 - pyf;
+        const hgs_f32x2 m2 = __builtin_elementwise_fma(qa2, dx2, qb2 * dy2);
+        const hgs_f32x2 m3 = qc2 * dy2;
+        const hgs_f32x2 p2 = __builtin_elementwise_fma(dx2, m2, m3 * dy2);
+        const hgs_f32x2 G2 = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+        const hgs_f32x2 og2 = op2 * G2;                      // un-clamped alpha
+        const bool on0 = (p2.x <= 0.0f) & (og2.x >= HGS_ALPHA_MIN) & (__float_as_uint(P5.x) <= nc);
+        const bool on1 = (p2.y <= 0.0f) & (og2.y >= HGS_ALPHA_MIN) & (__float_as_uint(P5.y) <= nc);
+        const hgs_f32x2 am2 = {on0 ? og2.x : 0.0f, on1 ? og2.y : 0.0f};      // 0 when inactive
+        const hgs_f32x2 a2 = {fminf(HGS_ALPHA_MAX, am2.x), fminf(HGS_ALPHA_MAX, am2.y)};
+        const hgs_f32x2 om2 = 1.0f - a2;
         // om >= 0.01, so dLda is always finite; inactive pixels are removed through am = 0
-        const float dLda = __builtin_fmaf(T, S, -((fp - F) * __builtin_amdgcn_rcpf(om)));
-        T *= om;
-        stage_k[u * HGS_STAGE_STRIDE + lane] = am * dLda;      // k = dL/dG * G
-        stage_w[u * HGS_STAGE_STRIDE + lane] = wgt;
+        const hgs_f32x2 rc2 = {__builtin_amdgcn_rcpf(om2.x), __builtin_amdgcn_rcpf(om2.y)};
+        const hgs_f32x2 S2 = __builtin_elementwise_fma(cr2, (hgs_f32x2)(g0), __builtin_elementwise_fma(cg2, (hgs_f32x2)(g1),
+                             __builtin_elementwise_fma(cb2, (hgs_f32x2)(g2), __builtin_elementwise_fma(cd2, (hgs_f32x2)(gd), (hgs_f32x2)(ga)))));
+        // the carried chains: T and F, record 2p then 2p + 1
+        const float T1 = T * om2.x;
+        const hgs_f32x2 T2 = {T, T1};
+        const hgs_f32x2 wgt2 = a2 * T2;
+        const float F0 = __builtin_fmaf(wgt2.x, S2.x, F);
+        const float F1 = __builtin_fmaf(wgt2.y, S2.y, F0);
+        const hgs_f32x2 Fn2 = {F0, F1};
+        const hgs_f32x2 dl2 = __builtin_elementwise_fma(T2, S2, -((fp - Fn2) * rc2));
+        const hgs_f32x2 k2 = am2 * dl2;                      // k = dL/dG * G
+        T = T1 * om2.y;
+        F = F1;
+        stage_k[u * HGS_STAGE_STRIDE + lane] = k2.x;
+        stage_k[(u + 1) * HGS_STAGE_STRIDE + lane] = k2.y;
+        stage_w[u * HGS_STAGE_STRIDE + lane] = wgt2.x;
+        stage_w[(u + 1) * HGS_STAGE_STRIDE + lane] = wgt2.y;
       };
       float4 P[6], N[6];
 #pragma unroll
@@ -345,8 +367,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
           for (int m = 0; m < 6; ++m) N[m] = srow[3 * (u + 2) + m];
         }
         __builtin_amdgcn_sched_barrier(0x7f);       // LDS reads stay ahead of the evaluation (the scheduler would sink them to their use)
-        eval_one(u, P[0].x, P[0].z, P[1].x, P[1].z, P[2].x, P[2].z, P[3].x, P[3].z, P[4].x, P[4].z, P[5].x);
-        eval_one(u + 1, P[0].y, P[0].w, P[1].y, P[1].w, P[2].y, P[2].w, P[3].y, P[3].w, P[4].y, P[4].w, P[5].y);
+        eval_pair(u, P[0], P[1], P[2], P[3], P[4], P[5]);
         if (u + 2 < HGS_RB) {
 #pragma unroll
           for (int m = 0; m < 6; ++m) P[m] = N[m];
