@@ -130,8 +130,8 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 
 #ifdef HGS_TIMELINE
   // per group: wall start | end | batches  (into L.keys: free after the sort)
-  unsigned long long tl_w0 = 0;
-  uint32_t tl_nb = 0;
+  unsigned long long tl_w0 = 0, tl_w1 = 0;
+  uint32_t tl_nb = 0, tl_live = 0;
 #endif
   // Persistent workgroups of HGS_BWD_BLOCK_WAVES waves (12: one workgroup per CU, three waves per SIMD).  A die's group
   // table is longest first; its workgroup b (of G)
@@ -157,7 +157,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       grp_next = group_of((uint32_t)__builtin_amdgcn_readfirstlane((int)t_next));
     }
 #ifdef HGS_TIMELINE
-    tl_w0 = wall_clock64(); tl_nb = 0;
+    tl_w0 = wall_clock64(); tl_nb = 0; tl_live = 0;
 #endif
     const uint32_t key = item.x, cnt = have ? item.y : 0u;
     const int g = (int)(key >> 4), c = (int)(key & 15u);
@@ -279,12 +279,14 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       row[4] = make_float2(a3[2], a3[3]);
     };
     for (uint32_t it0 = 0; it0 < maxcnt; it0 += HGS_RB) {
-#ifdef HGS_TIMELINE
-      ++tl_nb;
-#endif
       // does any pixel of any row still contribute at or behind this batch?  (positions: lane 16 j holds the batch's first record)
       const uint32_t bfirst = (uint32_t)__shfl((int)__float_as_uint(c2.w), lane & 48, 64);
       const unsigned long long act = __ballot((it0 < cnt) && (bfirst <= nc));
+#ifdef HGS_TIMELINE
+      if (tl_nb == 0) tl_w1 = wall_clock64() + (act & 1ull) * 0ull;      // (the first batch's records have arrived: end of the group's start chain)
+      ++tl_nb;
+      tl_live += ((act & 0xffffull) != 0) + (((act >> 16) & 0xffffull) != 0) + (((act >> 32) & 0xffffull) != 0) + ((act >> 48) != 0);      // rows with work in this batch
+#endif
       const float mxr = c0.x, myr = c0.y, qar = c0.z, qbr = c0.w, qcr = c1.x, opr = c1.y;   // this lane's gathered record
       if (act != 0ull) {
         __builtin_amdgcn_wave_barrier();               // the previous batch's LDS reads are done
@@ -412,7 +414,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       // (physical SIMD: XCC id and the SE / SH / CU / SIMD fields of HW_ID, for the per-SIMD balance in tools/timeline.py)
       const unsigned long long simd_key = ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) << 16) |
                                           (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff30u);
-      o[0] = tl_w0; o[1] = wall_clock64(); o[2] = tl_nb; o[3] = (unsigned long long)(cnt) | (simd_key << 8) | 1ull << 63;
+      o[0] = tl_w0; o[1] = wall_clock64(); o[2] = tl_nb | ((tl_w1 - tl_w0) << 32); o[3] = (unsigned long long)(cnt) | (simd_key << 8) | ((unsigned long long)tl_live << 32) | 1ull << 63;
     }
 #endif
     grp = grp_next; item = item_next; have = have_next;

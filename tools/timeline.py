@@ -156,7 +156,8 @@ tm = tm[idx].astype(np.int64)
 w0 = tm[:, 0].min()
 st, en = (tm[:, 0] - w0) * TICK_US, (tm[:, 1] - w0) * TICK_US
 dur = en - st
-nb = tm[:, 2]
+nb = tm[:, 2] & 0xffffffff
+chain = (tm[:, 2] >> 32) * TICK_US      # group start -> its first batch's records in registers
 print(f"\n== render_bwd: {len(idx)} groups, span {en.max():.1f} us; group duration us: mean {dur.mean():.2f} p10 {np.percentile(dur, 10):.2f} "
       f"p50 {np.percentile(dur, 50):.2f} p90 {np.percentile(dur, 90):.2f} max {dur.max():.2f}; sum {dur.sum() / 1024:.1f} us per SIMD; batches {int(nb.sum())}")
 span = en.max()
@@ -164,7 +165,9 @@ edges = np.linspace(0, span, 17)
 occ = [float(np.clip(np.minimum(en, b) - np.maximum(st, a), 0, None).sum() / (b - a) / 1024) for a, b in zip(edges[:-1], edges[1:])]
 print("groups in flight per SIMD over time:", " ".join("%.2f" % o for o in occ))
 simd_balance((tm[:, 3] >> 8) & 0xfffff, dur, en, "groups")
-for k in (4, 3, 2, 1):
+live = (tm[:, 3] >> 32) & 0xff             # row-batches with work (a row of a batch whose pixels still contribute)
+print(f"  row-batches with work: {int(live.sum())} of {int(4 * nb.sum())} issued ({live.sum() / (4.0 * nb.sum()):.3f}); groups without any: {int((live == 0).sum())}")
+for k in range(int(nb.max()), 0, -1):
     m = nb == k
     if m.any():
-        print(f"  groups of {k} batches: {int(m.sum())}, dur mean {dur[m].mean():.2f} us (p10 {np.percentile(dur[m], 10):.2f} p90 {np.percentile(dur[m], 90):.2f}), start p50 {np.percentile(st[m], 50):.1f}")
+        print(f"  groups of {k} batches: {int(m.sum())}, dur mean {dur[m].mean():.2f} us (p10 {np.percentile(dur[m], 10):.2f} p90 {np.percentile(dur[m], 90):.2f}), start p10 {np.percentile(st[m], 10):.1f} p50 {np.percentile(st[m], 50):.1f} p90 {np.percentile(st[m], 90):.1f}, end p50 {np.percentile(en[m], 50):.1f} max {en[m].max():.1f}; start chain p50 {np.percentile(chain[m], 50):.2f} p90 {np.percentile(chain[m], 90):.2f}; live row-batches {live[m].mean():.1f} of {4 * k}")
