@@ -97,9 +97,13 @@ def main():
     ap.add_argument("--points", type=int, default=P_POINTS)
     ap.add_argument("--sh-degree", type=int, default=SH_DEGREE)
     ap.add_argument("--variant", default="mid", choices=["mid", "init"])
-    ap.add_argument("--cloud", default="human_obj", choices=["human_obj", "capsule"],
+    ap.add_argument("--cloud", default="auto", choices=["auto", "human_obj", "capsule"],
                     help="where the points come from: area-uniform samples of the reference's load/shapes/human.obj (SURVEY.md 8(d); "
-                         "committed mesh fixture) or the analytic capsule humanoid of rounds 1-4")
+                         "a LOCAL asset built from the reference tree, humangaussian_amd/data) or the analytic capsule humanoid "
+                         "with the same extents; auto = the mesh where the asset exists (the line says which)")
+    ap.add_argument("--uninitialised-means2d", action="store_true",
+                    help="hand the rasterizer an uninitialised means2D leaf (no fill kernel; its values are never read) instead "
+                         "of the zero-filled one the drop-in render() and the reference hand out")
     ap.add_argument("--views", type=int, default=1,
                     help="views per rank per step rendered by ONE batched call (extra measurement when > 1)")
     ap.add_argument("--views-per-rank", type=int, default=1,
@@ -124,6 +128,7 @@ def main():
     from humangaussian_amd import rasterizer as _rast
     from humangaussian_amd import view_parallel as vp
 
+    args.cloud = synth.resolve_cloud_source(args.cloud)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,7 +204,9 @@ def main():
                 color, radii, depth, alpha = rasterize_gaussians_batch(
                     L["means3D"], means2D, L["shs"], None, L["opacities"], L["scales"], L["rotations"], None, self.rs)
             else:
-                means2D = torch.empty_like(L["means3D"]).requires_grad_(True)      # (never read by the kernels: no fill launch)
+                # the zero-filled leaf the reference's render() creates per view (gaussian_renderer/__init__.py:26; here one
+                # fill kernel, without its `+ 0`); --uninitialised-means2d: no kernel at all (the values are never read)
+                means2D = (torch.empty_like if args.uninitialised_means2d else torch.zeros_like)(L["means3D"]).requires_grad_(True)
                 color, radii, depth, alpha = self.rast(
                     means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
                     rotations=L["rotations"])
@@ -218,7 +225,7 @@ def main():
             for j in range(self.seq_views):
                 for t in L.values():
                     t.grad = None
-                means2D = torch.empty_like(L["means3D"]).requires_grad_(True)
+                means2D = (torch.empty_like if args.uninitialised_means2d else torch.zeros_like)(L["means3D"]).requires_grad_(True)
                 color, radii, depth, alpha = self.rasts[j](
                     means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
                     rotations=L["rotations"])
@@ -276,10 +283,61 @@ def main():
             _rast.set_stage_events(None, None)
             return {k: v / nprof * 1e3 for k, v in acc.items()}
 
+    class DropInWorkload:
+        """The reference-shaped call: renderer.render(camera, GaussianModel-like, pipe, bg) on RAW parameters."""
+
+        def __init__(self, P):
+            from humangaussian_amd import renderer
+            self.renderer = renderer
+            cloud = synth.init_cloud(P, 0, "mid", seed=0, source=args.cloud)
+            raw = {"_xyz": cloud.means3D, "_features_dc": cloud.shs[:, :1], "_features_rest": cloud.shs[:, 1:],
+                   "_opacity": torch.logit(cloud.opacities.clamp(1e-6, 1 - 1e-6)), "_scaling": torch.log(cloud.scales),
+                   "_rotation": cloud.rotations}
+            leaves = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in raw.items()}
+            self.leaves = leaves
+
+            class Model:           # gaussian_model.py:95-115
+                active_sh_degree = max_sh_degree = 0
+                get_xyz = property(lambda m: leaves["_xyz"])
+                get_features = property(lambda m: torch.cat((leaves["_features_dc"], leaves["_features_rest"]), dim=1))
+                get_opacity = property(lambda m: torch.sigmoid(leaves["_opacity"]))
+                get_scaling = property(lambda m: torch.exp(leaves["_scaling"]))
+                get_rotation = property(lambda m: torch.nn.functional.normalize(leaves["_rotation"]))
+            self.model = Model()
+
+            class Pipe:
+                convert_SHs_python = compute_cov3D_python = debug = False
+            self.pipe = Pipe()
+            c = camera(0)
+            self.cam = renderer.HostCamera(RES, RES, c.FoVx, c.FoVy, c.world_view_transform.to(dev), c.full_proj_transform.to(dev),
+                                           c.camera_center.to(dev))
+            self.bg = torch.zeros(3, device=dev)
+            g = torch.Generator().manual_seed(1)
+            self.gc = (torch.randn((3, RES, RES), generator=g) * 1e-3).to(dev)
+            self.gd = (torch.randn((1, RES, RES), generator=g) * 1e-3).to(dev)
+            self.ga = (torch.randn((1, RES, RES), generator=g) * 1e-3).to(dev)
+
+        def step(self):
+            for t in self.leaves.values():
+                t.grad = None
+            pkg = self.renderer.render(self.cam, self.model, self.pipe, self.bg)
+            torch.autograd.backward([pkg["render"], pkg["depth_3dgs"], pkg["alpha_3dgs"]], [self.gc, self.gd, self.ga])
+            return pkg["viewspace_points"].grad
+
+        def timed(self, steps, warmup, init_steps=None):
+            for _ in range((args.init_steps if init_steps is None else init_steps) + warmup):
+                self.step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            fence()
+            return time.perf_counter() - t0
+
     class AnimationWorkload:
         """configs[4] (animation.py:384-403,477-484,966-1004): per frame re-anchor the Gaussians on the posed body mesh
-        (hgs_reanchor; the 136 AMASS poses of content/amass_test_17.npz drive a toy articulation of the human.obj mesh,
-        vertices precomputed), render forward-only through `Renderer.render` (incl. its clamp), frame k on rank k mod N;
+        (hgs_reanchor; the 136 AMASS poses of content/amass_test_17.npz - a local asset - or a procedural sway drive a toy
+        articulation of the body mesh, vertices precomputed), render forward-only through `Renderer.render` (incl. its clamp), frame k on rank k mod N;
         with `gather` one asynchronous image all-gather per round of N frames, in flight under the next round's render."""
 
         def __init__(self, P, gather):
@@ -291,7 +349,8 @@ def main():
             driver = an.MotionDriver(verts, device=dev)
             self.num_poses = driver.num_poses
             self.verts = torch.stack([driver.vertices(i) for i in range(driver.num_poses)]).contiguous()
-            self.motion = "content/amass_test_17.npz poses (committed fixture)" if driver.poses is not None else "synthetic sway"
+            self.motion = driver.source
+            self.mesh = synth.human_mesh()[2]
             cloud = synth.init_cloud(P, 0, "mid", seed=0, source=args.cloud)
 
             class Model:
@@ -349,7 +408,7 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": args.init_steps,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"configs[4]: {P} Gaussians anchored on the human.obj mesh, one frame per rank per step: re-anchor "
+                "config": {"workload": f"configs[4]: {P} Gaussians anchored on the {wl.mesh} body mesh, one frame per rank per step: re-anchor "
                                        f"on the posed mesh (hgs_reanchor; motion = {wl.motion}, pose i mod {wl.num_poses}) + no-grad "
                                        "Renderer.render @1024^2 (elevation 0, azimuth i mod 360, radius 2, fovy 50: animation.py:936-1004), "
                                        "frame k on rank k mod N" + ("; ONE asynchronous all-gather of the round's (3,H,W) images per step, "
@@ -451,7 +510,7 @@ def main():
     dom = max(merged_us, key=merged_us.get)
     dom_bytes = merged_bytes[dom]
     achieved = dom_bytes / (merged_us[dom] * 1e-6) / 1e9
-    # HBM-side bytes of the dominant kernel from the committed PMC passes (tools/profile_round.sh), with the commit
+    # HBM-side bytes of the dominant kernel from the committed PMC passes (tools/gpu_round.sh pmc), with the commit
     # they were taken at: the two must be read together (the counters cannot be collected inside this process)
     traffic, traffic_commit = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -479,31 +538,56 @@ def main():
             and P == P_POINTS and sh_degree == SH_DEGREE and args.variant == "mid":
         extra = {}
 
-        def measure(name, wl, steps, warmup, units, note):
-            # two timed repetitions (each K steps behind W warm-up steps); the faster one is reported,
-            # both are recorded: these side measurements share the process with everything before them
-            ts = [wl.timed(steps, warmup), wl.timed(steps, warmup, init_steps=0)]
-            t = min(ts)
+        def pmc_roofline(tag, algorithmic, t_s):
+            """algorithmic bytes of the path over the measured step, and - from the committed PMC pass of the
+            same workload (profiles/<tag>pmc_traffic.json: bytes through the fabric per step, all kernels) - what the
+            memory system actually moved per second"""
+            out = {"bound": "hbm", "algorithmic_bytes": algorithmic, "achieved": algorithmic / t_s / 1e9, "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": algorithmic / t_s / 1e9 / HBM_PEAK_GBS, "traffic": None}
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tag + "pmc_traffic.json")))
+                tr = sum(v for k, v in tj.items() if not k.startswith("_") and isinstance(v, (int, float)))
+                out.update({"traffic": tr, "traffic_commit": tj.get("_commit"), "traffic_over_algorithmic": tr / algorithmic,
+                            "counter_achieved": tr / t_s / 1e9, "counter_frac": tr / t_s / 1e9 / HBM_PEAK_GBS})
+            except Exception:
+                pass
+            return out
+
+        def measure(name, wl, steps, warmup, units, note, roof=None):
+            # three timed repetitions (each K steps behind W warm-up steps); the MEDIAN is reported, all are recorded:
+            # these side measurements share the process with everything before them
+            ts = [wl.timed(steps, warmup), wl.timed(steps, warmup, init_steps=0), wl.timed(steps, warmup, init_steps=0)]
+            t = sorted(ts)[1]
             su = wl.stage_times(10) if hasattr(wl, "stage_times") else None
             extra[name] = {"value": units * steps / t, "unit": "Gaussians/s", "ms_per_step": t / steps * 1e3,
                            "ms_per_step_runs": [x / steps * 1e3 for x in ts],
                            "steps": steps, "warmup": warmup, "init_steps": INIT_STEPS,
-                           "workload": note + f" [the FASTER of two timed runs of {steps} steps; both in ms_per_step_runs]",
+                           "workload": note + f" [the MEDIAN of three timed runs of {steps} steps; all in ms_per_step_runs]",
                            "num_rendered_R": int(_rast._state(dev).max_R), "stage_us": su}
+            if roof is not None:
+                tag, Pn, Mn, Bn = roof
+                extra[name]["roofline"] = pmc_roofline(tag, path_bytes_survey(Pn, Mn, extra[name]["num_rendered_R"], npix, T, Bn),
+                                                       t / steps)
         k8 = max(20, args.steps // 6)
         measure("batched_8_views", Workload(P, sh_degree, "mid", 8, False, 0), k8, max(5, args.warmup // 5), 8 * P,
                 "configs[1] x 8 views batched: the 8 orbit cameras of configs[2] (azim 30+45*i) rendered fwd+bwd by ONE "
-                "hgs_forward_batch / hgs_backward_batch call per step; Gaussians/s = 8 * P / step time")
+                "hgs_forward_batch / hgs_backward_batch call per step; Gaussians/s = 8 * P / step time", roof=("8views_", P, M, 8))
         measure("init_variant", Workload(P, sh_degree, "init", 1, False, 0), max(20, args.steps // 3), max(5, args.warmup // 2),
                 P, "configs[1] with the step-0 cloud (opacity 0.1, isotropic scales, identity rotations: no early termination)")
         measure("forward_only", Workload(P, sh_degree, "mid", 1, True, 0), max(20, args.steps // 3), max(5, args.warmup // 2),
                 P, "configs[4] shape: no-grad forward of one 1024^2 view (animation path), per GPU")
-        measure("animation_frames", AnimationWorkload(P, gather=False), max(20, args.steps // 3), max(5, args.warmup // 2), P,
-                "configs[4]: per frame re-anchor on the posed human.obj mesh (hgs_reanchor, AMASS-driven toy articulation) + no-grad "
+        measure("drop_in_render", DropInWorkload(P), max(20, args.steps // 3), max(5, args.warmup // 2), P,
+                "configs[1] through the drop-in renderer.render() exactly as GaussianDreamer.py:244-266 calls the reference's: a "
+                "GaussianModel-shaped object with RAW parameters (get_* = sigmoid / exp / normalize / cat as gaussian_model.py:95-115, "
+                "un-fused torch kernels with their autograd), the zero-filled viewspace_points leaf, fwd+bwd of one 1024^2 view")
+        anim = AnimationWorkload(P, gather=False)
+        measure("animation_frames", anim, 300, max(5, args.warmup // 2), P,
+                f"configs[4] at its stated size, 300 frames per timed run: per frame re-anchor on the posed {anim.mesh} body mesh "
+                f"(hgs_reanchor; motion = {anim.motion}) + no-grad "
                 "Renderer.render @1024^2, camera and pose change every frame (animation.py:384-403,477-484,966-1004); one GPU: "
                 "`bench.py --forward-only --gpus N` shards the frames")
         measure("config4_500k_sh3", Workload(500_000, 3, "mid", 1, False, 0), max(20, args.steps // 6), max(5, args.warmup // 5),
-                500_000, "configs[3]: 500k Gaussians, SH degree 3, one 1024^2 view, fwd+bwd")
+                500_000, "configs[3]: 500k Gaussians, SH degree 3, one 1024^2 view, fwd+bwd", roof=("cfg3_", 500_000, 16, 1))
 
     # ---------------- CPU baseline: the PyTorch oracle on the host cores (rank 0, N=1): the FULL
     # forward + backward of the same view (every tile), 1 warm-up + median of 3.
@@ -555,7 +639,8 @@ def main():
                                    + (" one after the other (the reference's loop)" if VPR > 1 else "")
                                    + " (elev 10, azim 30+45*view, dist 1.75, fovy 55), "
                                    + ("fwd only" if args.forward_only else "fwd+bwd")
-                                   + "; the step's means2D leaf is uninitialised (its values are never read; the drop-in render() hands out zeros)",
+                                   + ("; the step's means2D leaf is uninitialised (--uninitialised-means2d: its values are never read)"
+                                      if args.uninitialised_means2d else "; means2D is the zero-filled leaf of the reference's render() (one fill per view)"),
                        "cloud": args.cloud,
                        "views_per_step": world * args.views * VPR, "views_per_rank_sequential": VPR, "num_rendered_R": int(R),
                        "host_mode": "sync (one host wait per forward for the device-side status, as upstream)",
@@ -584,6 +669,11 @@ def main():
             "stage_us": stage_us,
             "host": host_info,
             "collective": collective,
+            "multi_gpu": (None if world > 1 else
+                          "this line is N = 1.  No N > 1 value has ever been measured for this repository: gpurun boxes have one GPU; "
+                          "the view-parallel step and the frame-sharded animation leg are covered by gloo world-2/3 tests and by two "
+                          "ranks sharing one device (tests/test_gpu_multirank_one_gpu.py); RCCL itself has not executed. "
+                          "`python bench.py --gpus N` is the command the first multi-GPU node runs"),
             "cpu_baseline": cpu,
             "extra": extra,
         }

@@ -45,8 +45,7 @@ class MeshAnchoredGaussians:
 
 # ------------------------------------------------------------------------------ the motion that drives the frames
 
-_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-# toy skeleton on the committed human mesh (tests/golden/human_mesh.npz: A-pose, z-up, left = +x): SMPL-X joint index,
+# toy skeleton on the body mesh (`synth.human_mesh()`: A-pose, z-up, left = +x): SMPL-X joint index,
 # centre, and the smooth weight of the part that follows the joint.  Parents before children.
 _JOINTS = (
     # name, SMPL-X joint, parent, centre (x, y, z)
@@ -87,19 +86,26 @@ def _rodrigues(a: np.ndarray) -> np.ndarray:
 
 class MotionDriver:
     """Posed body-mesh vertices per frame, DRIVEN BY the reference's demo motion `content/amass_test_17.npz` (136 frames
-    of 55 SMPL-X joint rotations; committed as tests/golden/amass_test_17_poses.npz).  The SMPL-X model files that turn
-    poses into vertices are not in the reference tree, so the angles of nine joints (shoulders, elbows, hips, knees,
-    head) articulate the committed human mesh through smooth part weights instead - a toy skinning that moves the
-    surface the way the real sequence moves its body (amplitude `gain`), which is all the rasterize path sees of it:
-    `xyz` changes every frame, nothing else does (animation.py:384-403).  Frame i uses pose i mod 136
-    (animation.py:311-330).  Without the fixture: a smooth synthetic sway with the same period."""
+    of 55 SMPL-X joint rotations) where the LOCAL asset humangaussian_amd/data/amass_test_17_poses.npz exists (built from
+    the reference tree by data/make_motion.py; AMASS data, not redistributed), by a clip of the caller (`poses_path`: an
+    .npz with `poses` (F, 55, 3)), or by a procedural sway of the same nine joints with the same period (`self.source` says
+    which).  The SMPL-X model files that turn poses into vertices are not in the reference tree, so the angles of nine
+    joints (shoulders, elbows, hips, knees, head) articulate the body mesh through smooth part weights instead - a toy
+    skinning that moves the surface the way the real sequence moves its body (amplitude `gain`), which is all the
+    rasterize path sees of it: `xyz` changes every frame, nothing else does (animation.py:384-403).  Frame i uses pose
+    i mod 136 (animation.py:311-330)."""
 
     def __init__(self, vertices, device="cuda", gain: float = 0.6, poses_path: Optional[str] = None):
         self.device = torch.device(device)
         self.rest = torch.as_tensor(vertices, dtype=torch.float32).to(self.device)
         self.weights = _part_weights(self.rest)
-        path = poses_path or os.path.join(_GOLDEN, "amass_test_17_poses.npz")
+        from . import data
+        path = poses_path or data.MOTION
+        if poses_path and not os.path.exists(poses_path):
+            raise FileNotFoundError(poses_path)
         self.poses = np.load(path)["poses"].astype(np.float64) if os.path.exists(path) else None
+        self.source = ("procedural sway (no motion asset)" if self.poses is None else
+                       (os.path.basename(poses_path) if poses_path else "content/amass_test_17.npz poses (local asset)"))
         self.gain = gain
         self.num_poses = 136 if self.poses is None else int(self.poses.shape[0])
 
@@ -136,11 +142,13 @@ class MotionDriver:
 
 
 def human_mesh_anchors(n: int, seed: int = 0, device="cuda", max_dist: float = 0.004):
-    """The committed human mesh + n Gaussians anchored on it the way animation.py:339-345 anchors a trained avatar: a face,
-    barycentric coordinates, a signed distance along the face normal (area-uniform faces, |dist| <= max_dist).
+    """The body mesh (`synth.human_mesh()`: the reference's human.obj where the local asset exists, the procedural capsule
+    mesh otherwise) + n Gaussians anchored on it the way animation.py:339-345 anchors a trained avatar: a face, barycentric
+    coordinates, a signed distance along the face normal (area-uniform faces, |dist| <= max_dist).
     Returns (vertices (V,3) float32 numpy, MeshAnchoredGaussians)."""
-    m = np.load(os.path.join(_GOLDEN, "human_mesh.npz"))
-    v, f = m["vertices"].astype(np.float64), m["faces"]
+    from . import synth
+    mv, mf, _ = synth.human_mesh()
+    v, f = mv.astype(np.float64), mf
     a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
     area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
     rng = np.random.default_rng(seed)
@@ -148,7 +156,7 @@ def human_mesh_anchors(n: int, seed: int = 0, device="cuda", max_dist: float = 0
     r1, r2 = np.sqrt(rng.uniform(0, 1, n)), rng.uniform(0, 1, n)
     uvw = np.stack([1.0 - r1, r1 * (1.0 - r2), r1 * r2], 1).astype(np.float32)
     dist_ = rng.uniform(-max_dist, max_dist, n).astype(np.float32)
-    return m["vertices"].astype(np.float32), MeshAnchoredGaussians(f, tri.astype(np.int32), uvw, dist_, device=device)
+    return mv, MeshAnchoredGaussians(f, tri.astype(np.int32), uvw, dist_, device=device)
 
 
 # ------------------------------------------------------------------------------ one frame, and the sharded loop
@@ -196,6 +204,11 @@ def render_frames_parallel(frames: Sequence[int], render_frame_fn: Callable[[int
         for k in shard_views(len(frames), rank, world):
             yield frames[k], render_frame_fn(frames[k])
         return
+    if len(frames) < world:
+        # checked on EVERY rank before the first collective (the same frame list and world size everywhere): a rank
+        # without any frame could not size its slab, and raising only there would leave the others inside the all-gather
+        raise ValueError(f"render_frames_parallel(gather=True): {len(frames)} frames for {world} ranks - pass at least "
+                         f"one frame per rank, or gather=False")
     rounds = (len(frames) + world - 1) // world
     pending, shape_like = None, None
 
@@ -211,9 +224,7 @@ def render_frames_parallel(frames: Sequence[int], render_frame_fn: Callable[[int
             img = render_frame_fn(frames[k]).contiguous()
             shape_like = img
         else:                                                 # ragged last round: a zero frame nobody yields
-            if shape_like is None:
-                raise ValueError("fewer frames than ranks: a rank without any frame cannot size its slab; pass >= world frames")
-            img = torch.zeros_like(shape_like)
+            img = torch.zeros_like(shape_like)                #  (len(frames) >= world: this rank rendered round 0)
         started = _Gather(img, group, async_op=True)
         if pending is not None:
             yield from drain(j - 1, pending)

@@ -7,6 +7,7 @@
 //   backward work items) -> render_fwd (one workgroup per tile, heavy first)
 // Backward: render_bwd (persistent waves, four cell-list segments each) -> pair_reduce -> preprocess_bwd.
 #include "hgs_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
@@ -406,8 +407,9 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
   if (entry_capacity > HGS_MAX_ENTRY_CAPACITY) return HGS_EINVAL;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int ncu = cu_count(stream);
+  // (the gradient bit belongs to the backward: masked out, so that no forward kernel can ever branch on it)
   const View v = make_view(s, B, P, M, entry_capacity, max_tile_entries_hint > 0 ? max_tile_entries_hint : 0,
-                           activation_flags);
+                           activation_flags & 7);
   const Layout L = make_layout(geom, bin, img, B, P, v.H, v.W, entry_capacity);
   hgs_status* status_dev =
       reinterpret_cast<hgs_status*>(static_cast<char*>(geom) + carve_geom(B, P, v.H, v.W).status);
@@ -621,14 +623,28 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   // for what does not fit or when the limit cannot be raised.
   bool vpar_ok = v.B >= HGS_PRE_BWD_VPAR_MIN_VIEWS && v.B <= (deg >= 2 ? 8 : 16) && lds_p <= 160 * 1024;
   if (vpar_ok && lds_p > 65536) {
-    const void* kfn = deg == 0 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p0)
-                    : deg == 1 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p1)
-                    : deg == 2 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p2)
-                               : reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p3);
-    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) {
-      (void)hipGetLastError();
-      vpar_ok = false;
+    // the attribute is raised ONCE per (device, kernel) to the CU's whole LDS and remembered: a driver call per backward
+    // was host time on the hot path; a refusal is remembered too (and said once on stderr): the loop form then serves
+    static std::atomic<int> lds_raised[64][4];          // 0: not tried, 1: raised to 160 KB, -1: refused
+    int dev = 0;
+    if (hipStreamGetDevice(stream, &dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int st = lds_raised[dev][deg].load(std::memory_order_relaxed);
+    if (st == 0) {
+      const void* kfn = deg == 0 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p0)
+                      : deg == 1 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p1)
+                      : deg == 2 ? reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p2)
+                                 : reinterpret_cast<const void*>(hgs_k_preprocess_bwd_p3);
+      if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) {
+        st = 1;
+      } else {
+        (void)hipGetLastError();
+        st = -1;
+        fprintf(stderr, "libhgs_rast: cannot raise the dynamic LDS limit of hgs_k_preprocess_bwd_p%d on device %d: "
+                        "batches that need more than 64 KB take the (slower) loop form\n", deg, dev);
+      }
+      lds_raised[dev][deg].store(st, std::memory_order_relaxed);
     }
+    if (st < 0) vpar_ok = false;
   }
   const int mode = v.B == 1 ? 1 : (vpar_ok ? 2 : 0);
   const size_t lds_s = hgs_pre_bwd_stage_bytes(M, deg, shs != nullptr && dL_dshs != nullptr);      // (<= 53 KB)

@@ -527,10 +527,7 @@ __device__ __forceinline__ void gather_records_single(const View& v, const Layou
 #define HGS_TG(i)
 #endif
   // ---- sweep 1: records + masks; per chunk the packed per-cell counts (tab[ch][0..3]) and its pairs (tab[ch][16])
-#ifndef HGS_SORT_GU
-#define HGS_SORT_GU 2
-#endif
-  constexpr int GU = HGS_SORT_GU;
+  constexpr int GU = 2;            // gathers per thread in flight
   for (uint32_t kb0 = 0; kb0 < n; kb0 += (uint32_t)nt * GU) {      // (wave-uniform trip count: wave scans inside)
     const uint32_t kb = kb0 + threadIdx.x;
     uint32_t idxv[GU];
@@ -692,207 +689,7 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* keys, uint32_t 
   }
 }
 
-// ---- register / wave-shuffle / LDS hybrid of the same network -------------------------
-// Thread t owns E consecutive keys (indices t*E .. t*E+E-1) in REGISTERS.  A comparator
-// of stride < E stays inside the thread; stride < 64*E pairs lanes of one wave and goes
-// through DPP / permlane-swap lane exchanges (no LDS, no barrier); only strides >= 64*E (a
-// handful of the ~50-80 stages) exchange through LDS with barriers.  Padding is explicit (+inf keys).
 typedef unsigned long long u64;
-
-// Lane exchange i <-> i ^ M inside a wave WITHOUT the LDS pipe: every mask the network needs
-// (xor strides 1..32 and the mirror masks 3, 7, 15, 31, 63) maps to DPP controls or to gfx950's
-// v_permlane16_swap / v_permlane32_swap.  (The first version used ds_bpermute for all of them: a
-// dependent LDS round trip per stage, ~600 cycles per stage on the heaviest tile.)
-typedef unsigned hgs_u32x2 __attribute__((ext_vector_type(2)));
-
-#ifndef HGS_SORT_XCHG
-#define HGS_SORT_XCHG 0      // 0: ds_bpermute for every mask, 1: DPP inside a 16-lane row + ds_bpermute across rows,
-#endif                       // 2: DPP + v_permlane16/32_swap for every mask.  Measured: see DESIGN.md section 4.
-
-template <int M>
-__device__ __forceinline__ uint32_t xchg_xor32(uint32_t x, int lane) {
-  const int xi = (int)x;
-  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_QUAD_PERM(1, 0, 3, 2), 0xf, 0xf, false);
-  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_QUAD_PERM(2, 3, 0, 1), 0xf, 0xf, false);
-  else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_QUAD_PERM(3, 2, 1, 0), 0xf, 0xf, false);
-  else if constexpr (M == 4) {
-    // banks 0 and 2 of every row read 4 lanes up, banks 1 and 3 read 4 lanes down (bank masks)
-    const int t = __builtin_amdgcn_update_dpp(xi, xi, 0x100 + 4 /* row_shl:4 */, 0xf, 0x5, false);
-    return (uint32_t)__builtin_amdgcn_update_dpp(t, xi, HGS_DPP_ROW_SHR(4), 0xf, 0xa, false);
-  } else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
-  else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_ROW_ROR(8), 0xf, 0xf, false);
-  else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(xi, xi, HGS_DPP_ROW_MIRROR, 0xf, 0xf, false);
-  else if constexpr (M == 16) {
-    // v_permlane16_swap: odd rows of the first operand <-> even rows of the second
-    const hgs_u32x2 s2 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-    return (lane & 16) ? s2.x : s2.y;
-  } else if constexpr (M == 32) {
-    // v_permlane32_swap: upper half of the first operand <-> lower half of the second
-    const hgs_u32x2 s2 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return (lane & 32) ? s2.x : s2.y;
-  } else if constexpr (M == 31) return xchg_xor32<16>(xchg_xor32<15>(x, lane), lane);
-  else {
-    static_assert(M == 63, "unsupported lane mask");
-    return xchg_xor32<32>(xchg_xor32<16>(xchg_xor32<15>(x, lane), lane), lane);
-  }
-}
-
-template <int M>
-__device__ __forceinline__ u64 xchg_xor64(u64 v, int lane) {
-  const uint32_t lo = xchg_xor32<M>((uint32_t)v, lane);
-  const uint32_t hi = xchg_xor32<M>((uint32_t)(v >> 32), lane);
-  return ((u64)hi << 32) | lo;
-}
-
-template <int E>
-__device__ __forceinline__ void reg_stage_xor(u64 (&k)[E], int j) {      // j < E, power of 2
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if ((e & j) == 0) {
-      const u64 a = k[e], c = k[e | j];
-      k[e] = a < c ? a : c;
-      k[e | j] = a < c ? c : a;
-    }
-  }
-}
-
-template <int E>
-__device__ __forceinline__ void reg_stage_mirror(u64 (&k)[E], int kk) {   // kk <= E
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if ((e & (kk >> 1)) == 0) {
-      const int o = e ^ (kk - 1);
-      const u64 a = k[e], c = k[o];
-      k[e] = a < c ? a : c;
-      k[o] = a < c ? c : a;
-    }
-  }
-}
-
-// One stage whose partner lives in another lane of the same wave (lane ^ lane_mask).  Only the
-// exchange differs between the masks; the compare/select code behind it is shared (a switch
-// over whole stages tripled the kernel's code size and cost 10 us in instruction fetch).
-template <int E, int M>
-__device__ __forceinline__ void xchg_all(const u64 (&src)[E], u64 (&o)[E], int lane) {
-#pragma unroll
-  for (int e = 0; e < E; ++e) o[e] = xchg_xor64<M>(src[e], lane);
-}
-
-template <int E>
-__device__ __forceinline__ void lane_stage(u64 (&k)[E], int lane_mask, bool mirror, bool keep_min) {
-  const int lane = (int)threadIdx.x & 63;
-  u64 src[E], o[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) src[e] = mirror ? k[E - 1 - e] : k[e];
-#if HGS_SORT_XCHG == 0
-  {
-    const int addr = (lane ^ lane_mask) << 2;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)src[e]);
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(src[e] >> 32));
-      o[e] = ((u64)hi << 32) | lo;
-    }
-  }
-#else
-  switch (lane_mask) {                     // wave-uniform
-    case 1: xchg_all<E, 1>(src, o, lane); break;
-    case 2: xchg_all<E, 2>(src, o, lane); break;
-    case 3: xchg_all<E, 3>(src, o, lane); break;
-    case 4: xchg_all<E, 4>(src, o, lane); break;
-    case 7: xchg_all<E, 7>(src, o, lane); break;
-    case 8: xchg_all<E, 8>(src, o, lane); break;
-    case 15: xchg_all<E, 15>(src, o, lane); break;
-#if HGS_SORT_XCHG == 2
-    case 16: xchg_all<E, 16>(src, o, lane); break;
-    case 31: xchg_all<E, 31>(src, o, lane); break;
-    case 32: xchg_all<E, 32>(src, o, lane); break;
-    default: xchg_all<E, 63>(src, o, lane); break;
-#else
-    default: {                             // across 16-lane rows: one ds_bpermute pair per key
-      const int addr = (lane ^ lane_mask) << 2;
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)src[e]);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(src[e] >> 32));
-        o[e] = ((u64)hi << 32) | lo;
-      }
-    }
-#endif
-  }
-#endif
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const u64 a = k[e], c = o[e];
-    const u64 mn = a < c ? a : c, mx = a < c ? c : a;
-    k[e] = keep_min ? mn : mx;
-  }
-}
-
-// one stage whose partner lives in another wave: through LDS
-template <int E>
-__device__ __forceinline__ void lds_stage(u64 (&k)[E], u64* lds, uint32_t base, uint32_t xmask,
-                                          bool keep_min) {
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < E; ++e) lds[base + e] = k[e];
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const u64 a = k[e], c = lds[(base + e) ^ xmask];
-    const u64 mn = a < c ? a : c, mx = a < c ? c : a;
-    k[e] = keep_min ? mn : mx;
-  }
-}
-
-// one LDS stage for a wave that holds only padding: it must keep the barrier count of the others
-__device__ __forceinline__ void lds_stage_idle() {
-  __syncthreads();
-  __syncthreads();
-}
-
-template <int E, int NT>
-__device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad) {
-  const uint32_t base = threadIdx.x * E;
-  // Waves whose key slots all lie beyond npad hold +inf padding only; no comparator ever changes
-  // them, so they skip the network and just keep the barrier count.  (Device timestamps showed
-  // the kernel issue-bound with every tile running all of its 8 waves through every stage: 762
-  // tiles, most of them far shorter than 512 * E keys.)  Wave-uniform: npad and 64 E are powers
-  // of two.
-  const bool active = base < npad;
-  for (uint32_t kk = 2; kk <= npad; kk <<= 1) {
-    // --- mirror stage of span kk: index i pairs with i ^ (kk-1)
-    if (kk <= (uint32_t)E) {
-      if (active) {
-        if (kk == 2) reg_stage_mirror<E>(k, 2);
-        else if (kk == 4) { if (E >= 4) reg_stage_mirror<E>(k, 4); }
-        else if (kk == 8) { if (E >= 8) reg_stage_mirror<E>(k, 8); }
-        else if (kk == 16) { if (E >= 16) reg_stage_mirror<E>(k, 16); }
-      }
-    } else {
-      const bool keep_min = (base & (kk >> 1)) == 0;
-      if (kk <= 64u * E) { if (active) lane_stage<E>(k, (int)(kk / E - 1), true, keep_min); }
-      else if (active) lds_stage<E>(k, lds, base, kk - 1, keep_min);
-      else lds_stage_idle();
-    }
-    // --- xor stages j = kk/4 .. 1
-    for (uint32_t j = kk >> 2; j > 0; j >>= 1) {
-      if (j < (uint32_t)E) {
-        if (active) {
-          if (j == 1) reg_stage_xor<E>(k, 1);
-          else if (j == 2) { if (E > 2) reg_stage_xor<E>(k, 2); }
-          else if (j == 4) { if (E > 4) reg_stage_xor<E>(k, 4); }
-          else if (j == 8) { if (E > 8) reg_stage_xor<E>(k, 8); }
-        }
-      } else {
-        const bool keep_min = (base & j) == 0;
-        if (j < 64u * E) { if (active) lane_stage<E>(k, (int)(j / E), false, keep_min); }
-        else if (active) lds_stage<E>(k, lds, base, j, keep_min);
-        else lds_stage_idle();
-      }
-    }
-  }
-}
 
 }  // namespace
 
@@ -923,18 +720,9 @@ __device__ __forceinline__ void hybrid_sort(u64 (&k)[E], u64* lds, uint32_t npad
 #define HGS_RANK_NB_MAX 2048
 // 256 threads: three workgroups per CU by LDS (45 KB each) are three waves per SIMD, which leaves a wave 168 VGPRs for
 // up to 16 keys + their ranks + the gathers in flight.  A typical tile (~440 entries) is two keys per thread.
-#ifndef HGS_SORT_NT
 #define HGS_SORT_NT 256
-#endif
-#ifndef HGS_SORT_WAVES_PER_EU
 #define HGS_SORT_WAVES_PER_EU 3
-#endif
-#ifndef HGS_RANK_PRIO
-#define HGS_RANK_PRIO 0
-#endif
-#ifndef HGS_RANK_GU
 #define HGS_RANK_GU 2                  // geometry gathers per thread and round (16 registers each); two rounds are in flight
-#endif
 
 namespace {
 
@@ -1342,15 +1130,12 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
   // gathers out BEFORE the sort; longer ones stream the keys per phase and start the gathers behind the sort: their
   // many rounds amortise one exposed round trip.
   bool degenerate;
-#ifndef HGS_RANK_REG_MAXE
-#define HGS_RANK_REG_MAXE 8
-#endif
-  const bool early = n <= (uint32_t)HGS_RANK_REG_MAXE * NT;
+  const bool early = n <= 8u * NT;
   if (early) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) HGS_RANK_ISSUE(A, u, keyp[u]);
     if (n <= 2u * NT) degenerate = rank_keys<2, NT>(L, start, n, NB, keyp, pairs, R);
-    else if (n <= 4u * NT || HGS_RANK_REG_MAXE < 8) degenerate = rank_keys<4, NT>(L, start, n, NB, keyp, pairs, R);
+    else if (n <= 4u * NT) degenerate = rank_keys<4, NT>(L, start, n, NB, keyp, pairs, R);
     else degenerate = rank_keys<8, NT>(L, start, n, NB, keyp, pairs, R);
   } else {
     degenerate = rank_keys_stream<NT>(L, start, n, NB, pairs, R);
@@ -1450,14 +1235,7 @@ __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, c
 #endif
     bool degenerate;
     unsigned long long tp[4] = {0, 0, 0, 0};
-#if HGS_RANK_PRIO
-    // the kernel ends with its longest list: those workgroups win the issue arbitration against their co-residents
-    if (n > (uint32_t)HGS_RANK_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
     rank_sort_tile<NT, CH>(v, L, b, g, start, n, pairs, R, S, degenerate, tp);
-#if HGS_RANK_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef HGS_TIMELINE
     if (threadIdx.x == 0 && b < HGS_TL_SLOTS) {          // per tile (position in tile_order), wave 0: kernel ids 5 and 2
       const unsigned long long tpe = wall_clock64();

@@ -50,12 +50,8 @@
 #define HGS_RB 16              // records a row stages per batch (= lanes of a row)
 #define HGS_ROW_F4 (HGS_RB * 3 + 1)   // float4 per staged row: 16 records of 48 B + 16 B, so that the four rows of a wave
                                // (which read four DIFFERENT records per ds_read_b128) sit on different LDS banks
-#ifndef HGS_BWD_BLOCK_WAVES
 #define HGS_BWD_BLOCK_WAVES 12 // waves per workgroup of the blend backward: they share one LDS ticket for the workgroup's groups
-#endif
-#ifndef HGS_SEGLEN
 #define HGS_SEGLEN 128         // cell-list entries per backward work item; the forward stores the pixel state
-#endif
                                // of a cell at every multiple of this
 #define HGS_PAIRS_PER_ENTRY 16 // capacity of the pair arrays per entry of capacity (worst case: every cell)
 #define HGS_NEAR_Z 0.2f
@@ -63,9 +59,8 @@
 #define HGS_ALPHA_MAX 0.99f
 #define HGS_T_EPS 0.0001f
 #define HGS_CSTATE_FLOATS (6 * 16)             // T, C0, C1, C2, D, W for the 16 pixels of a cell
-#ifndef HGS_ROW_FLOATS
-#define HGS_ROW_FLOATS 12                       // gradient row per entry / per (entry, cell) pair (10 used); 64 B rows
-#endif                                          // (whole ECC granules per scattered store) measured slower: the rows are bandwidth
+#define HGS_ROW_FLOATS 12                       // gradient row per entry (10 used); 64 B rows (whole ECC granules per
+                                                // scattered store) measured slower: the rows are bandwidth
 #define HGS_GROW_F4 (HGS_ROW_FLOATS / 4)          // float4 per gradient row
 #define HGS_PROW_FLOATS 10                      // (entry, cell) pair row: the ten sums, packed (40 B: a sixth less pair traffic than 48 B)
 #define HGS_PROW_F2 (HGS_PROW_FLOATS / 2)         // float2 per pair row

@@ -215,13 +215,17 @@ hgs_k_knn_search(int P, const KnnGrid* __restrict__ Gp, const uint32_t* __restri
     // every point NOT yet seen lies outside the block [c - r, c + r]^3: at least `reach` away (conservative by 1e-3 h: the
     // cell of a point is floor((x - o) / h) in fp32, up to 2.4e-4 cells from the ideal boundary on a 4096-cell axis)
     if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == gx - 1 && y1 == gy - 1 && z1 == gz - 1) break;      // the whole grid
+    // (distances to the block's faces in GRID-RELATIVE coordinates: me - origin is the subtraction the cell assignment
+    //  itself makes; `origin + k h` in absolute coordinates rounds at ulp(|origin|) / 2, which for a cloud translated
+    //  far from the world origin exceeds the 1e-3 h margin - ADVICE r5)
+    const float rx = me.x - G.ox, ry = me.y - G.oy, rz = me.z - G.oz;
     float reach = big;
-    if (cx - r > 0) reach = fminf(reach, me.x - (G.ox + (float)(cx - r) * G.h));
-    if (cx + r < gx - 1) reach = fminf(reach, (G.ox + (float)(cx + r + 1) * G.h) - me.x);
-    if (cy - r > 0) reach = fminf(reach, me.y - (G.oy + (float)(cy - r) * G.h));
-    if (cy + r < gy - 1) reach = fminf(reach, (G.oy + (float)(cy + r + 1) * G.h) - me.y);
-    if (cz - r > 0) reach = fminf(reach, me.z - (G.oz + (float)(cz - r) * G.h));
-    if (cz + r < gz - 1) reach = fminf(reach, (G.oz + (float)(cz + r + 1) * G.h) - me.z);
+    if (cx - r > 0) reach = fminf(reach, rx - (float)(cx - r) * G.h);
+    if (cx + r < gx - 1) reach = fminf(reach, (float)(cx + r + 1) * G.h - rx);
+    if (cy - r > 0) reach = fminf(reach, ry - (float)(cy - r) * G.h);
+    if (cy + r < gy - 1) reach = fminf(reach, (float)(cy + r + 1) * G.h - ry);
+    if (cz - r > 0) reach = fminf(reach, rz - (float)(cz - r) * G.h);
+    if (cz + r < gz - 1) reach = fminf(reach, (float)(cz + r + 1) * G.h - rz);
     reach = fmaxf(reach - 1e-3f * G.h, 0.0f);
     if (b2 <= reach * reach) break;
   }

@@ -43,12 +43,6 @@
 // This file is its own translation unit (it compiles in parallel with api.hip; same flags).
 #include "hgs_common.h"
 
-#ifndef HGS_BWD_AHEAD
-#define HGS_BWD_AHEAD 1                // records whose LDS reads run ahead of the evaluation
-#endif
-#ifndef HGS_BWD_SNAKE
-#define HGS_BWD_SNAKE 1                // odd rounds of the persistent waves run through the group table backwards
-#endif
 #define HGS_STAGE_STRIDE 68              // floats per staged column: 64 pixels + 4 (bank spread)
 
 typedef float hgs_f32x4 __attribute__((ext_vector_type(4)));
@@ -142,7 +136,7 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
   // A device-wide ticket - one device-scope atomic per group on ONE address - serialised at the memory side of the
   // fabric: ~10 ns each, 110 us per view.)
   auto group_of = [&](uint32_t tk) {
-    return tk * nlb + ((HGS_BWD_SNAKE && (tk & 1u)) ? nlb - 1u - lb : lb);
+    return tk * nlb + ((tk & 1u) ? nlb - 1u - lb : lb);      // (odd rounds run through the group table backwards)
   };
   // the item of the NEXT group is fetched while this one is processed (a group's start is a chain of dependent
   // loads - item, cell list, records - at ~2 us each, and a view has more than one group per wave)
@@ -516,9 +510,6 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
     float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
     dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
     dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
-#if HGS_GROW_F4 > 3
-    dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
   }
 }
 
@@ -654,9 +645,6 @@ hgs_k_pair_reduce_ch(View v, Layout L, const hgs_status* __restrict__ status, co
       float4* dst = reinterpret_cast<float4*>(grad_rows + (size_t)entry * HGS_ROW_FLOATS);
       dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y); dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
       dst[2] = make_float4(s4.x, s4.y, 0.0f, 0.0f);
-#if HGS_GROW_F4 > 3
-      dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
     }
   }
 }

@@ -66,13 +66,8 @@ __device__ __forceinline__ void blend_one(PixState& s, float pxf, float pyf, con
 
 }  // namespace
 
-#ifndef HGS_FWD_C4
 #define HGS_FWD_C4 4            // length classes 0 .. HGS_FWD_C4 - 1 (>= 13 batches of 16 records) are walked four records at a time
-#endif
 typedef unsigned hgs_u32x2 __attribute__((ext_vector_type(2)));
-#ifndef HGS_FWD_GROUP
-#define HGS_FWD_GROUP 2          // records of a batch whose LDS reads are issued together (one group ahead of the blend)
-#endif
 
 // ---- LONG cell lists (length classes < HGS_FWD_C4: more than 192 records): ONE cell per wave, FOUR RECORDS per
 // iteration.  A wave issues one instruction per 4 cycles at best, so a 400-record list walked one record at a time

@@ -2,9 +2,10 @@
 
 * `human_points`     - area-uniform samples on the reference's `load/shapes/human.obj`, normalised as
   `threestudio/utils/poser.py:337-357` (1.20 x 0.30 x 1.56, z-up, area 1.51): the cloud SURVEY.md 8(d)
-  prescribes, standing in for `pcb()` (`threestudio/systems/GaussianDreamer.py:220-232`); the mesh is a
-  committed fixture (tests/golden/human_mesh.npz).
-* `humanoid_points`  - the same extents as an analytic capsule humanoid (rounds 1-4; source="capsule").
+  prescribes, standing in for `pcb()` (`threestudio/systems/GaussianDreamer.py:220-232`); the mesh is a LOCAL
+  asset (humangaussian_amd/data/human_mesh.npz, built from the reference tree where it exists, not redistributed).
+* `humanoid_points`  - the same extents as an analytic capsule humanoid (source="capsule": the fallback where the
+  asset is missing); `humanoid_mesh` - the same primitives as a triangle mesh (the animation leg's fallback).
 * `init_cloud`       - Gaussian parameters as `GaussianModel.create_from_pcd` makes them
   (`gaussiansplatting/scene/gaussian_model.py:124-147`: isotropic scale from the mean 3-NN
   distance, opacity 0.1, identity rotation, colour 0.5), or a randomised "mid-training"
@@ -78,19 +79,62 @@ def humanoid_points(n: int, seed: int = 0) -> np.ndarray:
     return pts.astype(np.float32)
 
 
-_HUMAN_MESH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "human_mesh.npz")
+def humanoid_mesh(around: int = 24, along: int = 16):
+    """The capsule humanoid of `humanoid_points` as a closed-enough triangle mesh (tubes of elliptic cross-section, a
+    lat-long ellipsoid for the head): (vertices (V,3) float32, faces (F,3) int32).  The animation leg's body mesh where the
+    reference's human.obj asset is missing - same extents, z-up, same joint centres for `animation.MotionDriver`."""
+    tubes = [((-0.09, 0.0, -0.78), (-0.09, 0.0, -0.02), (0.065, 0.065)), ((0.09, 0.0, -0.78), (0.09, 0.0, -0.02), (0.065, 0.065)),
+             ((0.0, 0.0, -0.02), (0.0, 0.0, 0.53), (0.16, 0.10)),
+             ((0.17, 0.0, 0.48), (0.60, 0.0, 0.42), (0.04, 0.04)), ((-0.17, 0.0, 0.48), (-0.60, 0.0, 0.42), (0.04, 0.04))]
+    V, F = [], []
+
+    def grid(pts, rows, cols, wrap):               # pts: (rows, cols, 3) -> quads split into two triangles
+        base = sum(len(v) for v in V)
+        V.append(pts.reshape(-1, 3))
+        for r in range(rows - 1):
+            for c in range(cols if wrap else cols - 1):
+                i0, i1 = base + r * cols + c, base + r * cols + (c + 1) % cols
+                j0, j1 = i0 + cols, i1 + cols
+                F.append((i0, i1, j1)); F.append((i0, j1, j0))
+
+    th = np.linspace(0.0, 2.0 * math.pi, around, endpoint=False)
+    for a, b, r in tubes:
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        axis = (b - a) / np.linalg.norm(b - a)
+        e1 = np.cross(axis, [0.0, 1.0, 0.0]); e1 /= np.linalg.norm(e1)
+        e2 = np.cross(axis, e1)
+        u = np.linspace(0.0, 1.0, along)
+        ring = r[0] * np.cos(th)[:, None] * e1[None] + r[1] * np.sin(th)[:, None] * e2[None]
+        grid(a[None, None] + u[:, None, None] * (b - a)[None, None] + ring[None], along, around, True)
+    ph = np.linspace(0.02, math.pi - 0.02, along)
+    head = np.stack([0.10 * np.sin(ph)[:, None] * np.cos(th)[None], 0.10 * np.sin(ph)[:, None] * np.sin(th)[None],
+                     0.12 * np.cos(ph)[:, None] * np.ones_like(th)[None]], -1) + np.array([0.0, 0.0, 0.66])
+    grid(head, along, around, True)
+    return np.concatenate(V, 0).astype(np.float32), np.asarray(F, np.int32)
+
+
+def human_mesh():
+    """(vertices (V,3) float32, faces (F,3) int32, label): the reference's normalised human.obj where the local asset
+    exists (humangaussian_amd/data), else the procedural capsule mesh - the label says which."""
+    from . import data
+    if data.have_human_mesh():
+        m = np.load(data.HUMAN_MESH)
+        return m["vertices"].astype(np.float32), m["faces"].astype(np.int32), "human_obj"
+    v, f = humanoid_mesh()
+    return v, f, "capsule"
 
 
 def human_points(n: int, seed: int = 0) -> np.ndarray:
     """(n,3) float32 points sampled AREA-UNIFORMLY on the reference's `load/shapes/human.obj`, normalised as the reference
     normalises its body mesh (threestudio/utils/poser.py:337-357 with `scale(-10)`: extent 1.20 x 0.30 x 1.56, z-up,
     area 1.51) - the cloud SURVEY.md 8(d) prescribes for every benchmark configuration, standing in for
-    `skel.sample_smplx_points` (GaussianDreamer.py:220-232).  The mesh is the committed fixture
-    tests/golden/human_mesh.npz (tests/golden/make_human_mesh.py); seeded `numpy.random.default_rng(seed)`."""
-    if not os.path.exists(_HUMAN_MESH):
-        raise FileNotFoundError(f"{_HUMAN_MESH} is missing (generate it with tests/golden/make_human_mesh.py where "
-                                f"/root/reference exists), or ask for source='capsule'")
-    m = np.load(_HUMAN_MESH)
+    `skel.sample_smplx_points` (GaussianDreamer.py:220-232).  The mesh is the LOCAL asset
+    humangaussian_amd/data/human_mesh.npz (data/make_human_mesh.py; not redistributed); seeded `numpy.random.default_rng(seed)`."""
+    from . import data
+    if not data.have_human_mesh():
+        raise FileNotFoundError(f"{data.HUMAN_MESH} is missing (generate it with humangaussian_amd/data/make_human_mesh.py "
+                                f"where /root/reference exists), or ask for source='capsule' / 'auto'")
+    m = np.load(data.HUMAN_MESH)
     v, f = m["vertices"].astype(np.float64), m["faces"]
     a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
     area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
@@ -102,7 +146,20 @@ def human_points(n: int, seed: int = 0) -> np.ndarray:
     return pts.astype(np.float32)                                     # (drawn independently: no spatial order in index space)
 
 
-CLOUD_SOURCES = ("human_obj", "capsule")
+def body_points(n: int, seed: int = 0, source: str = "auto") -> np.ndarray:
+    """`human_points` where the local mesh asset exists, `humanoid_points` otherwise (or as `source` says)."""
+    return human_points(n, seed) if resolve_cloud_source(source) == "human_obj" else humanoid_points(n, seed)
+
+
+CLOUD_SOURCES = ("auto", "human_obj", "capsule")
+
+
+def resolve_cloud_source(source: str = "auto") -> str:
+    """"auto" -> "human_obj" where the local mesh asset exists, else "capsule" (callers report the resolved name)."""
+    if source != "auto":
+        return source
+    from . import data
+    return "human_obj" if data.have_human_mesh() else "capsule"
 
 
 def mean_knn_dist2(points: np.ndarray, k: int = 3) -> np.ndarray:
@@ -122,16 +179,15 @@ class Cloud(NamedTuple):
     sh_degree: int
 
 
-def init_cloud(n: int, sh_degree: int = 0, variant: str = "mid", seed: int = 0, source: str = "human_obj") -> Cloud:
-    """source "human_obj" (the default: SURVEY.md 8(d)'s cloud, `human_points`) or "capsule" (`humanoid_points`: the
-    analytic stand-in of rounds 1-4, kept as a named variant and for boxes without the fixture)."""
+def init_cloud(n: int, sh_degree: int = 0, variant: str = "mid", seed: int = 0, source: str = "auto") -> Cloud:
+    """source "human_obj" (SURVEY.md 8(d)'s cloud, `human_points`: needs the local mesh asset), "capsule"
+    (`humanoid_points`: the analytic stand-in, same extents, workload shape within 2 %), or "auto" (the default):
+    human_obj where the asset exists, capsule otherwise - `resolve_cloud_source` tells a caller which."""
     rng = np.random.default_rng(seed + 1)
-    if source == "human_obj":
-        pts = human_points(n, seed)
-    elif source == "capsule":
-        pts = humanoid_points(n, seed)
-    else:
+    source = resolve_cloud_source(source)
+    if source not in ("human_obj", "capsule"):
         raise ValueError(source)
+    pts = body_points(n, seed, source)
     M = (sh_degree + 1) ** 2
     d2 = np.maximum(mean_knn_dist2(pts), 1e-7)
     log_scale = np.log(np.sqrt(d2))[:, None].repeat(3, 1)

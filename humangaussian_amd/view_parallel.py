@@ -297,8 +297,10 @@ def gather_view_images(outputs, num_views: int, group=None):
     view-separable; the SDS loss is)."""
     world = dist.get_world_size(group)
     per_rank = (num_views + world - 1) // world
-    if not outputs:
-        raise ValueError("gather_view_images: this rank rendered no view (fewer views than ranks): it cannot size its slab")
+    if num_views < world:
+        # the SAME test on every rank, before the collective: a rank without a view cannot size its slab, and raising
+        # only there would leave the other ranks inside the all-gather
+        raise ValueError(f"gather_view_images: {num_views} views for {world} ranks - every rank needs at least one view")
     v0, c0, d0, a0 = outputs[0]
     slab = torch.zeros((per_rank, 5) + tuple(c0.shape[1:]), dtype=c0.dtype, device=c0.device)
     for i, (_, c, d, a) in enumerate(outputs):

@@ -224,7 +224,7 @@ def test_dist_cuda2_grid_search_equals_the_brute_force_bit_for_bit():
     from humangaussian_amd.knn import distCUDA2
     rng = np.random.default_rng(5)
     clouds = {
-        "human_100k": synth.human_points(100_000, seed=0),
+        "body_100k": synth.body_points(100_000, seed=0),          # (human.obj where the local asset exists, else the capsule)
         "gauss": rng.normal(0, 0.4, (20_000, 3)),
         "planar": np.concatenate([rng.uniform(-1, 1, (5000, 2)), np.zeros((5000, 1))], 1),
         "collinear": np.stack([rng.uniform(-3, 3, 3000), np.zeros(3000), np.zeros(3000)], 1),
@@ -232,6 +232,9 @@ def test_dist_cuda2_grid_search_equals_the_brute_force_bit_for_bit():
         "all_equal": np.full((6000, 3), 0.25),          # > 4096 points in one cell: the device picks the brute force
         "tiny": rng.normal(0, 1, (5, 3)),
         "two_scales": np.concatenate([rng.normal((0, 0, 0), 0.002, (4000, 3)), rng.normal((1, 1, 1), 0.3, (4000, 3))]),
+        # translated far from the world origin: the ring search's stop rule works in grid-relative coordinates
+        "translated_1e3": synth.body_points(30_000, seed=1) + np.float32(1.0e3),
+        "translated_1e4": synth.body_points(30_000, seed=2) + np.array([1.0e4, -1.0e4, 3.0e3], np.float32),
     }
     dup = rng.normal(0, 0.2, (3000, 3))
     dup[5] = dup[6]
@@ -242,7 +245,7 @@ def test_dist_cuda2_grid_search_equals_the_brute_force_bit_for_bit():
         grid, brute = distCUDA2(p), distCUDA2(p, brute_force=True)
         assert torch.equal(grid.view(torch.int32), brute.view(torch.int32)), (name, float((grid - brute).abs().max()))
     # configs[3]-sized cloud against the k-d tree, and the point of it: time
-    pts = synth.human_points(500_000, seed=0)
+    pts = synth.body_points(500_000, seed=0)
     p = torch.from_numpy(pts).cuda()
     distCUDA2(p)
     torch.cuda.synchronize()

@@ -93,7 +93,8 @@ def test_bench_animation_leg_two_ranks_on_one_device():
     assert line["value"] > 0 and abs(line["value"] - 20000 * line["frames_per_s"]) <= 1e-6 * line["value"]
     a = line["animation"]
     assert a["frames"] == 12 and a["image_gather"] and a["backend"] == "gloo" and a["ms_per_step_without_gather"] > 0
-    assert "amass_test_17" in line["config"]["workload"]
+    from humangaussian_amd import data
+    assert ("amass_test_17" in line["config"]["workload"]) == data.have_motion()       # the line says which motion drove it
 
 
 def _run_workers(tmp_path, body, worlds=(1, 2)):
@@ -130,7 +131,7 @@ from humangaussian_amd import animation as an, synth
 P, H, W = 6000, 128, 128
 verts, anchors = an.human_mesh_anchors(P, seed=2, device="cuda")
 driver = an.MotionDriver(verts, device="cuda")
-assert driver.poses is not None and driver.num_poses == 136
+assert driver.num_poses == 136        # (the AMASS clip where the local asset exists, the procedural sway otherwise)
 cloud = synth.init_cloud(P, 0, "mid", seed=2)
 class Model:
     active_sh_degree = max_sh_degree = 0

@@ -73,10 +73,11 @@ def grid_knn(pts):
                 break
             reach = F(3.4e38)
             for a, c in enumerate((cx, cy, cz)):
+                rel = F(me[a] - lo[a])                      # grid-relative, like the cell assignment (knn.hip)
                 if c - r > 0:
-                    reach = min(reach, F(me[a] - (lo[a] + F(c - r) * h)))
+                    reach = min(reach, F(rel - F(F(c - r) * h)))
                 if c + r < g[a] - 1:
-                    reach = min(reach, F((lo[a] + F(c + r + 1) * h) - me[a]))
+                    reach = min(reach, F(F(F(c + r + 1) * h) - rel))
             reach = max(F(reach - F(1e-3) * h), F(0))
             if best[2] <= reach * reach:
                 break
@@ -112,6 +113,10 @@ def clouds():
     yield "all_equal", np.ones((40, 3)) * 0.25
     clus = np.concatenate([rng.normal((0, 0, 0), 0.01, (300, 3)), rng.normal((1, 1, 1), 0.3, (300, 3))])
     yield "two_scales", clus
+    # clouds translated far from the world origin: ulp(|coord|) is no longer small against 1e-3 h
+    far = rng.normal(0, 0.4, (600, 3)).astype(np.float32)
+    yield "translated_1e3", far + np.float32(1.0e3)
+    yield "translated_1e4", far + np.array([1.0e4, -1.0e4, 3.0e3], np.float32)
 
 
 @pytest.mark.parametrize("name,pts", list(clouds()), ids=[n for n, _ in clouds()])

@@ -7,12 +7,12 @@
 #   quick                 parity + batch suites only (fast gate for a kernel change)
 #   profile COMMIT        the round's artifacts: rocprofv3 --kernel-trace --stats, PMC FETCH/WRITE traffic (their own passes),
 #                         for configs[1], configs[3] and the 8-view batched call; three SQ-counter passes for configs[1]
-#                         -> gpurun_out/r05_*; copy what is to be judged into profiles/
+#                         -> gpurun_out/r06_*; copy what is to be judged into profiles/
 #   timeline NAME         device timelines of a -DHGS_TIMELINE variant (tools/timeline.py)      -> gpurun_out/timeline_NAME.txt
 # Modes can be chained:  bash tools/gpu_round.sh quick -- ab a b -- profile abc123
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-TAG=r05
+TAG=r06
 
 bench_line() {  # name, preload, extra bench args...
   local N=$1 PRE=$2; shift 2
