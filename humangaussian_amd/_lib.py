@@ -19,7 +19,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("HGS_LIB") or os.path.join(_PKG_DIR, "libhgs_rast.so")   # HGS_LIB: A/B experiments only
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared"]
@@ -79,6 +79,10 @@ EXPORTS = {
     "hgs_reduce_view_packs": (ctypes.c_int, [c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "hgs_reduce_view_packs_acc": (ctypes.c_int, [c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hgs_pack_view_contribution": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 9),
+    "hgs_backward_batch_packed": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 5
+                                  + [c_void_p] * 7 + [c_void_p] * 3 + [POINTER(HgsStatus), c_int64, c_void_p]
+                                  + [c_void_p] * 2 + [c_void_p, c_int32, c_void_p]),
+    "hgs_reduce_view_packs_unpack": (ctypes.c_int, [c_int32, c_int64, c_int32] + [c_void_p] * 9 + [c_void_p]),
     "hgs_densify_stats": (ctypes.c_int, [c_int32, c_int32] + [c_void_p] * 9),
     "hgs_densify_masks": (ctypes.c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p]
                           + [c_float] * 6 + [c_void_p] * 5),

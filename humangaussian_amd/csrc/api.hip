@@ -28,8 +28,8 @@ __device__ unsigned long long hgs_tl[HGS_TL_KERNELS][HGS_TL_SLOTS][4];
 extern "C" __global__ void hgs_k_render_bwd(View, Layout, const hgs_status*, const SortRec*, const float*,
                                             const float*, const float*, const float*, const float*,
                                             const float*, const float*, float*, uint32_t);
-extern "C" __global__ void hgs_k_pair_reduce_em(View, Layout, const hgs_status*, const SortRec*, const float*, float*, uint32_t);
-extern "C" __global__ void hgs_k_pair_reduce_ch(View, Layout, const hgs_status*, const SortRec*, const float*, float*, uint32_t);
+extern "C" __global__ void hgs_k_pair_reduce_em(View, Layout, const hgs_status*, const SortRec*, const float*, float*, uint32_t, uint32_t);
+extern "C" __global__ void hgs_k_pair_reduce_ch(View, Layout, const hgs_status*, const SortRec*, const float*, float*, uint32_t, uint32_t);
 
 namespace {
 
@@ -338,6 +338,21 @@ int hgs_reduce_view_packs_acc(int32_t world, int64_t P, int32_t F, const float* 
   return HGS_OK;
 }
 
+int hgs_reduce_view_packs_unpack(int32_t world, int64_t P, int32_t M, const float* gathered, const float* acc_in,
+                                 float* g_means3D, float* g_means2D, float* g_sh, float* g_opac, float* g_scales,
+                                 float* g_rot, int32_t* radii, void* stream_) {
+  if (world < 1 || P < 0 || M < 0) return HGS_EINVAL;
+  if (P == 0) return HGS_OK;
+  if (!gathered || !g_means3D || !g_means2D || (M > 0 && !g_sh) || !g_opac || !g_scales || !g_rot || !radii) return HGS_EINVAL;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int F = 15 + 3 * M;
+  const long long n = (long long)P * F;
+  hipLaunchKernelGGL(hgs_k_reduce_view_packs_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                     (int)world, n, (int)F, (int)M, gathered, acc_in, g_means3D, g_means2D, g_sh, g_opac, g_scales, g_rot, radii);
+  HGS_LAUNCH_CHECK();
+  return HGS_OK;
+}
+
 int hgs_reduce_view_packs(int32_t world, int64_t P, int32_t F, const float* gathered, float* out,
                           void* stream_) {
   return hgs_reduce_view_packs_acc(world, P, F, gathered, nullptr, out, stream_);
@@ -358,7 +373,7 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 14; }
+int hgs_abi_version(void) { return 15; }
 
 size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t H, int32_t W) {
   if (B < 1 || B > HGS_MAX_VIEWS || P < 0 || H <= 0 || W <= 0) return 0;
@@ -542,7 +557,12 @@ int hgs_forward(const hgs_settings* s, int32_t P, int32_t M, const float* means3
                            status_event, stage_events, stream_);
 }
 
-int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+}  // extern "C"
+
+namespace {
+// the backward of a batch; `pack` != nullptr: hgs_backward_batch_packed (one (P, pack_F) row-major pack instead of the six
+// parameter-gradient tensors; dL_dshs / dL_dscales / dL_drotations are then non-null MARKERS for the parts the row carries)
+int backward_impl(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
                            const float* shs, const float* colors_precomp, const float* opacities,
                            const float* scales, const float* rotations, const float* cov3D_precomp,
                            const int32_t* radii, const float* out_color, const float* out_depth,
@@ -552,7 +572,7 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
                            int64_t entry_capacity, void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                            float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
-                           int32_t activation_flags, void* stream_) {
+                           int32_t activation_flags, float* pack, int32_t pack_F, void* stream_) {
   (void)radii;
   if (activation_flags & ~(7 | HGS_GRAD_SCALE_TRUE_DERIVATIVE)) return HGS_EINVAL;
   if ((activation_flags & HGS_ACT_OPACITY_SIGMOID) && P > 0 && !opacities) return HGS_EINVAL;
@@ -594,12 +614,14 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
     HGS_LAUNCH_CHECK();
     HGS_STAGE(1);
     if (X > 0) {
+      // a caller that holds the status hands the reduction its entry count (no status round trip in front of its chain)
+      const uint32_t R_host = status ? status->num_rendered : 0xffffffffu;
       if (v.pairchunks)
         hipLaunchKernelGGL(hgs_k_pair_reduce_ch, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
-                           pair_rows, rows, pair_cap);
+                           pair_rows, rows, pair_cap, R_host);
       else
         hipLaunchKernelGGL(hgs_k_pair_reduce_em, dim3((unsigned)((X + 255) / 256)), dim3(256), 0, stream, v, L, status_dev, L.recs,
-                           pair_rows, rows, pair_cap);
+                           pair_rows, rows, pair_cap, R_host);
       HGS_LAUNCH_CHECK();
     }
   }
@@ -609,14 +631,14 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   hipLaunchKernelGGL(K, dim3(GRID), dim3(THREADS), LDS, stream, v, L, status_dev, rows, means3D, shs, \
                      colors_precomp, opacities, scales, rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, \
                      dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,            \
-                     dL_dcov3D_precomp)
+                     dL_dcov3D_precomp, pack, (int)pack_F)
   // One view: the instantiation without the loop over views (94 instead of 176 VGPRs at SH degree 0).  Several
   // views: one thread per (Gaussian, view) - a workgroup of B waves per 64 Gaussians, summed in view order
   // through LDS (preprocess.hip, mode 2); combinations whose exchange buffer would not fit: the loop.
   const int deg = shs ? v.D : 0;
   const int nc = (deg + 1) * (deg + 1);
   const unsigned thr_p = 64u * (unsigned)v.B, grid_p = (unsigned)((v.P + 63) / 64);
-  const size_t lds_p = (size_t)(20 + 3 * nc) * thr_p * sizeof(float);
+  const size_t lds_p = (size_t)(23 + 3 * nc) * thr_p * sizeof(float);
   // The exchange buffer may take the CU's whole LDS (160 KB on gfx950; beyond 64 KB the kernel's dynamic-LDS limit is raised
   // first): 16 views at SH degrees 0 / 1, 8 at degrees 2 / 3 (139 KB at degree 3) - the thread-per-(Gaussian, view) form
   // then covers every batch a training step makes; the loop form (d*: 256 VGPRs at degree 3, one wave per SIMD) remains
@@ -666,6 +688,41 @@ int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t 
   HGS_LAUNCH_CHECK();
   HGS_STAGE(3);
   return HGS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hgs_backward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                           const float* shs, const float* colors_precomp, const float* opacities,
+                           const float* scales, const float* rotations, const float* cov3D_precomp,
+                           const int32_t* radii, const float* out_color, const float* out_depth,
+                           const float* out_alpha, const float* dL_dout_color,
+                           const float* dL_dout_depth, const float* dL_dout_alpha, const void* geom,
+                           const void* bin, const void* img, const hgs_status* status,
+                           int64_t entry_capacity, void* bwd_scratch, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                           float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                           float* dL_drotations, float* dL_dcov3D_precomp, void* const* stage_events,
+                           int32_t activation_flags, void* stream_) {
+  return backward_impl(s, B, P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, out_color,
+                       out_depth, out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, geom, bin, img, status,
+                       entry_capacity, bwd_scratch, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities,
+                       dL_dscales, dL_drotations, dL_dcov3D_precomp, stage_events, activation_flags, nullptr, 0, stream_);
+}
+
+int hgs_backward_batch_packed(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                              const float* shs, const float* opacities, const float* scales, const float* rotations,
+                              const int32_t* radii, const float* out_color, const float* out_depth, const float* out_alpha,
+                              const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha,
+                              const void* geom, const void* bin, const void* img, const hgs_status* status,
+                              int64_t entry_capacity, void* bwd_scratch, float* pack, float* dL_dmeans2D_views,
+                              void* const* stage_events, int32_t activation_flags, void* stream_) {
+  if (!pack || !shs || !scales || !rotations || M < 1) return P == 0 ? HGS_OK : HGS_EINVAL;
+  float* marker = pack;        // (non-null markers: the row carries the SH, scale and rotation parts)
+  return backward_impl(s, B, P, M, means3D, shs, nullptr, opacities, scales, rotations, nullptr, radii, out_color, out_depth,
+                       out_alpha, dL_dout_color, dL_dout_depth, dL_dout_alpha, geom, bin, img, status, entry_capacity,
+                       bwd_scratch, marker, dL_dmeans2D_views, marker, nullptr, marker, marker, marker, nullptr, stage_events,
+                       activation_flags, pack, 15 + 3 * M, stream_);
 }
 
 int hgs_backward_batch(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,

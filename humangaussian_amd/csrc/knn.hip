@@ -291,6 +291,33 @@ hgs_k_reduce_view_packs(int world, long long n, int F, const float* __restrict__
   out[i] = acc;
 }
 
+// The same reduction with the UNPACK fused in: element (p, f) of the rank-ordered sum / max goes straight into the tensor
+// its column belongs to (means3D 3 | means2D 3 | sh 3M | opacity 1 | scales 3 | rotations 4 | radii 1 as int32) - the last
+// pass of a view-parallel step (hgs_reduce_view_packs_unpack): no (P, F) intermediate, no slicing / rounding kernels behind it.
+extern "C" __global__ void __launch_bounds__(256)
+hgs_k_reduce_view_packs_unpack(int world, long long n, int F, int M, const float* __restrict__ gathered,
+                               const float* __restrict__ acc_in, float* __restrict__ g_means3D,
+                               float* __restrict__ g_means2D, float* __restrict__ g_sh, float* __restrict__ g_opac,
+                               float* __restrict__ g_scales, float* __restrict__ g_rot, int32_t* __restrict__ radii) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long p = i / F;
+  const int f = (int)(i - p * F);
+  const bool is_max = f == F - 1;
+  float acc = acc_in ? acc_in[i] : gathered[i];
+  for (int r = acc_in ? 0 : 1; r < world; ++r) {
+    const float x = gathered[(long long)r * n + i];
+    acc = is_max ? fmaxf(acc, x) : acc + x;
+  }
+  if (f < 3) g_means3D[3 * p + f] = acc;
+  else if (f < 6) g_means2D[3 * p + (f - 3)] = acc;
+  else if (f < 6 + 3 * M) g_sh[p * 3 * M + (f - 6)] = acc;
+  else if (f == 6 + 3 * M) g_opac[p] = acc;
+  else if (f < 10 + 3 * M) g_scales[3 * p + (f - 7 - 3 * M)] = acc;
+  else if (f < 14 + 3 * M) g_rot[4 * p + (f - 10 - 3 * M)] = acc;
+  else radii[p] = (int32_t)rintf(acc);
+}
+
 // Packs one rank's per-Gaussian contribution [means3D 3 | means2D 3 | sh 3M | opacity 1 | scale 3 |
 // rot 4 | radii 1] into the (P, F) fp32 tensor that travels through the all-gather (radii as exact
 // fp32 integers).  One pass instead of seven reshapes/casts and a torch.cat.

@@ -464,11 +464,16 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const float* __restrict__ cov3D_precomp, float* __restrict__ dL_dmeans3D,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopac, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
-    float* __restrict__ dL_dcov3D) {
+    float* __restrict__ dL_dcov3D, float* __restrict__ pack, int pack_F) {
+  // `pack` (hgs_backward_batch_packed): the gradients of Gaussian i go into ONE row of pack_F = 15 + 3 M floats
+  //   [means3D 3 | means2D 3, summed over the call's views | sh 3 M | opacity 1 | scales 3 | rotations 4 | radii 1, max over the views]
+  // - the layout the view-parallel step all-gathers (view_parallel.py) - instead of into six tensors that a second kernel
+  // would have to read back and interleave.  The caller passes dL_dshs / dL_dscales / dL_drots as non-null markers (any
+  // value) for the parts it wants; dL_dmeans2D (per view) may still be given.
   constexpr int NC = (DEG + 1) * (DEG + 1);       // active SH coefficients
   constexpr bool SINGLE = MODE != 0;              // this thread handles exactly one view
   constexpr bool VPAR = MODE == 2;
-  constexpr int NV = 20 + 3 * NC;                 // values a thread hands over in mode 2
+  constexpr int NV = 23 + 3 * NC;                 // values a thread hands over in mode 2 (the last three: means2D x, y - sums - and the radius - a max)
   extern __shared__ float red[];                  // mode 2: [NV][threads of the workgroup]
   int i = blockIdx.x * HGS_BLOCK + threadIdx.x, bview = 0, il = threadIdx.x;
   if (VPAR) {                                     // wave = view (wave-uniform camera), lane = Gaussian
@@ -480,7 +485,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
   // single view, SH degree >= 1: the chunk's SH blocks come in (and the gradient blocks go out) through LDS as coalesced
   // ranges (stage_sh_chunk: per-thread 16 B pieces at a 12 M byte stride cost 8x the L2 <-> L1 traffic).  Full chunks only.
   const bool staged = MODE == 1 && DEG > 0 && dL_dshs != nullptr && shs != nullptr && hgs_sh_staged(v.M) &&
-                      (int)(blockIdx.x + 1) * HGS_BLOCK <= v.P;
+                      (int)(blockIdx.x + 1) * HGS_BLOCK <= v.P && pack == nullptr;
   if (staged) {
     stage_sh_chunk(shs, v.M, (int)blockIdx.x * HGS_BLOCK, HGS_BLOCK, red);
     __syncthreads();
@@ -531,6 +536,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
   float a_sh[3 * NC];
 #pragma unroll
   for (int k = 0; k < 3 * NC; ++k) a_sh[k] = 0.f;
+  float a_m2x = 0.f, a_m2y = 0.f, a_rad = 0.f;   // packed output: screen-space gradient summed over the views, largest radius
 
   const int b_begin = VPAR ? bview : 0;
   const int b_end = SINGLE ? b_begin + 1 : v.B;   // modes 1, 2: exactly one iteration, known at compile time (no loop-carried sums)
@@ -753,6 +759,9 @@ __device__ __forceinline__ void preprocess_bwd_body(
       o[1] = gmy * 0.5f * (float)v.H;
       o[2] = 0.f;
     }
+    a_m2x += gmx * 0.5f * (float)v.W;
+    a_m2y += gmy * 0.5f * (float)v.H;
+    a_rad = fmaxf(a_rad, (float)g.radius);
   }
 
   if (VPAR) {
@@ -773,6 +782,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
       vals[vi++] = a_op;
 #pragma unroll
       for (int k = 0; k < 3 * NC; ++k) vals[vi++] = a_sh[k];
+      vals[vi++] = a_m2x; vals[vi++] = a_m2y; vals[vi++] = a_rad;
     }
     const int nthr = (int)blockDim.x;
 #pragma unroll
@@ -786,7 +796,8 @@ __device__ __forceinline__ void preprocess_bwd_body(
     for (int bb = 0; bb < v.B; ++bb) {
       const float* col = red + bb * 64 + il;
 #pragma unroll
-      for (int k = 0; k < NV; ++k) vals[k] += col[k * nthr];
+      for (int k = 0; k < NV - 1; ++k) vals[k] += col[k * nthr];
+      vals[NV - 1] = fmaxf(vals[NV - 1], col[(NV - 1) * nthr]);       // (the radius: a max)
     }
     {
       int vi = 0;
@@ -803,7 +814,48 @@ __device__ __forceinline__ void preprocess_bwd_body(
       a_op = vals[vi++];
 #pragma unroll
       for (int k = 0; k < 3 * NC; ++k) a_sh[k] = vals[vi++];
+      a_m2x = vals[vi++]; a_m2y = vals[vi++]; a_rad = vals[vi++];
     }
+  }
+  if (pack) {
+    // ---- packed output: one row, fused activations' chain rule like below
+    float* __restrict__ row = pack + (size_t)i * pack_F;
+    row[0] = a_mean[0]; row[1] = a_mean[1]; row[2] = a_mean[2];
+    row[3] = a_m2x; row[4] = a_m2y; row[5] = 0.f;
+    if (dL_dshs) {
+#pragma unroll
+      for (int k = 0; k < 3 * NC; ++k)
+        if (k < 3 * v.M) row[6 + k] = a_sh[k];
+      for (int k = 3 * NC; k < 3 * v.M; ++k) row[6 + k] = 0.f;
+    }
+    float* __restrict__ tail = row + 6 + 3 * v.M;
+    float gop = a_op;
+    if (v.act & HGS_ACT_OPACITY_SIGMOID) {
+      const float y = act_opacity(opacities_raw[i], v.act);
+      gop = gop * ((1.0f - y) * y);
+    }
+    tail[0] = gop;
+    if (dL_dscales) {
+      if (v.act & HGS_ACT_SCALE_EXP) {
+        float s0, s1, s2;
+        act_scale(scales, i, v.act, s0, s1, s2);
+        a_sc[0] *= s0; a_sc[1] *= s1; a_sc[2] *= s2;
+      }
+      tail[1] = a_sc[0]; tail[2] = a_sc[1]; tail[3] = a_sc[2];
+    }
+    if (dL_drots) {
+      if (!SINGLE && !cov3D_precomp) q = act_rotation(rotations, i, v.act, q_inv_norm);
+      if (v.act & HGS_ACT_ROTATION_NORMALIZE) {
+        const float dot = q.x * a_rot[0] + q.y * a_rot[1] + q.z * a_rot[2] + q.w * a_rot[3];
+        a_rot[0] = (a_rot[0] - q.x * dot) * q_inv_norm;
+        a_rot[1] = (a_rot[1] - q.y * dot) * q_inv_norm;
+        a_rot[2] = (a_rot[2] - q.z * dot) * q_inv_norm;
+        a_rot[3] = (a_rot[3] - q.w * dot) * q_inv_norm;
+      }
+      tail[4] = a_rot[0]; tail[5] = a_rot[1]; tail[6] = a_rot[2]; tail[7] = a_rot[3];
+    }
+    tail[8] = a_rad;                                 // (an exact integer < 2^24)
+    return;
   }
 
   // ---- one write per output element
@@ -890,10 +942,10 @@ __device__ __forceinline__ void preprocess_bwd_body(
       const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,                 \
       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, \
       float* __restrict__ dL_dcolors, float* __restrict__ dL_dopac, float* __restrict__ dL_dscales,  \
-      float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {                                \
+      float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, float* __restrict__ pack, int pack_F) { \
     preprocess_bwd_body<DEG, MODE>(v, L, status, grad_rows, means3D, shs, colors_precomp, opacities_raw, scales, \
                              rotations, cov3D_precomp, dL_dmeans3D, dL_dmeans2D, dL_dshs,           \
-                             dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D);                \
+                             dL_dcolors, dL_dopac, dL_dscales, dL_drots, dL_dcov3D, pack, pack_F);  \
   }
 HGS_PRE_BWD_KERNEL(0, hgs_k_preprocess_bwd_d0, 0, HGS_BLOCK)         // thread per Gaussian, loop over the views
 HGS_PRE_BWD_KERNEL(1, hgs_k_preprocess_bwd_d1, 0, HGS_BLOCK)

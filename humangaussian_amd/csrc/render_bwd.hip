@@ -425,10 +425,16 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 #define HGS_RED_ROWS 128
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
-                  const float* __restrict__ pair_rows, float* __restrict__ grad_rows, uint32_t pair_cap) {
+                  const float* __restrict__ pair_rows, float* __restrict__ grad_rows, uint32_t pair_cap, uint32_t R_host) {
   __shared__ float2 s_rows[4][HGS_RED_ROWS * HGS_PROW_F2];
-  if (status->overflow) return;
-  const uint32_t R = status->num_rendered;
+  // R_host: the entry count of a caller that holds the forward's status (hgs_backward* refuses an overflowed one on the
+  // host): the kernel's first loads then do not wait for a status round trip (~1.5 us in front of every wave's chain
+  // entpair -> rows); ~0: unknown, read the device copy
+  uint32_t R = R_host;
+  if (R_host == 0xffffffffu) {
+    if (status->overflow) return;
+    R = status->num_rendered;
+  }
   const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   if (p - (uint32_t)lane >= R) return;                       // (wave-uniform)
@@ -531,10 +537,13 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
 typedef float hgs_f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));      // 16 B access at 8 B alignment (40 B pair rows)
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce_ch(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
-                      const float* __restrict__ pair_rows, float* __restrict__ grad_rows, uint32_t pair_cap) {
+                      const float* __restrict__ pair_rows, float* __restrict__ grad_rows, uint32_t pair_cap, uint32_t R_host) {
   __shared__ float2 s_rows[4][HGS_RED_ROWS * HGS_PROW_F2];
-  if (status->overflow) return;
-  const uint32_t R = status->num_rendered;
+  uint32_t R = R_host;                                     // (see hgs_k_pair_reduce_em)
+  if (R_host == 0xffffffffu) {
+    if (status->overflow) return;
+    R = status->num_rendered;
+  }
   const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
   const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;      // the wave's window of records
   if (w0 >= R) return;                                                   // (wave-uniform)

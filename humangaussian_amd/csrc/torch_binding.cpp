@@ -200,6 +200,15 @@ struct BwdPlan : torch::CustomClassHolder {
   }
 };
 
+// Packed backward (view_parallel.py): while the request is set, a backward whose inputs are the SH / scale / rotation
+// configuration writes ONE (P, 15 + 3M) pack (hgs_backward_batch_packed) - the tensor the rank sends - and hands autograd
+// strided views of it; `take_packed()` collects the pack.  Thread-local: the request belongs to the thread that runs
+// autograd.grad (torch's engine runs a CPU-initiated backward of one device on the calling thread's device worker; the
+// flag is read through a process-wide atomic for that reason, the pack returned per process).
+std::atomic<int> g_pack_request{0};
+std::mutex g_pack_mu;
+Tensor g_last_pack;
+
 struct Rasterize : public torch::autograd::Function<Rasterize> {
   // 22 arguments after ctx (backward returns one slot per argument).  `tanfov` is a CPU double
   // tensor [2][B] (x row, y row); `batch` = 0 for the single-view API, else the number of views;
@@ -430,6 +439,39 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
     // write nothing (NaN gradients) if the slot delivered a stale number (hgs_rast.h: hgs_backward)
     plan->status.num_pairs = (uint32_t)pairs;
     const auto tb1 = std::chrono::steady_clock::now();
+    const bool packed = g_pack_request.load(std::memory_order_relaxed) != 0 && plan->has_sh && plan->has_sr && !plan->has_cp &&
+                        !plan->has_cv && plan->M >= 1 && plan->P > 0;
+    if (packed) {
+      const int64_t P = plan->P, M = plan->M, F = 15 + 3 * M;
+      Tensor pack = at::empty({P, F}, at::TensorOptions().dtype(at::kFloat).device(dev));
+      const int rc = hgs_backward_batch_packed(
+          plan->settings.s.data(), plan->B, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(op_), fptr(sc_), fptr(ro_),
+          radii.data_ptr<int32_t>(), fptr(color), fptr(depth), fptr(alpha), fptr(gc), fptr(gd), fptr(ga), plan->geom, plan->bin,
+          plan->img, &plan->status, plan->cap, plan->rows, pack.data_ptr<float>(),
+          plan->batched ? fptr_mut(d_means2D) : nullptr, g_stage_bwd.empty() ? nullptr : g_stage_bwd.data(), plan->act, stream);
+      check_rc(rc, "hgs_backward_batch_packed");
+      variable_list out(22);
+      out[0] = pack.as_strided({P, 3}, {F, 1}, 0);
+      out[1] = plan->batched ? d_means2D : pack.as_strided({P, 3}, {F, 1}, 3);
+      out[2] = pack.as_strided({P, M, 3}, {F, 3, 1}, 6);
+      {
+        std::vector<int64_t> os = plan->opac_sizes, ostr(plan->opac_sizes.size(), 1);
+        if (!ostr.empty()) ostr[0] = F;
+        out[4] = pack.as_strided(os, ostr, 6 + 3 * M);
+      }
+      out[5] = pack.as_strided({P, 3}, {F, 1}, 7 + 3 * M);
+      out[6] = pack.as_strided({P, 4}, {F, 1}, 10 + 3 * M);
+      {
+        std::lock_guard<std::mutex> lk(g_pack_mu);
+        g_last_pack = pack;
+      }
+      DevState& st = state_for(dev.index());
+      const auto tb2 = std::chrono::steady_clock::now();
+      st.host_ns[5] += std::chrono::duration_cast<std::chrono::nanoseconds>(tb1 - tb0).count();
+      st.host_ns[6] += std::chrono::duration_cast<std::chrono::nanoseconds>(tb2 - tb1).count();
+      st.host_ns[7] += std::chrono::duration_cast<std::chrono::nanoseconds>(tb2 - tb0).count();
+      return out;
+    }
     const int rc = hgs_backward_batch_act(
         plan->settings.s.data(), plan->B, plan->P, plan->M, fptr(m3), fptr(sh_), fptr(cp_), fptr(op_), fptr(sc_), fptr(ro_),
         fptr(cv_), plan->P > 0 ? radii.data_ptr<int32_t>() : nullptr, fptr(color), fptr(depth), fptr(alpha), fptr(gc),
@@ -588,6 +630,51 @@ Tensor reduce_view_packs(const Tensor& gathered, const c10::optional<Tensor>& ac
                                            c10::hip::getCurrentHIPStream(dev.index()).stream());
   check_rc(rc, "hgs_reduce_view_packs_acc");
   return out;
+}
+
+void set_packed_backward(bool on) {
+  g_pack_request.store(on ? 1 : 0, std::memory_order_relaxed);
+  if (!on) return;
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  g_last_pack = Tensor();
+}
+
+// the pack the last packed backward wrote (None if the backward was not eligible: the caller packs the six tensors itself)
+c10::optional<Tensor> take_packed() {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  Tensor t = g_last_pack;
+  g_last_pack = Tensor();
+  if (!t.defined()) return c10::nullopt;
+  return t;
+}
+
+// the LAST reduction of a view-parallel step with the unpack fused in: (world, P, 15 + 3M) [+ running total (P, F)] ->
+// [means3D (P,3), means2D (P,3), sh (P,M,3), opacity (P,1), scales (P,3), rotations (P,4), radii (P,) int32]
+std::vector<Tensor> reduce_view_packs_unpack(const Tensor& gathered, const c10::optional<Tensor>& acc_in) {
+  at::NoGradGuard ng;
+  const c10::Device dev = gathered.device();
+  if (!dev.is_cuda()) throw std::runtime_error("humangaussian_amd: tensors must live on a HIP device");
+  if (gathered.dim() != 3 || gathered.size(2) < 15 || (gathered.size(2) - 15) % 3)
+    throw std::runtime_error("gathered packs must have dimensions (world, num_points, 15 + 3 M)");
+  DeviceSwitch guard(dev.index());
+  const Tensor g = f32c(gathered, dev, "gathered");
+  const int64_t P = g.size(1), F = g.size(2), M = (F - 15) / 3;
+  Tensor a;
+  if (acc_in.has_value() && acc_in->defined()) {
+    a = f32c(*acc_in, dev, "running total");
+    if (a.numel() != P * F) throw std::runtime_error("running total must have dimensions (num_points, F)");
+  }
+  const auto fopt = g.options();
+  Tensor m3 = at::empty({P, 3}, fopt), m2 = at::empty({P, 3}, fopt), sh = at::empty({P, M, 3}, fopt);
+  Tensor op = at::empty({P, 1}, fopt), sc = at::empty({P, 3}, fopt), ro = at::empty({P, 4}, fopt);
+  Tensor radii = at::empty({P}, fopt.dtype(at::kInt));
+  const int rc = hgs_reduce_view_packs_unpack((int32_t)g.size(0), P, (int32_t)M, g.data_ptr<float>(),
+                                              a.defined() ? a.data_ptr<float>() : nullptr, fptr_mut(m3), fptr_mut(m2),
+                                              fptr_mut(sh), fptr_mut(op), fptr_mut(sc), fptr_mut(ro),
+                                              P > 0 ? radii.data_ptr<int32_t>() : nullptr,
+                                              c10::hip::getCurrentHIPStream(dev.index()).stream());
+  check_rc(rc, "hgs_reduce_view_packs_unpack");
+  return {m3, m2, sh, op, sc, ro, radii};
 }
 
 // ---- bookkeeping either side of the path (include/hgs_rast.h: hgs_densify_*, hgs_compact_*, hgs_reanchor)
@@ -769,6 +856,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("reduce_view_packs", &reduce_view_packs, py::arg("gathered"), py::arg("acc_in") = py::none(),
         py::call_guard<py::gil_scoped_release>());
   m.def("pack_view_contribution", &pack_view_contribution, py::call_guard<py::gil_scoped_release>());
+  m.def("reduce_view_packs_unpack", &reduce_view_packs_unpack, py::arg("gathered"), py::arg("acc_in") = py::none(),
+        py::call_guard<py::gil_scoped_release>());
+  m.def("set_packed_backward", &set_packed_backward);
+  m.def("take_packed", &take_packed);
   m.def("densify_stats", &densify_stats, py::call_guard<py::gil_scoped_release>());
   m.def("densify_masks", &densify_masks, py::call_guard<py::gil_scoped_release>());
   m.def("compact_rows", &compact_rows, py::call_guard<py::gil_scoped_release>());

@@ -134,6 +134,27 @@ def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, s
         bool(r0.prefiltered), any(bool(rs.debug) for rs in rsl), want_grad, int(activation_flags))
 
 
+class packed_gradients:
+    """Context manager of the view-parallel step (view_parallel.py): a rasterizer backward that runs inside it writes the
+    per-Gaussian gradients as ONE (P, 15 + 3M) pack - [means3D 3 | means2D 3, summed over the call's views | sh 3M |
+    opacity 1 | scales 3 | rotations 4 | radii 1, max over the views] - straight from its last kernel
+    (include/hgs_rast.h: hgs_backward_batch_packed; the tensor the rank all-gathers) and hands autograd strided VIEWS of
+    it; `.take()` returns the pack (None if the backward was not eligible - colours / covariances precomputed, or no
+    backward ran: the caller then packs the six tensors itself)."""
+
+    def __enter__(self):
+        _lib.load_binding().set_packed_backward(True)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load_binding().set_packed_backward(False)
+        return False
+
+    @staticmethod
+    def take():
+        return _lib.load_binding().take_packed()
+
+
 class _RasterizeGaussians:
     """Name kept for callers that reach for upstream's autograd.Function directly:
     `_RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales,

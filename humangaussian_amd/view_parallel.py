@@ -54,6 +54,19 @@ def pack_contribution(grads: Dict[str, torch.Tensor], radii: torch.Tensor) -> to
     return torch.cat(cols, dim=1).contiguous()
 
 
+def reduce_gathered_unpacked(gathered: torch.Tensor, acc_in: Optional[torch.Tensor], shapes: Dict[str, torch.Size]):
+    """The LAST reduction of a step with the unpack fused in (one HIP pass: include/hgs_rast.h
+    hgs_reduce_view_packs_unpack): (world, P, F) [+ running total] -> (grads dict, radii int32) - the same bits as
+    `unpack_contribution(reduce_gathered(gathered, acc_in), shapes)`, without the (P, F) intermediate and the slicing /
+    rounding kernels behind it."""
+    if gathered.is_cuda and gathered.dim() == 3:
+        from . import _lib
+        m3, m2, sh, op, sc, ro, radii = _lib.load_binding().reduce_view_packs_unpack(gathered, acc_in)
+        out = {"means3D": m3, "means2D": m2, "shs": sh, "opacities": op, "scales": sc, "rotations": ro}
+        return {k: out[k].reshape(shapes[k]) for k in GRAD_KEYS}, radii
+    return unpack_contribution(reduce_gathered(gathered, acc_in), shapes)
+
+
 def unpack_contribution(pack: torch.Tensor, shapes: Dict[str, torch.Size]):
     out, c = {}, 0
     P = pack.shape[0]
@@ -149,6 +162,15 @@ def scatter_reduce_gather(pack: torch.Tensor, group=None) -> torch.Tensor:
 COLLECTIVE_MODES = ("allgather", "scatter")
 
 
+def allgather_reduce_unpacked(pack: torch.Tensor, shapes: Dict[str, torch.Size], group=None, mode: str = "allgather"):
+    """`allgather_reduce` + `unpack_contribution` with the last reduction and the unpack as ONE pass where the mode ends
+    in a local reduction of gathered packs (mode "allgather"; "scatter" ends in an all-gather of reduced shards: its
+    result is unpacked as before)."""
+    if mode == "allgather" and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return reduce_gathered_unpacked(allgather(pack, group), None, shapes)
+    return unpack_contribution(allgather_reduce(pack, group, mode), shapes)
+
+
 def allgather_reduce(pack: torch.Tensor, group=None, mode: str = "allgather") -> torch.Tensor:
     """The collective of a step: every rank's pack in, the rank-ordered reduction out (identical bits
     on every rank).  mode "allgather": ONE all-gather of the packs + local reduction (SURVEY.md 8(e));
@@ -211,7 +233,21 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
     shapes["means2D"] = leaves["means3D"].shape
     outputs = []
 
-    def one_view(v):
+    # On the HIP path the rasterizer's last backward kernel writes the pack itself (rasterizer.packed_gradients): no
+    # pack kernel, no second pass over the six gradient tensors on the exposed path of a step.
+    hip_pack = dev.type == "cuda"
+    if hip_pack:
+        from .rasterizer import packed_gradients
+
+    def grads_of(outs, tens, gouts):
+        """-> (gradient tuple, pack or None)"""
+        if not hip_pack or not outs:
+            return torch.autograd.grad(outs, tens, gouts, allow_unused=True), None
+        with packed_gradients() as pg:
+            gl = torch.autograd.grad(outs, tens, gouts, allow_unused=True)
+            return gl, pg.take()
+
+    def one_view(v, want_pack=False):
         means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
         color, radii, depth, alpha = render_fn(cameras[v], leaves, means2D, bg, sh_degree)
         gc, gd, ga = loss_grad_fn(v, color.detach(), depth.detach(), alpha.detach())
@@ -220,10 +256,13 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
         for o, g in ((color, gc), (depth, gd), (alpha, ga)):
             if g is not None:
                 outs.append(o); gouts.append(g)
-        gl = torch.autograd.grad(outs, tens, gouts, allow_unused=True)
+        gl, pack = grads_of(outs, tens, gouts)
         outputs.append((v, color.detach(), depth.detach(), alpha.detach()))
-        return {k: (g if g is not None else torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev))
-                for k, g in zip(names, gl)}, radii
+        g = {k: (g if g is not None else torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev))
+             for k, g in zip(names, gl)}
+        if want_pack:
+            return pack if pack is not None else pack_contribution(g, radii)
+        return g, radii
 
     if batched:
         acc = {k: torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev) for k in names}
@@ -241,23 +280,38 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
                     gouts.append(torch.stack([pv[col] if pv[col] is not None else torch.zeros_like(o[i])
                                               for i, pv in enumerate(per_view)]))
             tens = [leaves[k] for k in names[:-1]] + [means2D]
-            gl = torch.autograd.grad(outs, tens, gouts, allow_unused=True)
-            for k, g in zip(names, gl):
-                if g is not None:
-                    acc[k] = g if k != "means2D" else g.sum(0)       # (screen-space gradients: summed over the rank's views)
-            radii_max = radii.max(dim=0).values.to(torch.int32)
+            gl, bpack = grads_of(outs, tens, gouts)
             for i, v in enumerate(mine):
                 outputs.append((v, color[i].detach(), depth[i].detach(), alpha[i].detach()))
-        total = allgather_reduce(pack_contribution(acc, radii_max), group, mode=collective)
+            if bpack is None:
+                for k, g in zip(names, gl):
+                    if g is not None:
+                        acc[k] = g if k != "means2D" else g.sum(0)       # (screen-space gradients: summed over the rank's views)
+                radii_max = radii.max(dim=0).values.to(torch.int32)
+        else:
+            bpack = None
+        if bpack is None:
+            bpack = pack_contribution(acc, radii_max)
+        grads, radii_all = allgather_reduce_unpacked(bpack, {k: shapes[k] for k in GRAD_KEYS}, group, mode=collective)
+        if gather_images and world > 1:
+            outputs = gather_view_images(outputs, len(cameras), group)
+        return grads, radii_all, outputs
     elif not pipeline:
-        acc = {k: torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev) for k in names}
-        radii_max = torch.zeros(P, dtype=torch.int32, device=dev)
-        for v in mine:
-            g, radii = one_view(v)
-            for k in names:
-                acc[k] += g[k]
-            radii_max = torch.maximum(radii_max, radii)
-        total = allgather_reduce(pack_contribution(acc, radii_max), group, mode=collective)
+        if len(mine) == 1:                    # one view per rank (north_star's configs[2]): the pack comes from the backward itself
+            pack = one_view(mine[0], want_pack=True)
+        else:
+            acc = {k: torch.zeros(shapes[k], dtype=leaves["means3D"].dtype, device=dev) for k in names}
+            radii_max = torch.zeros(P, dtype=torch.int32, device=dev)
+            for v in mine:
+                g, radii = one_view(v)
+                for k in names:
+                    acc[k] += g[k]
+                radii_max = torch.maximum(radii_max, radii)
+            pack = pack_contribution(acc, radii_max)
+        grads, radii_all = allgather_reduce_unpacked(pack, {k: shapes[k] for k in GRAD_KEYS}, group, mode=collective)
+        if gather_images and world > 1:
+            outputs = gather_view_images(outputs, len(cameras), group)
+        return grads, radii_all, outputs
     else:
         # round j: every rank contributes the pack of its view j * world + rank (zeros beyond the last view:
         # x + 0 = x exactly), gathered while round j + 1 is rendered; chained in view order
@@ -266,8 +320,7 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
         for j in range(rounds):
             v = j * world + rank
             if v < len(cameras):
-                g, radii = one_view(v)
-                pack = pack_contribution(g, radii)
+                pack = one_view(v, want_pack=True)
             else:
                 if zero_pack is None:
                     F = sum(int(torch.Size(shapes[k]).numel() // max(P, 1)) for k in GRAD_KEYS) + 1
@@ -280,8 +333,11 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
                 pending = started
             else:
                 total = pack.clone() if total is None else reduce_gathered(pack[None], total)
-        if pending is not None:
-            total = reduce_gathered(pending.result(), total)
+        if pending is not None:                             # the last round's reduction writes the gradient tensors itself
+            grads, radii_all = reduce_gathered_unpacked(pending.result(), total, {k: shapes[k] for k in GRAD_KEYS})
+            if gather_images and world > 1:
+                outputs = gather_view_images(outputs, len(cameras), group)
+            return grads, radii_all, outputs
         if total is None:                                   # no view at all: the zero contribution
             F = sum(int(torch.Size(shapes[k]).numel() // max(P, 1)) for k in GRAD_KEYS) + 1
             total = torch.zeros((P, F), dtype=torch.float32, device=dev)

@@ -280,6 +280,27 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
                                const float* g_sh, const float* g_opac, const float* g_scales,
                                const float* g_rot, const int32_t* radii, float* out, void* stream);
 
+/* v15: the view-parallel step without its pack pass and without its unpack kernels.
+ * hgs_backward_batch_packed = hgs_backward_batch_act whose per-Gaussian kernel writes the gradients of Gaussian i as ONE
+ * row of `pack` [P][15 + 3M] in the layout above (dL/dmeans2D summed over the call's B views in view order, radii = max
+ * over the views, as an exact fp32 integer) instead of six tensors that hgs_pack_view_contribution would read back and
+ * interleave (7.2 MB written + read + written per 100k Gaussians on the exposed path of a step: the pack IS what the
+ * rank sends).  SH + scale / rotation inputs only (the configuration the reference trains: gaussian_renderer/__init__.py:
+ * 57-82 with both pipe flags off); dL_dmeans2D_views [B][P][3] is optional (NULL: not written).  Same status / scratch
+ * rules as hgs_backward*.
+ * hgs_reduce_view_packs_unpack = hgs_reduce_view_packs_acc (acc_in may be NULL) whose result goes straight into the six
+ * gradient tensors + radii [P] int32 (the step's LAST reduction: no [P][F] intermediate, no slicing / rounding kernels). */
+int hgs_backward_batch_packed(const hgs_settings* views, int32_t B, int32_t P, int32_t M, const float* means3D,
+                              const float* shs, const float* opacities, const float* scales, const float* rotations,
+                              const int32_t* radii, const float* out_color, const float* out_depth, const float* out_alpha,
+                              const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha,
+                              const void* geom, const void* bin, const void* img, const hgs_status* status,
+                              int64_t entry_capacity, void* bwd_scratch, float* pack, float* dL_dmeans2D_views,
+                              void* const* stage_events, int32_t activation_flags, void* stream);
+int hgs_reduce_view_packs_unpack(int32_t world, int64_t P, int32_t M, const float* gathered, const float* acc_in,
+                                 float* g_means3D, float* g_means2D, float* g_sh, float* g_opac, float* g_scales,
+                                 float* g_rot, int32_t* radii, void* stream);
+
 /* ---- bookkeeping either side of the path ------------------------------
  * Densification statistics of one training step over B views
  * (/root/reference/threestudio/systems/GaussianDreamer.py:253-256,289,385-391 and

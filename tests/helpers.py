@@ -66,7 +66,8 @@ atexit.register(_dump_parity_log)
 
 
 def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e-4, grad_tol=1e-3,
-                              cos_tol=1e-6, threads=None, minority_caps=True, gate_flip_images=True):
+                              cos_tol=1e-6, threads=None, minority_caps=True, gate_flip_images=True, raise_on_failure=True,
+                              grad_tol_by_key=None):
     """BASELINE.json's parity bar at full size.  `hip` = (color, radii, depth, alpha, grads dict)
     on the CPU; `grads` = the three incoming gradients (or None: forward only).
 
@@ -100,7 +101,7 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
     if not torch.is_grad_enabled():          # the oracle differentiates with autograd
         with torch.enable_grad():
             return check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol, grad_tol, cos_tol, threads,
-                                             minority_caps, gate_flip_images)
+                                             minority_caps, gate_flip_images, raise_on_failure, grad_tol_by_key)
     torch.set_num_threads(threads or max(1, min(os.cpu_count() or 1, 64)))
     c, r, d, a, g = hip
     st = settings_fp32
@@ -168,18 +169,20 @@ def check_against_fp64_oracle(name, cloud, settings_fp32, hip, grads, img_tol=1e
                    "1-cos": 1.0 - cos, "fp32oracle_1-cos": 1.0 - cos32}
             for kk, vv in st_.items():
                 stats[f"grad_{k}_{kk}"] = vv
-            boundB = max(grad_tol, 1.25 * st_["fp32oracle_vs_fp64_nonflip"])
-            gate(st_["vs_fp32oracle_nonflip"] <= grad_tol, k, "A: vs fp32 oracle", st_["vs_fp32oracle_nonflip"])
-            gate(st_["vs_fp32oracle_flip"] <= 10 * grad_tol, k, "A: vs fp32 oracle (flip Gaussians)", st_["vs_fp32oracle_flip"])
+            gtol = (grad_tol_by_key or {}).get(k, grad_tol)      # (per-tensor bound: tests/test_gpu_random_cameras.py)
+            boundB = max(gtol, 1.25 * st_["fp32oracle_vs_fp64_nonflip"])
+            gate(st_["vs_fp32oracle_nonflip"] <= gtol, k, "A: vs fp32 oracle", st_["vs_fp32oracle_nonflip"])
+            gate(st_["vs_fp32oracle_flip"] <= 10 * gtol, k, "A: vs fp32 oracle (flip Gaussians)", st_["vs_fp32oracle_flip"])
             gate(st_["vs_fp64_nonflip"] <= boundB, k, "B: vs fp64 oracle", st_["vs_fp64_nonflip"], boundB)
             # (a flipped threshold decision moves a Gaussian's gradient by a finite step: where the fp32 ORACLE's own step
             #  against fp64 exceeds ten bounds - 1.14e-2 on one Gaussian of configs[2]'s view 5 on the human.obj cloud - the
             #  gate is 1.25 x that step, as for the non-flip Gaussians; gate A above still pins us to the fp32 oracle)
             gate(st_["vs_fp64_flip"] <= max(10 * boundB, 1.25 * st_["fp32oracle_vs_fp64_flip"]), k,
                  "B: vs fp64 oracle (flip Gaussians)", st_["vs_fp64_flip"], st_["fp32oracle_vs_fp64_flip"])
-            gate(1.0 - cos <= max(cos_tol, 2.0 * (1.0 - cos32)), k, "cosine", cos, cos32)
+            gate(1.0 - cos <= max(cos_tol, 2.0 * (1.0 - cos32), gtol * gtol), k, "cosine", cos, cos32)
     stats["failures"] = [list(map(str, f)) for f in failures]
     PARITY_LOG.append(stats)
-    print("PARITY", stats)
-    assert not failures, (name, failures, stats)
+    if raise_on_failure:
+        print("PARITY", stats)
+        assert not failures, (name, failures, stats)
     return stats

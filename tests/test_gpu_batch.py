@@ -539,3 +539,82 @@ def test_scale_gradient_follows_the_fork_by_default_and_the_true_derivative_on_r
             assert float((got[k].double() - want[k]).abs().max()) <= 1e-3 * scale, k
     f, t = hip(0)["scales"], hip(GRAD_SCALE_TRUE_DERIVATIVE)["scales"]
     assert float(t.abs().max()) > 0 and torch.allclose(f * mod, t, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("B,deg,P,H,W", [(1, 0, 1500, 64, 80), (1, 2, 700, 48, 64), (3, 1, 900, 64, 80), (8, 0, 2000, 80, 80)])
+def test_packed_backward_writes_the_pack_the_pack_kernel_would(B, deg, P, H, W):
+    """ABI v15: inside `rasterizer.packed_gradients()` the backward's LAST kernel writes the
+    view-parallel pack itself - [means3D 3 | means2D 3 (summed over the call's views, view order) | sh 3M | opacity 1 |
+    scales 3 | rotations 4 | radii 1 (max over the views)] - and autograd gets strided views of it: bit-identical to
+    `hgs_pack_view_contribution` applied to the six tensors of the ordinary backward; `hgs_reduce_view_packs_unpack` ==
+    reduce + unpack, bit for bit, with and without a running total."""
+    from humangaussian_amd import view_parallel as vp
+    sc = make_scene(P=P, sh_degree=deg, seed=300 + B, H=H, W=W, spread=0.3, scale=0.05)
+    cams = _cams(B, H, W, seed=10 + B)
+    rsl = [_settings(c, torch.tensor([0.1 * b, 0.2, 0.3]), deg) for b, c in enumerate(cams)]
+    gc, gd, ga = _grads(B, H, W, seed=9)
+
+    def run(packed):
+        ins = {k: sc[k].to(DEV).requires_grad_(True) for k in NAMES}
+        if B == 1:
+            m2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+            c, r, d, a = GaussianRasterizer(rsl[0])(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                                    scales=ins["scales"], rotations=ins["rotations"])
+            outs, gouts = [c, d, a], [gc[0], gd[0], ga[0]]
+        else:
+            m2 = torch.zeros(B, P, 3, device=DEV, requires_grad=True)
+            c, r, d, a = rasterize_gaussians_batch(ins["means3D"], m2, ins["shs"], None, ins["opacities"], ins["scales"],
+                                                   ins["rotations"], None, rsl)
+            outs, gouts = [c, d, a], [gc, gd, ga]
+        tens = [ins[k] for k in NAMES] + [m2]
+        if packed:
+            with R.packed_gradients() as pg:
+                gl = torch.autograd.grad(outs, tens, gouts)
+                pack = pg.take()
+        else:
+            gl, pack = torch.autograd.grad(outs, tens, gouts), None
+        g = dict(zip(NAMES + ("means2D",), gl))
+        return g, r, pack
+
+    g0, r0, none = run(False)
+    g1, r1, pack = run(True)
+    assert none is None and pack is not None and pack.shape == (P, 15 + 3 * (deg + 1) ** 2) and pack.is_contiguous()
+    assert R.packed_gradients.take() is None                       # taken once
+    m2sum = g0["means2D"] if B == 1 else g0["means2D"].sum(0)
+    rmax = r0 if B == 1 else r0.max(dim=0).values.to(torch.int32)
+    want = vp.pack_contribution({**{k: g0[k] for k in NAMES}, "means2D": m2sum}, rmax)
+    F = pack.shape[1]
+    cols_m2 = [3, 4, 5]
+    other = [c for c in range(F) if c not in cols_m2]
+    assert torch.equal(pack[:, other], want[:, other])
+    if B == 1:
+        assert torch.equal(pack, want)
+    else:            # (B, P, 3).sum(0) is torch's reduction order; the kernel adds the views in view order
+        assert float((pack[:, cols_m2] - want[:, cols_m2]).abs().max()) <= 1e-6 * max(1e-20, float(want[:, cols_m2].abs().max()))
+        assert torch.equal(g1["means2D"], g0["means2D"])            # the per-view gradients are still handed out
+    # the gradients autograd received are views of the pack with the right values
+    for k in NAMES:
+        assert g1[k].shape == g0[k].shape and torch.equal(g1[k], g0[k]), k
+    if B == 1:
+        assert torch.equal(g1["means2D"], g0["means2D"])
+    # ---- reduce + unpack in one pass == reduce, then unpack
+    gen = torch.Generator().manual_seed(4)
+    gathered = torch.stack([pack, pack * 0.5 + 1.0, pack * -0.25]).contiguous()
+    gathered[:, :, -1] = torch.randint(0, 50, (3, P), generator=gen).float().to(DEV)
+    shapes = {k: g0[k].shape for k in NAMES}
+    shapes["means2D"] = (P, 3)
+    for acc in (None, (pack * 2.0).contiguous()):
+        ref_g, ref_r = vp.unpack_contribution(vp.reduce_gathered(gathered, acc), shapes)
+        got_g, got_r = vp.reduce_gathered_unpacked(gathered, acc, shapes)
+        assert torch.equal(got_r, ref_r) and got_r.dtype == torch.int32
+        for k in vp.GRAD_KEYS:
+            assert got_g[k].is_contiguous() and torch.equal(got_g[k], ref_g[k].contiguous()), k
+    # not eligible (precomputed colours): the ordinary backward runs, nothing to take
+    ins = {k: sc[k].to(DEV).requires_grad_(True) for k in NAMES}
+    cp = torch.rand(P, 3, device=DEV, requires_grad=True)
+    m2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    c, r, d, a = GaussianRasterizer(rsl[0])(means3D=ins["means3D"], means2D=m2, colors_precomp=cp, opacities=ins["opacities"],
+                                            scales=ins["scales"], rotations=ins["rotations"])
+    with R.packed_gradients() as pg:
+        torch.autograd.grad([c], [cp, ins["means3D"]], [gc[0]])
+        assert pg.take() is None

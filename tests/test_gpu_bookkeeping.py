@@ -129,3 +129,72 @@ def test_reanchor_matches_the_reference_numpy_pass():
         got = anchored.positions(verts)
         assert got.is_cuda and got.shape == (P, 3) and got.dtype == torch.float32
         assert np.abs(got.cpu().numpy() - points).max() <= 2e-6
+
+
+def test_densify_and_prune_matches_the_reference_method():
+    """SURVEY 8(f)-3 whole: `densify.densify_and_prune` against the reference's OWN `GaussianModel.densify_and_prune`
+    (gaussian_model.py:410-423 with clone :393-408, split + sampling :359-391, prune :303-318 and the Adam surgery
+    :283-357), recorded in the build container by tests/golden/make_densify_fixture.py: same state in, the reference's
+    normal samples replayed; row order and counts exact, every parameter / Adam moment / statistic <= 1e-6, and the
+    optimizer object ends up holding the new parameters with their moments."""
+    import os
+    import types
+    import numpy as np
+    from humangaussian_amd import densify
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_densify.npz"))
+    dev = torch.device("cuda")
+    groups = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+              ("scaling", "_scaling"), ("rotation", "_rotation"))
+    pc = types.SimpleNamespace()
+    plist = []
+    for name, attr in groups:
+        p = torch.nn.Parameter(torch.from_numpy(fx["in" + attr]).to(dev))
+        setattr(pc, attr, p)
+        plist.append({"params": [p], "lr": 1e-3, "name": name})
+    pc.optimizer = torch.optim.Adam(plist, lr=0.0, eps=1e-15)
+    for name, attr in groups:
+        pc.optimizer.state[getattr(pc, attr)] = {"step": torch.tensor(3.0), "exp_avg": torch.from_numpy(fx["in_exp_avg_" + name]).to(dev),
+                                                 "exp_avg_sq": torch.from_numpy(fx["in_exp_avg_sq_" + name]).to(dev)}
+    pc.xyz_gradient_accum = torch.from_numpy(fx["in_xyz_gradient_accum"]).to(dev)
+    pc.denom = torch.from_numpy(fx["in_denom"]).to(dev)
+    pc.max_radii2D = torch.from_numpy(fx["in_max_radii2D"]).to(dev)
+    max_grad, min_opacity, extent, max_screen_size, pc.percent_dense = (float(x) for x in fx["args"])
+    counts = densify.densify_and_prune(pc, max_grad, min_opacity, extent, max_screen_size,
+                                       split_samples=torch.from_numpy(fx["samples"]))
+    assert counts["children"] == fx["samples"].shape[0] and counts["cloned"] > 20 and counts["split"] > 20 and counts["pruned"] > 20
+    assert counts["points"] == fx["out_xyz"].shape[0]
+    for name, attr in groups:
+        p = getattr(pc, attr)
+        group = next(g for g in pc.optimizer.param_groups if g["name"] == name)
+        assert group["params"][0] is p and isinstance(p, torch.nn.Parameter) and p.requires_grad and p.is_leaf
+        st = pc.optimizer.state[p]
+        assert len(pc.optimizer.state) == 6 and float(st["step"]) == 3.0
+        for got, key in ((p.detach(), "out" + attr), (st["exp_avg"], "out_exp_avg_" + name), (st["exp_avg_sq"], "out_exp_avg_sq_" + name)):
+            want = torch.from_numpy(fx[key])
+            assert got.shape == want.shape, (key, got.shape, want.shape)
+            err = float((got.cpu() - want).abs().max())
+            assert err <= 1e-6 * max(1.0, float(want.abs().max())), (key, err)
+    # survivors and clones are COPIES: bit-exact rows (the row ORDER is the reference's)
+    n_children = fx["samples"].shape[0]
+    assert torch.equal(pc._opacity.detach().cpu(), torch.from_numpy(fx["out_opacity"]))
+    assert torch.equal(pc._rotation.detach().cpu(), torch.from_numpy(fx["out_rotation"]))
+    assert n_children > 0 and not torch.equal(pc._xyz.detach().cpu()[-1], torch.from_numpy(fx["in_xyz"])[-1])
+    for key, got in (("out_xyz_gradient_accum", pc.xyz_gradient_accum), ("out_denom", pc.denom), ("out_max_radii2D", pc.max_radii2D)):
+        assert torch.equal(got.cpu(), torch.from_numpy(fx[key])), key
+    # the optimizer still works on the new parameters
+    for _, attr in groups:
+        getattr(pc, attr).grad = torch.ones_like(getattr(pc, attr))
+    pc.optimizer.step()
+    # a fresh draw (no replayed samples) gives the same counts and different children
+    pc2 = types.SimpleNamespace(percent_dense=pc.percent_dense)
+    plist = []
+    for name, attr in groups:
+        p = torch.nn.Parameter(torch.from_numpy(fx["in" + attr]).to(dev))
+        setattr(pc2, attr, p)
+        plist.append({"params": [p], "lr": 1e-3, "name": name})
+    pc2.optimizer = torch.optim.Adam(plist, lr=0.0, eps=1e-15)       # no state yet: moments appear on the first step
+    pc2.xyz_gradient_accum = torch.from_numpy(fx["in_xyz_gradient_accum"]).to(dev)
+    pc2.denom = torch.from_numpy(fx["in_denom"]).to(dev)
+    pc2.max_radii2D = torch.from_numpy(fx["in_max_radii2D"]).to(dev)
+    c2 = densify.densify_and_prune(pc2, max_grad, min_opacity, extent, max_screen_size)
+    assert c2["cloned"] == counts["cloned"] and c2["split"] == counts["split"] and len(pc2.optimizer.state) == 0

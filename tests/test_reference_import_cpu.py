@@ -151,3 +151,23 @@ def test_our_render_mirror_matches_reference_render_arguments(reference_modules,
         assert getattr(sa, f) == getattr(sb, f), f
     for f in ("bg", "viewmatrix", "projmatrix", "campos"):
         assert torch.equal(getattr(sa, f), getattr(sb, f)), f
+
+
+def test_densify_fixture_is_what_the_reference_method_produces():
+    """tests/golden/reference_densify.npz (what tests/test_gpu_bookkeeping.py replays on the GPU) IS the reference's own
+    `GaussianModel.densify_and_prune` (gaussian_model.py:410-423): re-run here, every array equal."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("make_densify_fixture", os.path.join(ROOT, "tests", "golden", "make_densify_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        res = mod.run()
+    finally:
+        for name in [m for m in sys.modules if m.startswith("gaussiansplatting")]:
+            sys.modules.pop(name, None)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "reference_densify.npz"))
+    assert sorted(fx.files) == sorted(res)
+    for k in fx.files:
+        assert np.array_equal(fx[k], res[k]), k
+    assert res["out_xyz"].shape[0] != res["in_xyz"].shape[0] and res["samples"].shape[0] > 0
