@@ -160,6 +160,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    PARAMS = ("means3D", "shs", "opacities", "scales", "rotations")
+
     class Workload:
         """One rank's step: `views` views of a `P`-Gaussian cloud, fwd (+bwd), single or batched call."""
 
@@ -174,6 +176,8 @@ def main():
                 [camera(j * world + rank) for j in range(seq_views)]
             self.leaves = {k: getattr(cloud, k).to(dev).requires_grad_(True)
                            for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+            self.shapes = {k: self.leaves[k].shape for k in PARAMS}
+            self.shapes["means2D"] = self.leaves["means3D"].shape
             bg = torch.zeros(3, device=dev)
             self.rs = [GaussianRasterizationSettings(
                 RES, RES, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), bg, 1.0, c.world_view_transform.to(dev),
@@ -210,12 +214,14 @@ def main():
                 color, radii, depth, alpha = self.rast(
                     means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
                     rotations=L["rotations"])
-            torch.autograd.backward([color, depth, alpha], [self.gc, self.gd, self.ga])
             if world > 1:
-                grads = {k: L[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")}
-                grads["means2D"] = means2D.grad if self.views == 1 else means2D.grad.sum(0)
-                rad = radii if self.views == 1 else radii.max(dim=0).values
-                return vp.allgather_reduce(vp.pack_contribution(grads, rad), mode=collective_mode[0])
+                # the view-parallel step: the backward's last kernel writes the rank's pack itself (ABI v15: no pack
+                # kernel), one collective, the last reduction writes the six gradient tensors + radii (no unpack kernels)
+                with _rast.packed_gradients() as pg:
+                    torch.autograd.grad([color, depth, alpha], [L[k] for k in PARAMS] + [means2D], [self.gc, self.gd, self.ga])
+                    pack = pg.take()
+                return vp.allgather_reduce_unpacked(pack, self.shapes, mode=collective_mode[0])
+            torch.autograd.backward([color, depth, alpha], [self.gc, self.gd, self.ga])
             return means2D.grad
 
         def step_rounds(self):
@@ -229,20 +235,21 @@ def main():
                 color, radii, depth, alpha = self.rasts[j](
                     means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
                     rotations=L["rotations"])
-                torch.autograd.backward([color, depth, alpha], [self.gc, self.gd, self.ga])
                 if world > 1 and self.collectives:
-                    grads = {k: L[k].grad for k in ("means3D", "shs", "opacities", "scales", "rotations")}
-                    grads["means2D"] = means2D.grad
-                    pack = vp.pack_contribution(grads, radii)
+                    with _rast.packed_gradients() as pg:
+                        torch.autograd.grad([color, depth, alpha], [L[k] for k in PARAMS] + [means2D], [self.gc, self.gd, self.ga])
+                        pack = pg.take()
                     if self.seq_views == 1:
-                        return vp.allgather_reduce(pack, mode=collective_mode[0])
+                        return vp.allgather_reduce_unpacked(pack, self.shapes, mode=collective_mode[0])
                     started = vp.PackGather(pack, async_op=True)
                     if pending is not None:
                         total = vp.reduce_gathered(pending.result(), total)
                     pending = started
+                else:
+                    torch.autograd.backward([color, depth, alpha], [self.gc, self.gd, self.ga])
             if pending is not None:
-                total = vp.reduce_gathered(pending.result(), total)
-            return total if total is not None else means2D.grad
+                return vp.reduce_gathered_unpacked(pending.result(), total, self.shapes)
+            return means2D.grad
 
         def timed(self, steps, warmup, init_steps=None):
             init_steps = args.init_steps if init_steps is None else init_steps
@@ -429,30 +436,28 @@ def main():
     # --collective auto then runs the timed steps with the faster mode (every rank takes the same decision)
     collective = None
     if world > 1:
-        L = main_wl.leaves
-        grads = {k: torch.zeros_like(L[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
-        grads["means2D"] = torch.zeros_like(L["means3D"])
-        rad = torch.ones(P, dtype=torch.int32, device=dev)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        # (no pack pass since ABI v15: the backward's last kernel writes the pack; the timed part is the collective + the
+        #  reduction that also unpacks)
+        pack = torch.zeros((P, 15 + 3 * main_wl.M), device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         nrep = 20
         res = {}
         for mode in vp.COLLECTIVE_MODES:
-            acc = [0.0, 0.0]
+            acc = 0.0
             for it in range(nrep + 5):
                 fence()
                 ev[0].record()
-                pack = vp.pack_contribution(grads, rad)
+                vp.allgather_reduce_unpacked(pack, main_wl.shapes, mode=mode)
                 ev[1].record()
-                vp.allgather_reduce(pack, mode=mode)
-                ev[2].record()
                 torch.cuda.synchronize()
                 if it >= 5:
-                    acc[0] += ev[0].elapsed_time(ev[1])
-                    acc[1] += ev[1].elapsed_time(ev[2])
-            tt = max_over_ranks([a / nrep * 1e3 for a in acc])
-            res[mode] = {"pack_us": tt[0], "collective_and_reduce_us": tt[1]}
+                    acc += ev[0].elapsed_time(ev[1])
+            tt = max_over_ranks([acc / nrep * 1e3])
+            res[mode] = {"pack_us": 0.0, "collective_and_reduce_us": tt[0]}
         if args.collective == "auto":
             collective_mode[0] = min(vp.COLLECTIVE_MODES, key=lambda m: res[m]["collective_and_reduce_us"])
+            if not all(math.isfinite(res[m]["collective_and_reduce_us"]) and res[m]["collective_and_reduce_us"] > 0 for m in res):
+                collective_mode[0] = "scatter" if world >= 8 else "allgather"      # (no usable timing: the fewer-bytes form at 8 ranks)
         # what the collectives ADD to a step, measured: the same step with and without them (outside the timed region),
         # for one view per rank (nothing to overlap: the per-Gaussian backward that produces the gradients is the last
         # kernel of the step) and for two (round 0's all-gather runs under round 1's render)

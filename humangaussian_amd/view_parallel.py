@@ -162,6 +162,14 @@ def scatter_reduce_gather(pack: torch.Tensor, group=None) -> torch.Tensor:
 COLLECTIVE_MODES = ("allgather", "scatter")
 
 
+def default_collective(world: int) -> str:
+    """What "auto" means where nobody has timed the two modes on the node at hand: the single all-gather up to four ranks,
+    `scatter` from eight ranks on - per rank (world - 1) packs cross the point-to-point xGMI links in an all-gather, 2
+    (world - 1) / world in the scatter form (7 vs 1.75 packs at world 8), for one more collective's latency.
+    (bench.py --collective auto times both and takes the faster one.)"""
+    return "scatter" if world >= 8 else "allgather"
+
+
 def allgather_reduce_unpacked(pack: torch.Tensor, shapes: Dict[str, torch.Size], group=None, mode: str = "allgather"):
     """`allgather_reduce` + `unpack_contribution` with the last reduction and the unpack as ONE pass where the mode ends
     in a local reduction of gathered packs (mode "allgather"; "scatter" ends in an all-gather of reduced shards: its
@@ -217,6 +225,8 @@ def render_views_parallel(cameras: Sequence, params: Dict[str, torch.Tensor], bg
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     mine = shard_views(len(cameras), rank, world)
     rounds = (len(cameras) + world - 1) // world
+    if collective == "auto":
+        collective = default_collective(world) if not pipeline else "allgather"
     if batched and pipeline:
         raise ValueError("batched=True renders the rank's views in one call: there are no rounds to pipeline")
     if pipeline is None:                                    # (an explicit collective mode is honoured: it needs the one-collective form)

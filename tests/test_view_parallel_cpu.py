@@ -317,3 +317,26 @@ def test_animation_frames_without_a_process_group_is_the_plain_loop():
     from humangaussian_amd import animation as an
     got = list(an.render_frames_parallel(range(5), _frame_image))
     assert [i for i, _ in got] == list(range(5)) and all(torch.equal(img, _frame_image(i)) for i, img in got)
+
+
+def test_auto_collective_rule_and_fused_unpack_fallback():
+    """`collective="auto"` without a timing at hand: all-gather up to four ranks, scatter from eight on (7 vs
+    1.75 packs per rank on the xGMI links at world 8); on tensors that are not on a HIP device the fused reduce + unpack is
+    reduce, then unpack (the same bits)."""
+    assert [vp.default_collective(w) for w in (1, 2, 4, 8, 16)] == ["allgather", "allgather", "allgather", "scatter", "scatter"]
+    g = torch.Generator().manual_seed(0)
+    P, M = 40, 4
+    gathered = torch.randn(3, P, 15 + 3 * M, generator=g)
+    gathered[:, :, -1] = torch.randint(0, 30, (3, P), generator=g).float()
+    shapes = {"means3D": (P, 3), "means2D": (P, 3), "shs": (P, M, 3), "opacities": (P, 1), "scales": (P, 3), "rotations": (P, 4)}
+    for acc in (None, torch.randn(P, 15 + 3 * M, generator=g).abs()):
+        ref_g, ref_r = vp.unpack_contribution(vp.reduce_gathered(gathered, acc), shapes)
+        got_g, got_r = vp.reduce_gathered_unpacked(gathered, acc, shapes)
+        assert torch.equal(got_r, ref_r)
+        for k in vp.GRAD_KEYS:
+            assert torch.equal(got_g[k], ref_g[k]) and got_g[k].shape == torch.Size(shapes[k])
+    # one rank, no process group: "auto" resolves and the step runs
+    sc, cams, params = _scene_and_cams()
+    grads, radii, outs = vp.render_views_parallel(cams[:2], params, sc["bg"].double(), 1, _loss_grad, render_fn=_oracle_render_fn,
+                                                  collective="auto", pipeline=False)
+    assert len(outs) == 2 and radii.dtype == torch.int32 and grads["means3D"].shape == params["means3D"].shape
