@@ -579,6 +579,13 @@ def main():
                 "hgs_forward_batch / hgs_backward_batch call per step; Gaussians/s = 8 * P / step time", roof=("8views_", P, M, 8))
         measure("init_variant", Workload(P, sh_degree, "init", 1, False, 0), max(20, args.steps // 3), max(5, args.warmup // 2),
                 P, "configs[1] with the step-0 cloud (opacity 0.1, isotropic scales, identity rotations: no early termination)")
+        # the same step with autograd's backward on the CALLING thread (torch.autograd.set_multithreading_enabled(False): no
+        # hand-off to the device's engine thread and back): a host-side setting of the caller, the same kernels; it moves
+        # the step only where the host is the slower side
+        with torch.autograd.set_multithreading_enabled(False):
+            measure("single_thread_autograd", Workload(P, sh_degree, "mid", 1, False, 0), max(20, args.steps // 3), max(5, args.warmup // 2),
+                    P, "configs[1], the headline step with torch.autograd.set_multithreading_enabled(False) (the backward runs on "
+                       "the calling thread); the headline keeps torch's default")
         measure("forward_only", Workload(P, sh_degree, "mid", 1, True, 0), max(20, args.steps // 3), max(5, args.warmup // 2),
                 P, "configs[4] shape: no-grad forward of one 1024^2 view (animation path), per GPU")
         measure("drop_in_render", DropInWorkload(P), max(20, args.steps // 3), max(5, args.warmup // 2), P,

@@ -54,7 +54,9 @@ hgs_k_tiles(View v, Layout L) {
         for (int k = 0; k < BR; ++k) c[k] = (r + k < r1) ? col[(size_t)(r + k) * v.T] : 0u;
 #pragma unroll
         for (int k = 0; k < BR; ++k) {
-          if (r + k < r1) col[(size_t)(r + k) * v.T] = run;
+          // (a row that has no entry in this tile keeps its 0: hgs_k_fill never uses the base of a tile its chunk does not
+          //  touch, and seven of eight histogram words are such zeros - the stores were half of this kernel's traffic)
+          if (r + k < r1 && c[k]) col[(size_t)(r + k) * v.T] = run;
           run += c[k];
         }
       }

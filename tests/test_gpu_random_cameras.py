@@ -233,7 +233,7 @@ def test_backward_cuts_drop_no_gradient_row(both_builds):
 
 
 # The oracle gate.  north_star's 1e-3 of max|g| holds for the tensors the base noise reaches directly (means2D, SH, opacity:
-# measured <= 5e-5 against the fp32 AND the fp64 oracle on all 48 cameras); means3D / scales / rotations carry the
+# measured <= 2.8e-4 against the fp32 AND the fp64 oracle on all 48 cameras); means3D / scales / rotations carry the
 # (length / width)^2 amplification of the comment above - two thirds of the 48 cameras stay below 1e-3 there (the test prints
 # the count), the worst (a grazing
 # camera, every tile lists 4 800 of the 5 000 Gaussians) measures 2.5e-2, where the fp32 oracle itself is 2.4e-4 from fp64

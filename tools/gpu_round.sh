@@ -9,6 +9,7 @@
 #                         for configs[1], configs[3] and the 8-view batched call; three SQ-counter passes for configs[1]
 #                         -> gpurun_out/r06_*; copy what is to be judged into profiles/
 #   timeline NAME         device timelines of a -DHGS_TIMELINE variant (tools/timeline.py)      -> gpurun_out/timeline_NAME.txt
+#   gap                   per-kernel GPU idle gaps of a step (kernel + HIP-call trace, tools/gap_trace.py) -> gpurun_out/r06_gap_trace.txt
 # Modes can be chained:  bash tools/gpu_round.sh quick -- ab a b -- profile abc123
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -119,6 +120,13 @@ print("valu_busy", {k: round(v, 3) for k, v in busy.items()})
 PY
   for t in $TAG ${TAG}_cfg3 ${TAG}_8views; do echo "-- $t traffic"; python -c "
 import json;d=json.load(open('$O/${t}_pmc_traffic.json'));print({k:round(v/1e6,1) for k,v in d.items() if not k.startswith('_')})"; done
+}
+
+mode_gap() {   # kernel-trace + HIP-call trace of the bench loop -> per-kernel idle gaps (tools/gap_trace.py); no counters in this run
+  cd /tmp; export TMPDIR=/tmp
+  timeout 300 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/gap_$TAG -o run -- python $R/bench.py --no-cpu-baseline --no-extra --steps 100 --warmup 10 > $O/gap_$TAG.log 2>&1
+  python $R/tools/gap_trace.py $O/gap_$TAG > $O/${TAG}_gap_trace.txt 2>&1; cat $O/${TAG}_gap_trace.txt
+  rm -rf $O/gap_$TAG
 }
 
 mode_timeline() {
