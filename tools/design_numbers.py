@@ -1,5 +1,5 @@
-"""Per-kernel roofline table of DESIGN.md section 4 from the committed artifacts (profiles/r05_kernel_stats.csv,
-profiles/r05_pmc_traffic.json, profiles/r05_bench.json): rewrites the block between the KTABLE markers and prints the
+"""Per-kernel roofline table of DESIGN.md section 4 from the committed artifacts (profiles/r06_kernel_stats.csv,
+profiles/r06_pmc_traffic.json, profiles/r06_bench.json): rewrites the block between the KTABLE markers and prints the
 numbers the prose quotes.  python tools/design_numbers.py [--write]"""
 import csv
 import json
@@ -8,13 +8,13 @@ import re
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-b = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+b = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
 R, P, M, npix, T = b["config"]["num_rendered_R"], 100000, 1, 1 << 20, 4096
 alg = {"preprocess_fwd": P * (44 + 12 * M + 76), "tiles": 8 * T, "fill": P * 16 + 12 * R, "sort": 24 * R,
        "render_fwd": 44 * R + 24 * npix, "render_bwd": 44 * R + 28 * npix, "pair_reduce": 40 * R,
        "preprocess_bwd": P * (60 + 12 * M + 44 + 12 * M) + P * 76 + 40 * R}
-tr = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))
-dur = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_kernel_stats.csv")))}
+tr = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))
+dur = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_stats.csv")))}
 names = {"preprocess_fwd": "hgs_k_preprocess_fwd", "tiles": "hgs_k_tiles", "fill": "hgs_k_fill", "sort": "hgs_k_sort_lds",
          "render_fwd": "hgs_k_render_fwd_store", "render_bwd": "hgs_k_render_bwd", "pair_reduce": "hgs_k_pair_reduce_em",
          "preprocess_bwd": "hgs_k_preprocess_bwd_s0"}
