@@ -1137,20 +1137,7 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
 #pragma unroll
     for (int u = 0; u < GU; ++u) HGS_RANK_ISSUE(A, u, keyp[u]);
     if (n <= 2u * NT) degenerate = rank_keys<2, NT>(L, start, n, NB, keyp, pairs, R);
-    else if (n <= 4u * NT) {
-#ifdef HGS_SORT_PREB
-      // lists of 513 .. 1024 entries (a fifth of a view's tiles, and the ones the kernel's tail is made of once the seven
-      // heaviest are gone): the thread's keys 2 and 3 - round B of the record phase - send their gathers out before the
-      // ranking as well (the keys are re-read by rank_keys: L2 hits)
-#pragma unroll
-      for (int u = 0; u < GU; ++u) {
-        const uint32_t k = (uint32_t)(GU + u) * NT + (uint32_t)tid;
-        const u64 kv = L.keys[start + min(k, n - 1u)];
-        HGS_RANK_ISSUE(B, u, (k < n) ? kv : ~0ull);
-      }
-#endif
-      degenerate = rank_keys<4, NT>(L, start, n, NB, keyp, pairs, R);
-    }
+    else if (n <= 4u * NT) degenerate = rank_keys<4, NT>(L, start, n, NB, keyp, pairs, R);
     else degenerate = rank_keys<8, NT>(L, start, n, NB, keyp, pairs, R);
   } else {
     degenerate = rank_keys_stream<NT>(L, start, n, NB, pairs, R);
@@ -1199,21 +1186,9 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
     }
   }
   const uint32_t per_round = (uint32_t)GU * NT;
-#ifdef HGS_SORT_PREB
-  const bool preb = early && !degenerate && n > per_round && n <= 4u * NT;     // round B's records are already in flight
-  if (preb) {
-#pragma unroll
-    for (int u = 0; u < GU; ++u) {
-      const uint32_t k = (uint32_t)(GU + u) * NT + (uint32_t)tid;
-      Bpr[u] = (k < n) ? pairs[k] : ~0ull;
-    }
-  }
-#else
-  const bool preb = false;
-#endif
   for (uint32_t r = 0; r * per_round < n; r += 2u) {       // (workgroup-uniform trip count)
     const bool hb = (r + 1u) * per_round < n, ha = (r + 2u) * per_round < n;
-    if (hb && !(preb && r == 0u)) { HGS_RANK_ROUND(B, r + 1u) }
+    if (hb) { HGS_RANK_ROUND(B, r + 1u) }
     HGS_RANK_CONSUME(A)
     if (ha) { HGS_RANK_ROUND(A, r + 2u) }
     if (hb) { HGS_RANK_CONSUME(B) }
