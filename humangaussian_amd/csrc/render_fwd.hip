@@ -29,10 +29,13 @@
 
 namespace {
 
+typedef float hgs_fwd_f32x2 __attribute__((ext_vector_type(2)));
+
 struct PixState {
-  float T;          // running transmittance; 0 once the pixel has terminated (or lies outside the image)
-  float Tout;       // transmittance after the last blended record (what the background sees)
-  float C0, C1, C2, D, Wt;
+  hgs_fwd_f32x2 C01, C2D;       // (C0 C1), (C2 D): updated as pairs - v_pk_fma_f32 - written out explicitly (left to the
+  float Wt;                     //  SLP vectoriser the packing came and went with unrelated edits of this function)
+  float T;          // running transmittance while the pixel is alive (> 0); once it has terminated: MINUS the transmittance
+                    // behind its last blended record (what the background sees); 0 outside the image
   uint32_t last;
 };
 
@@ -40,8 +43,10 @@ struct PixState {
 // position in the TILE's list (upstream's `contributor` count); pad records have opacity 0 and never blend.
 //
 // Upstream's rule - skip (power > 0 or alpha < 1/255), stop at test_T < 1e-4 WITHOUT blending that Gaussian,
-// nothing behind it counts - as arithmetic on ONE carried value: a terminated pixel's T becomes 0, so every
-// later test_T is 0 < 1e-4 and blends nothing.  The carried chain per record is v_mul -> v_cmp -> v_cndmask;
+// nothing behind it counts - as arithmetic on ONE carried value: a terminated pixel's T turns NEGATIVE (it keeps its
+// magnitude: the transmittance the background sees), so every later test_T is <= 0 < 1e-4 and blends nothing.  (Until
+// round 6 it became 0 and a second carried value, updated per record, remembered the magnitude: one v_cndmask per
+// record more for the same bits.)  The carried chain per record is v_mul -> v_cmp -> v_cndmask;
 // with a separate `done` flag it ran through four scalar mask operations per record (VALU -> SALU -> VALU
 // round trips), which is what a wave alone on its SIMD - the tail of this kernel - was waiting for.
 // Same values as the flag formulation, bit for bit (a skipped record multiplies T by exactly 1).
@@ -53,14 +58,12 @@ __device__ __forceinline__ void blend_one(PixState& s, float pxf, float pyf, con
   const float test_T = s.T * (1.0f - ak);
   const bool ok = test_T >= HGS_T_EPS;                  // false from the terminating record on
   const float wgt = ok ? ak * s.T : 0.0f;
-  s.T = ok ? test_T : 0.0f;
+  s.T = ok ? test_T : -__builtin_fabsf(s.T);            // (a skipped record: ak = 0, test_T = T: nothing changes)
   const bool upd = keep && ok;
-  s.C0 = __builtin_fmaf(r1.z, wgt, s.C0);
-  s.C1 = __builtin_fmaf(r1.w, wgt, s.C1);
-  s.C2 = __builtin_fmaf(r2.x, wgt, s.C2);
-  s.D = __builtin_fmaf(r2.y, wgt, s.D);
+  const hgs_fwd_f32x2 rg = {r1.z, r1.w}, bd = {r2.x, r2.y}, w2 = {wgt, wgt};
+  s.C01 = __builtin_elementwise_fma(rg, w2, s.C01);
+  s.C2D = __builtin_elementwise_fma(bd, w2, s.C2D);
   s.Wt += wgt;
-  s.Tout = upd ? test_T : s.Tout;
   s.last = upd ? __float_as_uint(r2.w) : s.last;
 }
 
@@ -85,12 +88,14 @@ __device__ __forceinline__ float hgs_xor32(float x, int lane) {
   const hgs_u32x2 s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float((lane & 32) ? s2.x : s2.y);
 }
-// sum / min / max over the four rows (lanes l, l ^ 16, l ^ 32, l ^ 48), same association in every lane
+// sum over the four rows (lanes l, l ^ 16, l ^ 32, l ^ 48), same association in every lane: (row 0 + row 1) + (row 2 + row 3)
+// (the swap leaves "even row" / "odd row" of a pair in its two results in BOTH rows: no partner select)
 __device__ __forceinline__ float hgs_rows_sum(float x, int lane) {
-  const float p = hgs_xor16(x, lane);
-  const float s01 = (lane & 16) ? p + x : x + p;          // row (even) + row (odd)
-  const float q = hgs_xor32(s01, lane);
-  return (lane & 32) ? q + s01 : s01 + q;                 // rows (0 + 1) + rows (2 + 3)
+  (void)lane;
+  const hgs_u32x2 s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float s01 = __uint_as_float(s16.x) + __uint_as_float(s16.y);       // row (even) + row (odd)
+  const hgs_u32x2 s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s01), false, false);
+  return __uint_as_float(s32.x) + __uint_as_float(s32.y);                  // rows (0 + 1) + rows (2 + 3)
 }
 
 template <bool STORE>
@@ -165,11 +170,17 @@ __device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L,
       const bool keep = hgs_eval_alpha(ra.x - pxf, ra.y - pyf, ra.z, ra.w, rb.x, rb.y, G, alpha, m2, m3);
       const float ak = keep ? alpha : 0.0f;
       const float a = 1.0f - ak;
-      // exclusive prefix of a over the four rows of this pixel, and the product of all four
-      const float p1 = hgs_xor16(a, lane);
-      const float p01 = a * p1;                            // rows (0, 1) or (2, 3): the same value in both rows
-      const float q = hgs_xor32(p01, lane);
-      const float excl = ((lane & 16) ? p1 : 1.0f) * ((lane & 32) ? q : 1.0f);
+      // exclusive prefix of a over the four rows of this pixel, and the product of all four.  v_permlane16_swap(a, a)
+      // leaves the EVEN row's value of every row pair in its first result and the ODD row's in the second - in both rows
+      // - so the pair's product needs no "which one is my partner" select (nor does the four-row product behind
+      // v_permlane32_swap): two v_cndmask per iteration less than partner = select(...), a * partner; the same products
+      // (multiplication commutes: the same bits).
+      const hgs_u32x2 s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+      const float a_even = __uint_as_float(s16.x), a_odd = __uint_as_float(s16.y);
+      const float p01 = a_even * a_odd;                    // rows (0, 1) or (2, 3): the same value in both rows
+      const hgs_u32x2 s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p01), __float_as_uint(p01), false, false);
+      const float p_lo = __uint_as_float(s32.x), p_hi = __uint_as_float(s32.y);      // rows (0, 1) / rows (2, 3), in every row
+      const float excl = ((lane & 16) ? a_even : 1.0f) * ((lane & 32) ? p_lo : 1.0f);
       const float Tb = T * excl;                           // transmittance in front of this record
       const float test_T = Tb * a;
       const bool ok = test_T >= HGS_T_EPS;
@@ -189,7 +200,7 @@ __device__ __forceinline__ void render_fwd_cell4(const View& v, const Layout& L,
       const uint32_t ok2 = (uint32_t)okm & (uint32_t)(okm >> 32);          // rows 0 & 2 | rows 1 & 3
       const uint32_t ok4 = (ok2 & (ok2 >> 16) & 0xffffu) * 0x10001u;       // all four rows, in both halves
       const bool go = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)ok4 << 32) | ok4);
-      T = go ? T * (p01 * q) : 0.0f;
+      T = go ? T * (p_lo * p_hi) : 0.0f;
       ra = na; rb = nb; rc = nc;
     }
   }
@@ -278,7 +289,8 @@ __device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L,
 
   PixState s;
   s.T = inside ? 1.0f : 0.0f;
-  s.Tout = 1.0f; s.C0 = s.C1 = s.C2 = s.D = s.Wt = 0.f;
+  s.C01 = s.C2D = (hgs_fwd_f32x2){0.f, 0.f};
+  s.Wt = 0.f;
   s.last = 0;
 
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -300,12 +312,12 @@ __device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L,
 
   for (uint32_t it0 = 0;; it0 += HGS_RB) {
     // rows still at work: list not exhausted and a pixel not finished
-    const unsigned long long act = __ballot((it0 < len) && (s.T != 0.0f));
+    const unsigned long long act = __ballot((it0 < len) && (s.T > 0.0f));
     if (act == 0ull) break;
     const bool row_on = ((act >> (lane & 48)) & 0xffffull) != 0ull;
     if (STORE && row_on && it0 > 0 && (it0 % HGS_SEGLEN) == 0) {
       float* cs = cstate + (size_t)(sbase + it0 / HGS_SEGLEN - 1) * HGS_CSTATE_FLOATS + i;
-      cs[0 * 16] = s.T; cs[1 * 16] = s.C0; cs[2 * 16] = s.C1; cs[3 * 16] = s.C2; cs[4 * 16] = s.D; cs[5 * 16] = s.Wt;
+      cs[0 * 16] = s.T; cs[1 * 16] = s.C01.x; cs[2 * 16] = s.C01.y; cs[3 * 16] = s.C2D.x; cs[4 * 16] = s.C2D.y; cs[5 * 16] = s.Wt;
     }
     __builtin_amdgcn_wave_barrier();                 // the previous batch's LDS reads are done
     c1.y = (__float_as_uint(c2.w) == 0xffffffffu) ? 0.0f : c1.y;      // pad record: never blends
@@ -356,10 +368,11 @@ __device__ __forceinline__ void render_fwd_cells(const View& v, const Layout& L,
   if (inside) {
     const float* __restrict__ bg = v.cam[bview].bg;
     const size_t pix = (size_t)py * v.W + px, o1 = (size_t)bview * HW, o3 = 3 * o1;
-    out_color[o3 + 0 * HW + pix] = s.C0 + s.Tout * bg[0];
-    out_color[o3 + 1 * HW + pix] = s.C1 + s.Tout * bg[1];
-    out_color[o3 + 2 * HW + pix] = s.C2 + s.Tout * bg[2];
-    out_depth[o1 + pix] = s.D;
+    const float Tout = __builtin_fabsf(s.T);          // transmittance behind the last blended record
+    out_color[o3 + 0 * HW + pix] = s.C01.x + Tout * bg[0];
+    out_color[o3 + 1 * HW + pix] = s.C01.y + Tout * bg[1];
+    out_color[o3 + 2 * HW + pix] = s.C2D.x + Tout * bg[2];
+    out_depth[o1 + pix] = s.C2D.y;
     out_alpha[o1 + pix] = s.Wt;
     L.n_contrib[o1 + pix] = s.last;
   }
