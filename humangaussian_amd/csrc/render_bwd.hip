@@ -437,8 +437,9 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
 // contiguous range (inside a tile): the wave streams it through LDS with fully coalesced 8 B loads, 128 rows at a
 // time, and every lane (= entry) then adds its own rows from LDS in order.  (Per-thread row loads - 48 B at a
 // stride of ~170 B per lane - reached 3 TB/s; at 8 views the 456 MB of pair rows made this the second-largest
-// kernel of the step.)  A wave whose entries straddle two tiles (pair ranges apart) takes the per-thread path.
+// kernel of the step.)  A wave whose entries straddle tiles (pair ranges apart) streams one run per tile.
 #define HGS_RED_ROWS 128
+#define HGS_RED_RUNS 4      // contiguous runs a wave streams before its lanes fall back to gathering their own rows
 extern "C" __global__ void __launch_bounds__(256)
 hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, const SortRec* __restrict__ recs_all,
                   const float* __restrict__ pair_rows, float* __restrict__ grad_rows, uint32_t pair_cap, uint32_t R_host) {
@@ -462,23 +463,34 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
   const bool poisoned = (uint32_t)L.ctr->alloc_ps > pair_cap;
   const uint32_t cnt = poisoned ? 0u : ep.x >> 27;
   const uint32_t incl = hgs_wave_incl_scan(cnt), off = incl - cnt;
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   float2 s0 = make_float2(0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
-  // contiguous?  every entry with pairs must sit at (first pair of the wave) + (pairs of the lanes before it)
-  const unsigned long long withp = __ballot(cnt != 0u);
-  if (withp != 0ull) {
-    const int first = __builtin_ctzll(withp);
+  // RUNS of contiguous rows: inside a tile the pair ids are entry-major, so the rows of the wave's entries of ONE tile are one
+  // range (an entry with pairs sits at the run's first row + the pairs of the lanes before it); a wave whose 64 entries
+  // straddle a tile boundary (one in five: tiles hold ~360 entries) has two runs.  Every run is streamed the same way.
+  // (The straddling waves used to take a per-thread path - a lane loading its own rows, up to 16 dependent-in-time rounds of
+  // five 8 B loads: those waves WERE the kernel's length.)  More than HGS_RED_RUNS runs (tiles of a few entries): the lanes
+  // that are left gather their rows themselves.
+  unsigned long long todo = __ballot(cnt != 0u);
+  float2* __restrict__ sl = s_rows[w];
+  for (int run = 0; run < HGS_RED_RUNS && todo != 0ull; ++run) {          // (wave-uniform)
+    const int first = __builtin_ctzll(todo);
     const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(ep.y - off), first);
-    const bool contiguous = __ballot(cnt != 0u && ep.y - off != base) == 0ull;
-    if (contiguous) {
-      const float2* __restrict__ src = reinterpret_cast<const float2*>(pair_rows) + (size_t)base * HGS_PROW_F2;
-      float2* __restrict__ sl = s_rows[w];
-      // double buffered through registers: the loads of tile t + 1 are in flight while tile t is summed (a wave has
-      // ~3 tiles; one after the other their load latency was most of the kernel's 20 us)
-      static_assert(HGS_RED_ROWS * HGS_PROW_F2 == 10 * 64, "ten float2 per lane and tile");
-      float2 b0, b1, b2, b3, b4, b5, b6, b7, b8, b9;   // (named registers: an array here went to scratch memory)
-      // (no branch around the loads: behind the last tile every lane re-reads element 0 - one cache line; a
-      // conditional block made the compiler wait for the loads where they are issued)
+    const bool mine = cnt != 0u && ep.y - off == base;
+    const unsigned long long in_run = __ballot(mine);
+    todo &= ~in_run;
+    const int lastl = 63 - __builtin_clzll(in_run);
+    // rows [r_lo, r_hi) behind `base` hold the run (and, between two lanes of it, nothing else: equality with `base` is contiguity)
+    const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readlane((int)off, first);
+    const uint32_t r_hi = (uint32_t)__builtin_amdgcn_readlane((int)incl, lastl);
+    const uint32_t total = r_hi - r_lo;
+    const uint32_t moff = off - r_lo, mcnt = mine ? cnt : 0u;               // this lane's rows inside the run (moff wraps for lanes outside: mcnt = 0)
+    const float2* __restrict__ src = reinterpret_cast<const float2*>(pair_rows) + (size_t)(base + r_lo) * HGS_PROW_F2;
+    // double buffered through registers: the loads of tile t + 1 are in flight while tile t is summed (a wave has
+    // ~3 tiles; one after the other their load latency was most of the kernel's 20 us)
+    static_assert(HGS_RED_ROWS * HGS_PROW_F2 == 10 * 64, "ten float2 per lane and tile");
+    float2 b0, b1, b2, b3, b4, b5, b6, b7, b8, b9;   // (named registers: an array here went to scratch memory)
+    // (no branch around the loads: behind the last tile every lane re-reads element 0 - one cache line; a
+    // conditional block made the compiler wait for the loads where they are issued)
 #define HGS_RED_ISSUE(T0)                                                                                      \
   {                                                                                                            \
     const uint32_t t0n__ = (T0);                                                                               \
@@ -491,25 +503,26 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
     b6 = p__[min((uint32_t)lane + 384u, last__)]; b7 = p__[min((uint32_t)lane + 448u, last__)];                \
     b8 = p__[min((uint32_t)lane + 512u, last__)]; b9 = p__[min((uint32_t)lane + 576u, last__)];                \
   }
-      HGS_RED_ISSUE(0u);
-      for (uint32_t t0 = 0; t0 < total; t0 += HGS_RED_ROWS) {
-        const uint32_t nrow = min((uint32_t)HGS_RED_ROWS, total - t0);
-        const uint32_t nfl = nrow * HGS_PROW_F2;
-        __builtin_amdgcn_wave_barrier();               // the previous tile's LDS reads are done
-        if ((uint32_t)lane < nfl) sl[lane] = b0;
-        if ((uint32_t)lane + 64u < nfl) sl[lane + 64] = b1;
-        if ((uint32_t)lane + 128u < nfl) sl[lane + 128] = b2;
-        if ((uint32_t)lane + 192u < nfl) sl[lane + 192] = b3;
-        if ((uint32_t)lane + 256u < nfl) sl[lane + 256] = b4;
-        if ((uint32_t)lane + 320u < nfl) sl[lane + 320] = b5;
-        if ((uint32_t)lane + 384u < nfl) sl[lane + 384] = b6;
-        if ((uint32_t)lane + 448u < nfl) sl[lane + 448] = b7;
-        if ((uint32_t)lane + 512u < nfl) sl[lane + 512] = b8;
-        if ((uint32_t)lane + 576u < nfl) sl[lane + 576] = b9;
-        HGS_RED_ISSUE(t0 + HGS_RED_ROWS);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t r_begin = max(off, t0), r_end = min(off + cnt, t0 + nrow);
+    HGS_RED_ISSUE(0u);
+    for (uint32_t t0 = 0; t0 < total; t0 += HGS_RED_ROWS) {
+      const uint32_t nrow = min((uint32_t)HGS_RED_ROWS, total - t0);
+      const uint32_t nfl = nrow * HGS_PROW_F2;
+      __builtin_amdgcn_wave_barrier();               // the previous tile's LDS reads are done
+      if ((uint32_t)lane < nfl) sl[lane] = b0;
+      if ((uint32_t)lane + 64u < nfl) sl[lane + 64] = b1;
+      if ((uint32_t)lane + 128u < nfl) sl[lane + 128] = b2;
+      if ((uint32_t)lane + 192u < nfl) sl[lane + 192] = b3;
+      if ((uint32_t)lane + 256u < nfl) sl[lane + 256] = b4;
+      if ((uint32_t)lane + 320u < nfl) sl[lane + 320] = b5;
+      if ((uint32_t)lane + 384u < nfl) sl[lane + 384] = b6;
+      if ((uint32_t)lane + 448u < nfl) sl[lane + 448] = b7;
+      if ((uint32_t)lane + 512u < nfl) sl[lane + 512] = b8;
+      if ((uint32_t)lane + 576u < nfl) sl[lane + 576] = b9;
+      HGS_RED_ISSUE(t0 + HGS_RED_ROWS);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (mcnt) {
+        const uint32_t r_begin = max(moff, t0), r_end = min(moff + mcnt, t0 + nrow);
         for (uint32_t r = r_begin; r < r_end; ++r) {
           const float2* q = sl + HGS_PROW_F2 * (r - t0);
           const float2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
@@ -517,14 +530,17 @@ hgs_k_pair_reduce_em(View v, Layout L, const hgs_status* __restrict__ status, co
           s3.x += a3.x; s3.y += a3.y; s4.x += a4.x; s4.y += a4.y;
         }
       }
-    } else {
-      const float2* __restrict__ rows = reinterpret_cast<const float2*>(pair_rows) + (size_t)ep.y * HGS_PROW_F2;
-      for (uint32_t r = 0; r < cnt; ++r) {
-        const float2* q = rows + HGS_PROW_F2 * r;
-        const float2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
-        s0.x += a0.x; s0.y += a0.y; s1.x += a1.x; s1.y += a1.y; s2.x += a2.x; s2.y += a2.y;
-        s3.x += a3.x; s3.y += a3.y; s4.x += a4.x; s4.y += a4.y;
-      }
+    }
+#undef HGS_RED_ISSUE
+  }
+  if (todo != 0ull) {
+    const bool left = ((todo >> lane) & 1ull) != 0ull;
+    const float2* __restrict__ rows = reinterpret_cast<const float2*>(pair_rows) + (size_t)ep.y * HGS_PROW_F2;
+    for (uint32_t r = 0; r < (left ? cnt : 0u); ++r) {
+      const float2* q = rows + HGS_PROW_F2 * r;
+      const float2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+      s0.x += a0.x; s0.y += a0.y; s1.x += a1.x; s1.y += a1.y; s2.x += a2.x; s2.y += a2.y;
+      s3.x += a3.x; s3.y += a3.y; s4.x += a4.x; s4.y += a4.y;
     }
   }
   if (have) {
