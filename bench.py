@@ -293,9 +293,9 @@ def main():
     class DropInWorkload:
         """The reference-shaped call: renderer.render(camera, GaussianModel-like, pipe, bg) on RAW parameters."""
 
-        def __init__(self, P):
+        def __init__(self, P, fuse=False):
             from humangaussian_amd import renderer
-            self.renderer = renderer
+            self.renderer, self.fuse = renderer, fuse
             cloud = synth.init_cloud(P, 0, "mid", seed=0, source=args.cloud)
             raw = {"_xyz": cloud.means3D, "_features_dc": cloud.shs[:, :1], "_features_rest": cloud.shs[:, 1:],
                    "_opacity": torch.logit(cloud.opacities.clamp(1e-6, 1 - 1e-6)), "_scaling": torch.log(cloud.scales),
@@ -305,6 +305,8 @@ def main():
 
             class Model:           # gaussian_model.py:95-115
                 active_sh_degree = max_sh_degree = 0
+                _opacity, _scaling, _rotation = leaves["_opacity"], leaves["_scaling"], leaves["_rotation"]
+                _features_dc, _features_rest = leaves["_features_dc"], leaves["_features_rest"]
                 get_xyz = property(lambda m: leaves["_xyz"])
                 get_features = property(lambda m: torch.cat((leaves["_features_dc"], leaves["_features_rest"]), dim=1))
                 get_opacity = property(lambda m: torch.sigmoid(leaves["_opacity"]))
@@ -327,7 +329,7 @@ def main():
         def step(self):
             for t in self.leaves.values():
                 t.grad = None
-            pkg = self.renderer.render(self.cam, self.model, self.pipe, self.bg)
+            pkg = self.renderer.render(self.cam, self.model, self.pipe, self.bg, fuse_activations=self.fuse)
             torch.autograd.backward([pkg["render"], pkg["depth_3dgs"], pkg["alpha_3dgs"]], [self.gc, self.gd, self.ga])
             return pkg["viewspace_points"].grad
 
@@ -592,6 +594,10 @@ def main():
                 "configs[1] through the drop-in renderer.render() exactly as GaussianDreamer.py:244-266 calls the reference's: a "
                 "GaussianModel-shaped object with RAW parameters (get_* = sigmoid / exp / normalize / cat as gaussian_model.py:95-115, "
                 "un-fused torch kernels with their autograd), the zero-filled viewspace_points leaf, fwd+bwd of one 1024^2 view")
+        measure("drop_in_render_fused", DropInWorkload(P, fuse=True), max(20, args.steps // 3), max(5, args.warmup // 2), P,
+                "the same call with renderer.render(..., fuse_activations=True) (or renderer.FUSE_ACTIVATIONS): the RAW "
+                "_opacity / _scaling / _rotation go to the rasterizer, sigmoid / exp / normalize run inside its per-Gaussian "
+                "kernels forward and backward (values equal to the un-fused path to rounding)")
         anim = AnimationWorkload(P, gather=False)
         measure("animation_frames", anim, 300, max(5, args.warmup // 2), P,
                 f"configs[4] at its stated size, 300 frames per timed run: per frame re-anchor on the posed {anim.mesh} body mesh "

@@ -118,10 +118,14 @@ def rasterize_gaussians_batch(means3D, means2D, sh, colors_precomp, opacities, s
             raise ValueError("all views of a batch must share image size, sh_degree and scale_modifier")
     B = len(rsl)
     dev = means3D.device
-    vm = torch.stack([rs.viewmatrix.to(dev, torch.float32).reshape(4, 4) for rs in rsl])
-    pm = torch.stack([rs.projmatrix.to(dev, torch.float32).reshape(4, 4) for rs in rsl])
-    cp = torch.stack([rs.campos.to(dev, torch.float32).reshape(3) for rs in rsl])
-    bg = torch.stack([rs.bg.to(dev, torch.float32).reshape(3) for rs in rsl])
+    if B == 1:          # (views of the caller's tensors: no stack kernels in front of a single view)
+        vm, pm = r0.viewmatrix.to(dev, torch.float32).reshape(1, 4, 4), r0.projmatrix.to(dev, torch.float32).reshape(1, 4, 4)
+        cp, bg = r0.campos.to(dev, torch.float32).reshape(1, 3), r0.bg.to(dev, torch.float32).reshape(1, 3)
+    else:
+        vm = torch.stack([rs.viewmatrix.to(dev, torch.float32).reshape(4, 4) for rs in rsl])
+        pm = torch.stack([rs.projmatrix.to(dev, torch.float32).reshape(4, 4) for rs in rsl])
+        cp = torch.stack([rs.campos.to(dev, torch.float32).reshape(3) for rs in rsl])
+        bg = torch.stack([rs.bg.to(dev, torch.float32).reshape(3) for rs in rsl])
     if means2D is None:
         means2D = means3D.new_zeros((0,))
     want_grad = torch.is_grad_enabled() and any(

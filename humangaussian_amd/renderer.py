@@ -69,10 +69,34 @@ def _screenspace_points(xyz, views=None):
     return make(shape, dtype=xyz.dtype, device=xyz.device).requires_grad_(True)
 
 
+# FUSE_ACTIVATIONS = True: `render()` hands the model's RAW parameters (`pc._opacity`, `pc._scaling`, `pc._rotation`) to the
+# rasterizer, which applies sigmoid / exp / normalize (scene/gaussian_model.py:95-115) inside its per-Gaussian kernels,
+# forward and backward: three elementwise launches and three autograd nodes fewer per view in each direction.  Off by
+# default: the un-fused path evaluates `pc.get_*` exactly like the reference (results agree to rounding - expf vs
+# torch.exp - not bit for bit); a model whose activations are NOT the reference's must leave it off.
+FUSE_ACTIVATIONS = False
+
+
+def _render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, screenspace_points, settings):
+    from .rasterizer import (ACT_OPACITY_SIGMOID, ACT_ROTATION_NORMALIZE, ACT_SCALE_EXP, rasterize_gaussians_batch)
+    f = lambda t: None if t is None else t.float()  # noqa: E731
+    shs = None
+    if override_color is None:
+        # (`get_features` = cat(_features_dc, _features_rest), gaussian_model.py:108-111: with sh_degree 0 - HumanGaussian's
+        # setting - the rest is empty and the cat a pure copy, forward and backward: the dc tensor goes in as it is)
+        rest = getattr(pc, "_features_rest", None)
+        shs = pc._features_dc if rest is not None and rest.shape[1] == 0 and hasattr(pc, "_features_dc") else pc.get_features
+    image, radii, depth, alpha = rasterize_gaussians_batch(
+        f(pc.get_xyz), f(screenspace_points).unsqueeze(0), f(shs), f(override_color), f(pc._opacity), f(pc._scaling),
+        f(pc._rotation), None, [settings], activation_flags=ACT_OPACITY_SIGMOID | ACT_SCALE_EXP | ACT_ROTATION_NORMALIZE)
+    # (squeeze, not [0]: a select's backward zero-fills and copies a full-size gradient per output)
+    return image.squeeze(0), radii.squeeze(0), depth.squeeze(0), alpha.squeeze(0)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
-           override_color=None):
+           override_color=None, fuse_activations=None):
     """Render one view.  Returns the reference's dict: render, viewspace_points,
-    visibility_filter, radii, depth_3dgs, alpha_3dgs."""
+    visibility_filter, radii, depth_3dgs, alpha_3dgs.  `fuse_activations` (default: the module's FUSE_ACTIVATIONS): see there."""
     screenspace_points = _screenspace_points(pc.get_xyz)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
@@ -88,6 +112,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         prefiltered=False,
         debug=bool(getattr(pipe, "debug", False)),
     )
+    fuse = FUSE_ACTIVATIONS if fuse_activations is None else bool(fuse_activations)
+    if fuse and not getattr(pipe, "compute_cov3D_python", False) and not getattr(pipe, "convert_SHs_python", False) and \
+            all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation")):
+        rendered_image, radii, depth, alpha = _render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier,
+                                                            override_color, screenspace_points, raster_settings)
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii, "depth_3dgs": depth, "alpha_3dgs": alpha}
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     means3D = pc.get_xyz
@@ -135,7 +166,7 @@ class Renderer:
                                      dtype=torch.float32, device=device)
 
     def render(self, viewpoint_camera, scaling_modifier=1.0, bg_color=None, override_color=None,
-               compute_cov3D_python=False, convert_SHs_python=False):
+               compute_cov3D_python=False, convert_SHs_python=False, fuse_activations=None):
         class _Pipe:
             pass
         pipe = _Pipe()
@@ -144,7 +175,7 @@ class Renderer:
         pipe.debug = False
         out = render(viewpoint_camera, self.gaussians, pipe,
                      self.bg_color if bg_color is None else bg_color, scaling_modifier,
-                     override_color)
+                     override_color, fuse_activations=fuse_activations)
         return {"image": out["render"].clamp(0, 1),     # gs_renderer.py:1017
                 "depth": out["depth_3dgs"],
                 "alpha": out["alpha_3dgs"],

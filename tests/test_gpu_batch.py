@@ -400,6 +400,42 @@ def test_fused_activations_match_the_unfused_path_forward_and_backward():
         assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-12)
 
 
+@pytest.mark.parametrize("deg", [0, 1])
+def test_render_with_fused_activations_matches_the_reference_shaped_call(deg):
+    """render(..., fuse_activations=True) (and the module switch renderer.FUSE_ACTIVATIONS): the single-view drop-in on the
+    model's RAW parameters - same dict, same shapes, values and raw-parameter gradients equal to the `pc.get_*` path to
+    rounding; `viewspace_points` stays a (P, 3) leaf whose .grad is the view's screen-space gradient."""
+    from humangaussian_amd import renderer
+    from test_gpu_api_contract import FakeCamera, FakeGaussianModel, Pipe
+    P, H, W = 1500, 64, 72
+    sc = make_scene(P=P, sh_degree=deg, seed=62, H=H, W=W, spread=0.3)        # (degree 0: `_features_rest` is empty, no cat)
+    cam = FakeCamera(_cams(1, H, W, seed=14)[0])
+    bg = sc["bg"].to(DEV)
+    g = torch.Generator().manual_seed(5)
+    wc, wd, wa = (torch.randn(s, generator=g).to(DEV) for s in ((3, H, W), (1, H, W), (1, H, W)))
+    res = []
+    for mode in ("plain", "argument", "switch"):
+        pc = FakeGaussianModel(sc, deg)
+        try:
+            renderer.FUSE_ACTIVATIONS = mode == "switch"
+            out = renderer.render(cam, pc, Pipe(), bg, fuse_activations=True if mode == "argument" else None)
+        finally:
+            renderer.FUSE_ACTIVATIONS = False
+        ((out["render"] * wc).sum() + (out["depth_3dgs"] * wd).sum() + (out["alpha_3dgs"] * wa).sum()).backward()
+        assert out["viewspace_points"].shape == (P, 3) and out["viewspace_points"].is_leaf
+        res.append((out, [p.grad.clone() for p in pc.params() if p.numel()], out["viewspace_points"].grad.clone()))
+    (o0, g0, v0) = res[0]
+    for (o1, g1, v1) in res[1:]:
+        assert set(o1) == set(o0) and all(o1[k].shape == o0[k].shape for k in o0)
+        assert torch.equal(o0["radii"], o1["radii"]) and torch.equal(o0["visibility_filter"], o1["visibility_filter"])
+        for k in ("render", "depth_3dgs", "alpha_3dgs"):
+            assert float((o0[k] - o1[k]).abs().max()) <= 2e-6 * max(1.0, float(o0[k].abs().max())), k
+        for a, b in zip(g0 + [v0], g1 + [v1]):
+            assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-12)
+    for a, b in zip(res[1][1] + [res[1][2]], res[2][1] + [res[2][2]]):
+        assert torch.equal(a, b)                                      # argument and switch are the same path
+
+
 def test_batch_capacity_overflow_retries_transparently_and_matches_single_calls():
     """Huge splats: R of the batch exceeds the first capacity guess (4 P B entries) - the device reports
     the overflow, the binding re-runs with the exact size, results are those of single calls."""
