@@ -728,6 +728,13 @@ typedef unsigned long long u64;
 
 namespace {
 
+#ifdef HGS_TIMELINE
+__shared__ unsigned long long hgs_s_tq[8];          // finer stamps of the tile in flight (thread 0): ranking sub-phases, record rounds
+#define HGS_TQ(i) { if (threadIdx.x == 0) hgs_s_tq[(i)] = wall_clock64(); }
+#else
+#define HGS_TQ(i) {}
+#endif
+
 // workgroup barrier that orders LDS traffic only (no global load / atomic is waited for: gathers and the bump
 // allocation stay in flight across it).  Every cross-wave hand-off in this kernel goes through LDS.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -862,6 +869,7 @@ __device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint3
     if (lane == 0) { atomicMin(&R.dmin, lo); atomicMax(&R.dmax, hi); }
   }
   lds_barrier();
+  HGS_TQ(0)
   // ---- 3. histogram
   const float flo = __uint_as_float(R.dmin);
   const float range = __uint_as_float(R.dmax) - flo;
@@ -877,6 +885,7 @@ __device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint3
     }
   }
   lds_barrier();
+  HGS_TQ(1)
   // exclusive scan of the NB counts in place (thread = PER consecutive buckets), largest bucket on the way
   {
     const uint32_t PER = NB >= (uint32_t)NT ? NB / NT : 1u;         // a power of two <= NB_MAX / NT
@@ -900,6 +909,7 @@ __device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint3
     if (tid == 0) R.hist[NB] = n;
   }
   lds_barrier();
+  HGS_TQ(2)
   const bool degenerate = R.maxcnt > (uint32_t)HGS_RANK_BUCKET_MAX;      // (workgroup-uniform)
   if (!degenerate) {
     // ---- 4. bucket order, then the rank inside the bucket
@@ -917,6 +927,7 @@ __device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint3
       }                                                    // (padding keeps 0: no probe)
     }
     lds_barrier();
+    HGS_TQ(3)
     // the probes of the thread's keys interleaved: EG independent LDS reads per step (one key after the other, each
     // with its own data-dependent loop, was 5 us of a 1400-entry tile)
 #pragma unroll
@@ -1190,8 +1201,10 @@ __device__ __forceinline__ void rank_sort_tile(const View& v, const Layout& L, u
     const bool hb = (r + 1u) * per_round < n, ha = (r + 2u) * per_round < n;
     if (hb) { HGS_RANK_ROUND(B, r + 1u) }
     HGS_RANK_CONSUME(A)
+    if (r < 4u) HGS_TQ(4 + r)        // (timeline builds: round ends)
     if (ha) { HGS_RANK_ROUND(A, r + 2u) }
     if (hb) { HGS_RANK_CONSUME(B) }
+    if (r < 3u) HGS_TQ(5 + r)
   }
 #undef HGS_RANK_ISSUE
 #undef HGS_RANK_ROUND
@@ -1249,6 +1262,9 @@ __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, c
       // phases: ranks | records | tables | allocation (its exposed rest)   and   cell lists
       hgs_tl[2][b][0] = cl(tp[0] - tp0) | (cl(tp[1] - tp[0]) << 16) | (cl(tp[2] - tp[1]) << 32) | (cl(tp[3] - tp[2]) << 48);
       hgs_tl[2][b][1] = cl(tpe - tp[3]);
+      // ranking: range | histogram | scan | scatter (then the probes up to tp[0]); record rounds 0..3 (ends, from tp[0])
+      hgs_tl[2][b][2] = cl(hgs_s_tq[0] - tp0) | (cl(hgs_s_tq[1] - hgs_s_tq[0]) << 16) | (cl(hgs_s_tq[2] - hgs_s_tq[1]) << 32) | (cl(hgs_s_tq[3] - hgs_s_tq[2]) << 48);
+      hgs_tl[2][b][3] = cl(hgs_s_tq[4] - tp[0]) | (cl(hgs_s_tq[5] - tp[0]) << 16) | (cl(hgs_s_tq[6] - tp[0]) << 32) | (cl(hgs_s_tq[7] - tp[0]) << 48);
     }
 #endif
     lds_barrier();                                       // the LDS tables are reused by the next tile

@@ -29,6 +29,31 @@ using std::min;
 #endif
 #endif
 
+// sqrt / reciprocal / log / clamp / fma of the MASK (not of hgs_alpha_rect, whose result decides which list entries exist): on
+// the device the raw 1-ulp instructions (v_sqrt_f32, v_rcp_f32, v_log_f32), v_med3_f32 and v_fma_f32.  HIP's `sqrtf` and `/`
+// are correctly rounded by default - a ~15-instruction fix-up sequence per sqrt and ~10 per division, two thirds of this
+// function's former ~320 instructions - and the function sits in the per-tile latency chain of the sort kernel (a build
+// with a constant mask ran that kernel 6.8 us shorter; the raw forms gave 3 us of it back at one view, 10 us at 8 views).
+// The margins below (tau inflated by 0.2 % + 0.03, eps on the intervals) are 1e3 x an ulp of anything compared here;
+// tests/test_cellmask_cpu.py runs its brute-force check also on host builds whose sqrt / rcp / log results are pushed
+// 3 ulp in either direction (HGS_CM_SKEW_*).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HGS_CM_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define HGS_CM_RCP(x) __builtin_amdgcn_rcpf(x)
+#define HGS_CM_LN(x) (__builtin_amdgcn_logf(x) * 0.69314718056f)
+#define HGS_CM_CLAMP(x, lo, hi) __builtin_amdgcn_fmed3f((x), (lo), (hi))      // (lo <= hi wherever the result is used)
+#else
+#ifndef HGS_CM_SKEW_SQRT
+#define HGS_CM_SKEW_SQRT 1.0f
+#define HGS_CM_SKEW_RCP 1.0f
+#define HGS_CM_SKEW_LN 1.0f
+#endif
+#define HGS_CM_SQRT(x) (sqrtf(x) * HGS_CM_SKEW_SQRT)
+#define HGS_CM_RCP(x) ((1.0f / (x)) * HGS_CM_SKEW_RCP)
+#define HGS_CM_LN(x) (logf(x) * HGS_CM_SKEW_LN)
+#define HGS_CM_CLAMP(x, lo, hi) fminf(fmaxf((x), (lo)), (hi))
+#endif
+
 #define HGS_CELL 4              // pixels per cell edge
 #define HGS_CELLS_PER_TILE 16
 
@@ -53,26 +78,26 @@ HGS_HD uint32_t hgs_cell_mask(float mx, float my, float ca, float cb, float cc, 
   if (!(a255 >= 0.999f)) return 0u;                     // alpha <= op < 1/255 everywhere
   const float det = hgs_conic_det(ca, cb, cc);
   if (!hgs_conic_cullable(ca, cc, det)) return 0xffffu; // degenerate / extremely elongated conic: never cull
-  const float tau = 2.0f * logf(fmaxf(a255, 1.0f)) * 1.002f + 0.03f;
-  const float idet = 1.0f / det;
-  const float ex = sqrtf(tau * cc * idet), ey = sqrtf(tau * ca * idet);   // half extents of the ellipse
-  const float eps = 2e-3f;
-  const float ica = 1.0f / ca;
-  const float dyR = -cb * ex / cc;                      // dy of the rightmost point; the leftmost one has -dyR
+  const float tau = 2.0f * HGS_CM_LN(fmaxf(a255, 1.0f)) * 1.002f + 0.03f;
+  const float idet = HGS_CM_RCP(det);
+  const float ex = HGS_CM_SQRT(tau * cc * idet), ey = HGS_CM_SQRT(tau * ca * idet);   // half extents of the ellipse
+  const float eps = 4e-3f;
+  const float ica = HGS_CM_RCP(ca);
+  const float dyR = -cb * ex * HGS_CM_RCP(cc);          // dy of the rightmost point; the leftmost one has -dyR
   const float bca = cb * ica, k0 = tau * ica, k1 = det * ica * ica;
   uint32_t mask = 0;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < 4; ++b) {                         // (branch-free: a band the ellipse misses contributes no bit)
     const float d0 = (y0 + 4.0f * (float)b) - my, d1 = d0 + 3.0f;
     const float lo = fmaxf(d0, -ey), hi = fminf(d1, ey);
-    if (!(lo <= hi + eps)) continue;                    // band misses the ellipse
-    const float yr = fminf(fmaxf(dyR, lo), hi), yl = fminf(fmaxf(-dyR, lo), hi);
-    const float R = -bca * yr + sqrtf(fmaxf(0.0f, k0 - k1 * yr * yr)) + eps;
-    const float Lx = -bca * yl - sqrtf(fmaxf(0.0f, k0 - k1 * yl * yl)) - eps;
+    const bool band = lo <= hi + eps;
+    const float yr = HGS_CM_CLAMP(dyR, lo, hi), yl = HGS_CM_CLAMP(-dyR, lo, hi);
+    const float R = fmaf(-bca, yr, HGS_CM_SQRT(fmaxf(0.0f, fmaf(-k1 * yr, yr, k0)))) + eps;
+    const float Lx = fmaf(-bca, yl, -HGS_CM_SQRT(fmaxf(0.0f, fmaf(-k1 * yl, yl, k0)))) - eps;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float c0 = (x0 + 4.0f * (float)c) - mx, c1 = c0 + 3.0f;
-      if (Lx <= c1 && R >= c0) mask |= 1u << (4 * b + c);
+      if (band && Lx <= c1 && R >= c0) mask |= 1u << (4 * b + c);
     }
   }
   return mask;

@@ -11,15 +11,33 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("cellmask") / "cellmask_host.so")
-    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas",
+def _build(tmp_path_factory, name, flags=()):
+    so = str(tmp_path_factory.mktemp("cellmask") / f"cellmask_host_{name}.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas", *flags,
                            os.path.join(ROOT, "tests", "cellmask_host.cpp"), "-o", so])
     L = ctypes.CDLL(so)
     L.hgs_cell_mask_host.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9
     L.hgs_alpha_rect_host.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7
     return L
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    return _build(tmp_path_factory, "exact")
+
+
+# The device build of the mask takes sqrt / reciprocal / log from the raw 1-ulp instructions (cellmask.h: HGS_CM_*): host
+# builds whose three results are pushed 3 ulp (3.6e-7 relative) down / up, in every combination of directions, must pass
+# the same brute-force check - the margins of the test have to carry any such error, whatever its sign.
+_SKEWS = [(a, b, c) for a in (-1, 1) for b in (-1, 1) for c in (-1, 1)]
+
+
+@pytest.fixture(scope="module", params=_SKEWS, ids=lambda t: "sqrt%+d_rcp%+d_ln%+d" % t)
+def skewed_lib(request, tmp_path_factory):
+    f = lambda sgn: "(1.0f%s3.6e-7f)" % ("+" if sgn > 0 else "-")  # noqa: E731
+    a, b, c = request.param
+    return _build(tmp_path_factory, "skew%d%d%d" % (a + 1, b + 1, c + 1),
+                  ["-DHGS_CM_SKEW_SQRT=" + f(a), "-DHGS_CM_SKEW_RCP=" + f(b), "-DHGS_CM_SKEW_LN=" + f(c)])
 
 
 def _masks(lib, mx, my, ca, cb, cc, op, x0, y0):
@@ -108,6 +126,17 @@ def test_cell_mask_with_huge_elongated_gaussians(lib):
     for seed in range(3):
         e = _random_entries(40000, 100 + seed, s1_max=3000.0, aniso_min=1e-3)
         m = _masks(lib, *e)
+        live_cells, _ = _live_cells(*e)
+        hidden = live_cells & ~m
+        assert not hidden.any(), (int(np.count_nonzero(hidden)), [v[np.nonzero(hidden)[0][:3]] for v in e])
+
+
+def test_cell_mask_carries_three_ulp_of_error_in_its_sqrt_rcp_and_log(skewed_lib):
+    """What the device's raw v_sqrt_f32 / v_rcp_f32 / v_log_f32 may do to the mask (each within 1 ulp, either sign): the
+    brute-force check on ordinary and on huge elongated Gaussians with those results skewed by 3 ulp."""
+    for seed, (s1_max, aniso) in ((300, (40.0, 0.02)), (301, (3000.0, 1e-3))):
+        e = _random_entries(40000, seed, s1_max=s1_max, aniso_min=aniso)
+        m = _masks(skewed_lib, *e)
         live_cells, _ = _live_cells(*e)
         hidden = live_cells & ~m
         assert not hidden.any(), (int(np.count_nonzero(hidden)), [v[np.nonzero(hidden)[0][:3]] for v in e])

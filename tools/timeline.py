@@ -139,6 +139,10 @@ for lo, hi in ((1, 64), (64, 256), (256, 512), (512, 1024), (1024, 2048), (2048,
         sub = [((g >> (16 * i)) & 0xffff).mean() * TICK_US for i in range(4)] + [(gp[m, 1] & 0xffff).mean() * TICK_US]
         print(f"  n in [{lo},{hi}): {int(m.sum())} tiles: total {tot.mean():.2f} (max {tot.max():.2f}) || " + " | ".join("%.2f" % x for x in sub)
               + f" ; start p50 {np.percentile((ph[m, 0] - t0s) * TICK_US, 50):.1f} max {((ph[m, 0] - t0s) * TICK_US).max():.1f}; end max {((ph[m, 1] - t0s) * TICK_US).max():.1f}; fallback {int(ph[m, 2].sum())}")
+        rk = [((gp[m, 2] >> (16 * i)) & 0xffff).mean() * TICK_US for i in range(4)]
+        rr = [((gp[m, 3] >> (16 * i)) & 0xffff).mean() * TICK_US for i in range(4)]
+        print("      ranking: range %.2f | histogram %.2f | scan %.2f | scatter %.2f | probes %.2f ;  record rounds end at (from the ranks): %s"
+              % (rk[0], rk[1], rk[2], rk[3], sub[0] - sum(rk), " ".join("%.2f" % x for x in rr)))
 
 # ---- backward
 print('backward ...', flush=True)
