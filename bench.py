@@ -43,6 +43,12 @@ SH_DEGREE = 0
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
 INIT_STEPS = 100               # un-timed first-use steps before the W warm-up steps (reported as init_steps): the
                                # estimates settle and the GPU leaves its idle clocks (some boxes need > 20 ms for that)
+INIT_SECONDS = 2.0             # ... and the first measurement of a process keeps stepping until this much wall time has
+                               # passed: a FRESH box runs the same step 12-20 % slower for its first 0.6-1.0 s (0.175-0.19
+                               # ms, then 0.155-0.157 from one step to the next; a second process on the same box starts
+                               # at 0.16 and is at 0.155 within 300 steps: host and GPU clocks ramping, tools/_warm.py).
+                               # With the driver's --steps 20 --warmup 5 the timed region would sit 20 ms into that ramp.
+                               # Reported as init_seconds / init_steps_run; --init-seconds 0 switches it off.
 
 FWD_STAGES = ["preprocess_fwd", "tiles", "fill", "sort", "render_fwd"]
 BWD_STAGES = ["render_bwd", "pair_reduce", "preprocess_bwd"]
@@ -102,14 +108,19 @@ def main():
                          "a LOCAL asset built from the reference tree, humangaussian_amd/data) or the analytic capsule humanoid "
                          "with the same extents; auto = the mesh where the asset exists (the line says which)")
     ap.add_argument("--uninitialised-means2d", action="store_true",
-                    help="hand the rasterizer an uninitialised means2D leaf (no fill kernel; its values are never read) instead "
+                    help="hand the rasterizer an uninitialised means2D leaf (its values are never read) instead "
                          "of the zero-filled one the drop-in render() and the reference hand out")
+    ap.add_argument("--torch-zero-means2d", action="store_true",
+                    help="zero-fill the means2D leaf with torch.zeros (one fill launch per view: what render() did before ABI v16) "
+                         "instead of inside the forward's per-Gaussian kernel")
     ap.add_argument("--views", type=int, default=1,
                     help="views per rank per step rendered by ONE batched call (extra measurement when > 1)")
     ap.add_argument("--views-per-rank", type=int, default=1,
                     help="views per rank per step rendered ONE AFTER THE OTHER (the reference's loop); with N > 1 the "
                          "collective of round k runs under the render of round k + 1")
     ap.add_argument("--init-steps", type=int, default=INIT_STEPS, help="un-timed first-use steps before the warm-up")
+    ap.add_argument("--init-seconds", type=float, default=INIT_SECONDS,
+                    help="the process's first measurement keeps stepping (un-timed) until this much wall time has passed")
     ap.add_argument("--collective", default="auto", choices=["auto", "allgather", "scatter"],
                     help="N > 1: how the per-rank gradient packs are reduced (view_parallel.allgather_reduce); auto times "
                          "both outside the timed region and uses the faster one")
@@ -161,6 +172,29 @@ def main():
         torch.cuda.synchronize()
 
     PARAMS = ("means3D", "shs", "opacities", "scales", "rotations")
+    # the step's means2D leaf (see Workload.step)
+    leaf_in_kernel = not (args.uninitialised_means2d or args.torch_zero_means2d)
+    leaf_make = torch.zeros if args.torch_zero_means2d else torch.empty
+    settled = {}               # filled by the first timed() of the process: the un-timed steps / seconds it ran first
+
+    def init_phase(step_fn, init_steps):
+        """The un-timed steps in front of the W warm-up steps: `init_steps` first-use steps and - once per process - further
+        steps until INIT_SECONDS of wall time have passed (the same number on every rank: a step may hold a collective)."""
+        t_init = time.perf_counter()
+        for _ in range(init_steps):
+            step_fn()
+        fence()
+        if init_steps and args.init_seconds > 0 and not settled:
+            more = 0
+            while True:        # (chunks of 200 steps; every rank takes the same decision: the slowest rank's clock)
+                dt = time.perf_counter() - t_init
+                if (max_over_ranks([dt])[0] if world > 1 else dt) >= args.init_seconds:
+                    break
+                for _ in range(200):
+                    step_fn()
+                fence()
+                more += 200
+            settled.update(steps=init_steps + more, seconds=round(time.perf_counter() - t_init, 3))
 
     class Workload:
         """One rank's step: `views` views of a `P`-Gaussian cloud, fwd (+bwd), single or batched call."""
@@ -203,17 +237,19 @@ def main():
                 return self.step_rounds()
             for t in L.values():
                 t.grad = None
+            # the zero-filled leaf the reference's render() creates per view (gaussian_renderer/__init__.py:26), built the way
+            # renderer.render() builds it since ABI v16: storage from torch.empty, the zeros written by the forward's own
+            # per-Gaussian kernel (--torch-zero-means2d: one torch fill launch; --uninitialised-means2d: no zeros at all)
             if self.views > 1:
-                means2D = torch.zeros((self.views,) + tuple(L["means3D"].shape), device=dev, requires_grad=True)
+                means2D = leaf_make((self.views,) + tuple(L["means3D"].shape), device=dev).requires_grad_(True)
                 color, radii, depth, alpha = rasterize_gaussians_batch(
-                    L["means3D"], means2D, L["shs"], None, L["opacities"], L["scales"], L["rotations"], None, self.rs)
+                    L["means3D"], means2D, L["shs"], None, L["opacities"], L["scales"], L["rotations"], None, self.rs,
+                    activation_flags=_rast.ZERO_MEANS2D if leaf_in_kernel else 0)
             else:
-                # the zero-filled leaf the reference's render() creates per view (gaussian_renderer/__init__.py:26; here one
-                # fill kernel, without its `+ 0`); --uninitialised-means2d: no kernel at all (the values are never read)
-                means2D = (torch.empty_like if args.uninitialised_means2d else torch.zeros_like)(L["means3D"]).requires_grad_(True)
+                means2D = leaf_make(tuple(L["means3D"].shape), device=dev).requires_grad_(True)
                 color, radii, depth, alpha = self.rast(
                     means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
-                    rotations=L["rotations"])
+                    rotations=L["rotations"], zero_means2D=leaf_in_kernel)
             if world > 1:
                 # the view-parallel step: the backward's last kernel writes the rank's pack itself (ABI v15: no pack
                 # kernel), one collective, the last reduction writes the six gradient tensors + radii (no unpack kernels)
@@ -231,10 +267,10 @@ def main():
             for j in range(self.seq_views):
                 for t in L.values():
                     t.grad = None
-                means2D = (torch.empty_like if args.uninitialised_means2d else torch.zeros_like)(L["means3D"]).requires_grad_(True)
+                means2D = leaf_make(tuple(L["means3D"].shape), device=dev).requires_grad_(True)
                 color, radii, depth, alpha = self.rasts[j](
                     means3D=L["means3D"], means2D=means2D, shs=L["shs"], opacities=L["opacities"], scales=L["scales"],
-                    rotations=L["rotations"])
+                    rotations=L["rotations"], zero_means2D=leaf_in_kernel)
                 if world > 1 and self.collectives:
                     with _rast.packed_gradients() as pg:
                         torch.autograd.grad([color, depth, alpha], [L[k] for k in PARAMS] + [means2D], [self.gc, self.gd, self.ga])
@@ -255,9 +291,7 @@ def main():
             init_steps = args.init_steps if init_steps is None else init_steps
             # first-use initialisation, not part of W: the rasterizer's decaying capacity / longest-list
             # estimates settle over the first calls (retries, buffer growth), the GPU leaves its idle clocks
-            for _ in range(init_steps):
-                self.step()
-            fence()
+            init_phase(self.step, init_steps)
             for _ in range(warmup):
                 self.step()
             fence()
@@ -387,8 +421,7 @@ def main():
             return n
 
         def timed(self, steps, warmup, init_steps=None):
-            self.run(args.init_steps if init_steps is None else init_steps)
-            fence()
+            init_phase(lambda: self.run(1), args.init_steps if init_steps is None else init_steps)
             self.run(warmup)
             fence()
             t0 = time.perf_counter()
@@ -415,6 +448,7 @@ def main():
                 "metric": "rasterize fwd-only Gaussians/sec @1024^2 (animation frames; extra measurement)",
                 "value": P * frames / elapsed, "unit": "Gaussians/s", "frames_per_s": frames / elapsed,
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": args.init_steps,
+                "init_run": dict(settled),
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"configs[4]: {P} Gaussians anchored on the {wl.mesh} body mesh, one frame per rank per step: re-anchor "
@@ -647,6 +681,7 @@ def main():
             "value": P * args.views * VPR * world * args.steps / elapsed,
             "unit": "Gaussians/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "init_steps": args.init_steps,
+            "init_run": dict(settled),      # un-timed steps / seconds the first measurement ran before its W warm-up steps
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {P} Gaussians on " + ("the reference's load/shapes/human.obj (area-uniform, seed 0, normalised "
@@ -658,7 +693,11 @@ def main():
                                    + " (elev 10, azim 30+45*view, dist 1.75, fovy 55), "
                                    + ("fwd only" if args.forward_only else "fwd+bwd")
                                    + ("; the step's means2D leaf is uninitialised (--uninitialised-means2d: its values are never read)"
-                                      if args.uninitialised_means2d else "; means2D is the zero-filled leaf of the reference's render() (one fill per view)"),
+                                      if args.uninitialised_means2d else
+                                      "; means2D is the zero-filled leaf of the reference's render(), filled by one torch launch per view (--torch-zero-means2d)"
+                                      if args.torch_zero_means2d else
+                                      "; means2D is the zero-filled leaf of the reference's render(), built as renderer.render() builds it: "
+                                      "fresh storage per view, the zeros written by the forward's per-Gaussian kernel (ABI v16)"),
                        "cloud": args.cloud,
                        "views_per_step": world * args.views * VPR, "views_per_rank_sequential": VPR, "num_rendered_R": int(R),
                        "host_mode": "sync (one host wait per forward for the device-side status, as upstream)",

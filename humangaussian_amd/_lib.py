@@ -19,7 +19,7 @@ from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_size_t, c_ui
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("HGS_LIB") or os.path.join(_PKG_DIR, "libhgs_rast.so")   # HGS_LIB: A/B experiments only
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared"]
@@ -62,6 +62,9 @@ EXPORTS = {
     "hgs_forward_batch_act": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 7
                               + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
                                                   c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hgs_forward_batch_act_leaf": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 7
+                                   + [c_void_p] * 4 + [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32,
+                                                       c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "hgs_backward_batch_act": (ctypes.c_int, [POINTER(HgsSettings), c_int32, c_int32, c_int32] + [c_void_p] * 8
                                + [c_void_p] * 6 + [c_void_p] * 3 + [POINTER(HgsStatus), c_int64, c_void_p]
                                + [c_void_p] * 8 + [c_void_p, c_int32, c_void_p]),

@@ -373,7 +373,7 @@ int hgs_pack_view_contribution(int32_t P, int32_t M, const float* g_means3D, con
   return HGS_OK;
 }
 
-int hgs_abi_version(void) { return 15; }
+int hgs_abi_version(void) { return 16; }
 
 size_t hgs_geom_bytes_batch(int32_t B, int32_t P, int32_t H, int32_t W) {
   if (B < 1 || B > HGS_MAX_VIEWS || P < 0 || H <= 0 || W <= 0) return 0;
@@ -404,6 +404,20 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
                           int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
                           int32_t status_host_mapped, void* status_event, void* const* stage_events,
                           int32_t activation_flags, void* stream_) {
+  return hgs_forward_batch_act_leaf(s, B, P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                    out_color, out_depth, out_alpha, radii, geom, bin, entry_capacity, img, store_bwd_state,
+                                    max_tile_entries_hint, status_host, status_host_mapped, status_event, stage_events,
+                                    activation_flags, nullptr, stream_);
+}
+
+int hgs_forward_batch_act_leaf(const hgs_settings* s, int32_t B, int32_t P, int32_t M, const float* means3D,
+                               const float* shs, const float* colors_precomp, const float* opacities,
+                               const float* scales, const float* rotations, const float* cov3D_precomp,
+                               float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                               void* geom, void* bin, int64_t entry_capacity, void* img,
+                               int32_t store_bwd_state, int32_t max_tile_entries_hint, hgs_status* status_host,
+                               int32_t status_host_mapped, void* status_event, void* const* stage_events,
+                               int32_t activation_flags, float* means2D_leaf, void* stream_) {
   if (activation_flags & ~(7 | HGS_GRAD_SCALE_TRUE_DERIVATIVE)) return HGS_EINVAL;      // (the gradient bit is the backward's: ignored here)
   if (!batch_ok(s, B) || P < 0 || !out_color || !out_depth || !out_alpha || !geom || !img ||
       entry_capacity < 0)
@@ -444,11 +458,11 @@ int hgs_forward_batch_act(const hgs_settings* s, int32_t B, int32_t P, int32_t M
     if (v.lds_bins)
       hipLaunchKernelGGL(hgs_k_preprocess_fwd, dim3(v.B * v.nwg), dim3(HGS_BLOCK), lds_bytes, stream, v,
                          L, means3D, shs, colors_precomp, opacities, scales, rotations,
-                         cov3D_precomp, radii);
+                         cov3D_precomp, radii, means2D_leaf);
     else
       hipLaunchKernelGGL(hgs_k_preprocess_fwd_ga, dim3(v.B * v.nblk), dim3(HGS_BLOCK), 0, stream, v, L,
                          means3D, shs, colors_precomp, opacities, scales, rotations,
-                         cov3D_precomp, radii);
+                         cov3D_precomp, radii, means2D_leaf);
     HGS_LAUNCH_CHECK();
   }
   HGS_STAGE(1);

@@ -372,7 +372,7 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
                      const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                      const float* __restrict__ opacities, const float* __restrict__ scales,
                      const float* __restrict__ rotations,
-                     const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
+                     const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii, float* __restrict__ zero_leaf) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
   zero_counters(L);
@@ -391,6 +391,10 @@ hgs_k_preprocess_fwd(View v, Layout L, const float* __restrict__ means3D,
       tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
                           cov3D_precomp, rec);
       radii[(size_t)b * v.P + i] = rec.radius;
+      if (zero_leaf) {         // the caller's screen-space leaf [B][P][3] (hgs_forward_batch_act_leaf): zeros, no fill launch
+        float* z = zero_leaf + ((size_t)b * v.P + i) * 3;
+        z[0] = 0.0f; z[1] = 0.0f; z[2] = 0.0f;
+      }
       store_geom(&L.geom[(size_t)b * v.P + i], rec);      // the record leaves the registers now ...
       if (tt) {
         const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;
@@ -414,7 +418,7 @@ hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
                         const float* __restrict__ shs, const float* __restrict__ colors_precomp,
                         const float* __restrict__ opacities, const float* __restrict__ scales,
                         const float* __restrict__ rotations,
-                        const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii) {
+                        const float* __restrict__ cov3D_precomp, int32_t* __restrict__ radii, float* __restrict__ zero_leaf) {
   __shared__ uint32_t wtot[HGS_BLOCK / 64];
   zero_counters(L);
   const int b = (int)blockIdx.x / v.nblk, chunk = (int)blockIdx.x % v.nblk;
@@ -426,6 +430,10 @@ hgs_k_preprocess_fwd_ga(View v, Layout L, const float* __restrict__ means3D,
     tt = preprocess_one(v, cam, i, means3D, shs, colors_precomp, opacities, scales, rotations,
                         cov3D_precomp, rec);
     radii[(size_t)b * v.P + i] = rec.radius;
+    if (zero_leaf) {
+      float* z = zero_leaf + ((size_t)b * v.P + i) * 3;
+      z[0] = 0.0f; z[1] = 0.0f; z[2] = 0.0f;
+    }
     store_geom(&L.geom[(size_t)b * v.P + i], rec);
     if (tt) {
       const int minx = rec.rect_lo & 0xffffu, miny = rec.rect_lo >> 16;

@@ -219,8 +219,12 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
                                const Tensor& bg, const Tensor& viewmatrix, const Tensor& projmatrix,
                                const Tensor& campos, const Tensor& tanfov, int64_t H, int64_t W,
                                double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
-                               bool want_grad, int64_t batch, int64_t act) {
-    (void)means2D;
+                               bool want_grad, int64_t batch, int64_t act_in) {
+    // bit 16 of `act` is the binding's own (never handed to the library): `means2D` is UNINITIALISED storage that the
+    // forward's per-Gaussian kernel zero-fills (ABI v16: hgs_forward_batch_act_leaf) - what renderer.render() passes
+    // instead of launching torch.zeros
+    const bool zero_leaf = ((act_in >> 16) & 1) != 0;
+    const int64_t act = act_in & 0xffff;
     const auto th0 = std::chrono::steady_clock::now();
     const c10::Device dev = means3D.device();
     if (!dev.is_cuda())
@@ -270,6 +274,17 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       radii = at::empty({P}, fopt.dtype(at::kInt));
     }
 
+    float* leaf_ptr = nullptr;
+    if (zero_leaf && means2D.defined() && means2D.numel() > 0) {
+      if (means2D.numel() != B * P * 3) throw std::runtime_error("means2D must have (views x) num_points x 3 elements");
+      if (means2D.device() == dev && means2D.scalar_type() == at::kFloat && means2D.is_contiguous()) {
+        leaf_ptr = static_cast<float*>(means2D.data_ptr());
+      } else {                       // (a leaf the kernel cannot write: filled the ordinary way)
+        at::NoGradGuard ng;
+        const_cast<Tensor&>(means2D).zero_();
+      }
+    }
+
     DevState& st = state_for(dev.index());
     std::lock_guard<std::mutex> lk(st.mu);
     hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
@@ -308,12 +323,12 @@ struct Rasterize : public torch::autograd::Function<Rasterize> {
       std::atomic_thread_fence(std::memory_order_seq_cst);
       const auto th1 = std::chrono::steady_clock::now();
       if (attempt == 0) st.host_ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(th1 - th0).count();
-      const int rc = hgs_forward_batch_act(plan->settings.s.data(), (int32_t)B, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_),
-                                           fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth),
-                                           fptr_mut(alpha), P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom,
-                                           plan->bin, cap, plan->img, want_grad ? 1 : 0, hint, &st.ring[slot], /*mapped=*/1,
-                                           /*status_event=*/nullptr, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(),
-                                           (int32_t)act, stream);
+      const int rc = hgs_forward_batch_act_leaf(plan->settings.s.data(), (int32_t)B, (int32_t)P, M, fptr(m3), fptr(sh_), fptr(cp_),
+                                                fptr(op_), fptr(sc_), fptr(ro_), fptr(cv_), fptr_mut(color), fptr_mut(depth),
+                                                fptr_mut(alpha), P > 0 ? radii.data_ptr<int32_t>() : nullptr, plan->geom,
+                                                plan->bin, cap, plan->img, want_grad ? 1 : 0, hint, &st.ring[slot], /*mapped=*/1,
+                                                /*status_event=*/nullptr, g_stage_fwd.empty() ? nullptr : g_stage_fwd.data(),
+                                                (int32_t)act, leaf_ptr, stream);
       check_rc(rc, "hgs_forward_batch");
       const auto th2 = std::chrono::steady_clock::now();
       st.host_ns[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(th2 - th1).count();
@@ -516,10 +531,11 @@ std::vector<Tensor> rasterize(const Tensor& means3D, const Tensor& means2D, cons
                               const c10::optional<Tensor>& cov3D, const Tensor& bg, const Tensor& viewmatrix,
                               const Tensor& projmatrix, const Tensor& campos, int64_t H, int64_t W, double tanfovx,
                               double tanfovy, double scale_modifier, int64_t sh_degree, bool prefiltered, bool debug,
-                              bool want_grad) {
+                              bool want_grad, bool zero_means2D) {
   return Rasterize::apply(means3D, means2D, opt(sh), opt(colors_precomp), opacities, opt(scales), opt(rotations),
                           opt(cov3D), bg, viewmatrix, projmatrix, campos, tanfov_tensor({tanfovx}, {tanfovy}), H, W,
-                          scale_modifier, sh_degree, prefiltered, debug, want_grad, (int64_t)0, (int64_t)0);
+                          scale_modifier, sh_degree, prefiltered, debug, want_grad, (int64_t)0,
+                          (int64_t)(zero_means2D ? (1 << 16) : 0));
 }
 
 // B views in one launch set: bg (3) or (B,3), viewmatrix / projmatrix (B,4,4), campos (B,3), means2D (B,P,3);

@@ -67,9 +67,11 @@ def _state(device: torch.device):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                        cov3Ds_precomp, raster_settings):
+                        cov3Ds_precomp, raster_settings, zero_means2D: bool = False):
     """Replaces upstream's `_RasterizeGaussians.apply` (forward -> `_C.rasterize_gaussians`,
-    backward -> `_C.rasterize_gaussians_backward`)."""
+    backward -> `_C.rasterize_gaussians_backward`).
+    zero_means2D: `means2D` is UNINITIALISED storage (`torch.empty`); the forward's per-Gaussian kernel writes the zeros
+    upstream's `torch.zeros_like(xyz) + 0` holds (ABI v16, `hgs_forward_batch_act_leaf`) - no fill launch."""
     want_grad = torch.is_grad_enabled() and (
         means3D.requires_grad or means2D.requires_grad or opacities.requires_grad
         or (sh is not None and sh.requires_grad)
@@ -82,11 +84,14 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
         means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
         rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width),
         float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree),
-        bool(rs.prefiltered), bool(rs.debug), want_grad)
+        bool(rs.prefiltered), bool(rs.debug), want_grad, bool(zero_means2D))
     return color, radii, depth, alpha
 
 
 ACT_OPACITY_SIGMOID, ACT_SCALE_EXP, ACT_ROTATION_NORMALIZE = 1, 2, 4      # HGS_ACT_* of include/hgs_rast.h
+# the torch binding's own bit (stripped before the library sees the flags): `means2D` is uninitialised storage, the
+# forward zero-fills it inside its per-Gaussian kernel (see rasterize_gaussians)
+ZERO_MEANS2D = 1 << 16
 # backward only: dL/dscales as the TRUE derivative at scale_modifier != 1 (the default follows the fork, whose backward
 # drops the modifier's factor; identical at 1.0, the only value the reference passes) - HGS_GRAD_SCALE_TRUE_DERIVATIVE
 GRAD_SCALE_TRUE_DERIVATIVE = 8
@@ -188,7 +193,7 @@ class GaussianRasterizer(nn.Module):
             int(rs.sh_degree), bool(rs.prefiltered), bool(rs.debug))
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
-                rotations=None, cov3D_precomp=None):
+                rotations=None, cov3D_precomp=None, zero_means2D=False):
         raster_settings = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
@@ -198,4 +203,4 @@ class GaussianRasterizer(nn.Module):
                             'precomputed 3D covariance!')
         # upstream turns missing optionals into empty tensors for its `_C`; the binding takes None
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
-                                   rotations, cov3D_precomp, raster_settings)
+                                   rotations, cov3D_precomp, raster_settings, zero_means2D=zero_means2D)

@@ -56,17 +56,23 @@ def _tan_half(fov):
 # The reference creates `screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0` per view
 # (gaussian_renderer/__init__.py:26): a fill AND an add kernel in front of every forward.  The rasterizer only routes
 # dL/dmeans2D into the tensor's `.grad` (GaussianDreamer.py:385-387), but the reference's own 3DGS trainer reads the VALUES
-# too (`gaussiansplatting/train.py:113` -> `gaussian_model.py:436`), so a drop-in hands out ZEROS like the reference: one
-# zero-filled leaf (the `+ 0` kernel is gone, the values are the same).  ZERO_SCREENSPACE_POINTS = False is the opt-in fast
-# path for loops that never read the values (an uninitialised leaf: no kernel at all) - bench.py's step does the same with
-# its own tensor and says so in its workload string.
+# too (`gaussiansplatting/train.py:113` -> `gaussian_model.py:436`), so a drop-in hands out ZEROS like the reference - but
+# without either launch: the leaf comes from `torch.empty` and the forward's per-Gaussian kernel writes its zeros (ABI v16,
+# `_screenspace_points` below; before v16: one torch fill kernel, 2.6 us of a 158 us step with its kernel boundary).
+# ZERO_SCREENSPACE_POINTS = False hands out an uninitialised leaf (for loops that never read the values).  bench.py's step
+# builds its leaf the same way as render() and says so in its workload string.
 ZERO_SCREENSPACE_POINTS = True
 
 
 def _screenspace_points(xyz, views=None):
+    """-> (leaf, zero_in_kernel).  With ZERO_SCREENSPACE_POINTS the zeros are written by the forward's own per-Gaussian
+    kernel (ABI v16: `rasterize_gaussians(..., zero_means2D=True)` / the ZERO_MEANS2D flag of the batched call) into
+    storage that comes from `torch.empty`: the values behind the call are the reference's, the fill launch is gone.
+    (A leaf the kernel cannot write - not fp32 on the device - is filled by torch.zeros as before.)"""
     shape = tuple(xyz.shape) if views is None else (int(views),) + tuple(xyz.shape)
-    make = torch.zeros if ZERO_SCREENSPACE_POINTS else torch.empty
-    return make(shape, dtype=xyz.dtype, device=xyz.device).requires_grad_(True)
+    in_kernel = ZERO_SCREENSPACE_POINTS and xyz.dtype == torch.float32 and xyz.is_cuda
+    make = torch.zeros if (ZERO_SCREENSPACE_POINTS and not in_kernel) else torch.empty
+    return make(shape, dtype=xyz.dtype, device=xyz.device).requires_grad_(True), in_kernel
 
 
 # FUSE_ACTIVATIONS = True: `render()` hands the model's RAW parameters (`pc._opacity`, `pc._scaling`, `pc._rotation`) to the
@@ -77,8 +83,10 @@ def _screenspace_points(xyz, views=None):
 FUSE_ACTIVATIONS = False
 
 
-def _render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, screenspace_points, settings):
-    from .rasterizer import (ACT_OPACITY_SIGMOID, ACT_ROTATION_NORMALIZE, ACT_SCALE_EXP, rasterize_gaussians_batch)
+def _render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, screenspace_points, settings,
+                  zero_in_kernel=False):
+    from .rasterizer import (ACT_OPACITY_SIGMOID, ACT_ROTATION_NORMALIZE, ACT_SCALE_EXP, ZERO_MEANS2D,
+                             rasterize_gaussians_batch)
     f = lambda t: None if t is None else t.float()  # noqa: E731
     shs = None
     if override_color is None:
@@ -88,7 +96,8 @@ def _render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, overri
         shs = pc._features_dc if rest is not None and rest.shape[1] == 0 and hasattr(pc, "_features_dc") else pc.get_features
     image, radii, depth, alpha = rasterize_gaussians_batch(
         f(pc.get_xyz), f(screenspace_points).unsqueeze(0), f(shs), f(override_color), f(pc._opacity), f(pc._scaling),
-        f(pc._rotation), None, [settings], activation_flags=ACT_OPACITY_SIGMOID | ACT_SCALE_EXP | ACT_ROTATION_NORMALIZE)
+        f(pc._rotation), None, [settings],
+        activation_flags=ACT_OPACITY_SIGMOID | ACT_SCALE_EXP | ACT_ROTATION_NORMALIZE | (ZERO_MEANS2D if zero_in_kernel else 0))
     # (squeeze, not [0]: a select's backward zero-fills and copies a full-size gradient per output)
     return image.squeeze(0), radii.squeeze(0), depth.squeeze(0), alpha.squeeze(0)
 
@@ -97,7 +106,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
            override_color=None, fuse_activations=None):
     """Render one view.  Returns the reference's dict: render, viewspace_points,
     visibility_filter, radii, depth_3dgs, alpha_3dgs.  `fuse_activations` (default: the module's FUSE_ACTIVATIONS): see there."""
-    screenspace_points = _screenspace_points(pc.get_xyz)
+    screenspace_points, zero_in_kernel = _screenspace_points(pc.get_xyz)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
         image_width=int(viewpoint_camera.image_width),
@@ -116,7 +125,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if fuse and not getattr(pipe, "compute_cov3D_python", False) and not getattr(pipe, "convert_SHs_python", False) and \
             all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation")):
         rendered_image, radii, depth, alpha = _render_fused(viewpoint_camera, pc, pipe, bg_color, scaling_modifier,
-                                                            override_color, screenspace_points, raster_settings)
+                                                            override_color, screenspace_points, raster_settings, zero_in_kernel)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
                 "radii": radii, "depth_3dgs": depth, "alpha_3dgs": alpha}
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
@@ -145,7 +154,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rendered_image, radii, depth, alpha = rasterizer(
         means3D=f(means3D), means2D=f(screenspace_points), shs=f(shs),
         colors_precomp=f(colors_precomp), opacities=f(opacity), scales=f(scales),
-        rotations=f(rotations), cov3D_precomp=f(cov3D_precomp))
+        rotations=f(rotations), cov3D_precomp=f(cov3D_precomp), zero_means2D=zero_in_kernel)
 
     return {"render": rendered_image,
             "viewspace_points": screenspace_points,
@@ -258,7 +267,7 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_mo
     cams = list(viewpoint_cameras)
     xyz = pc.get_xyz
     B, P = len(cams), xyz.shape[0]
-    screenspace_points = _screenspace_points(xyz, views=B)
+    screenspace_points, zero_in_kernel = _screenspace_points(xyz, views=B)
     bg_color = bg_color.to(xyz.device)
     settings = [GaussianRasterizationSettings(
         image_height=int(c.image_height), image_width=int(c.image_width),
@@ -268,13 +277,14 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_mo
         sh_degree=pc.active_sh_degree, campos=c.camera_center, prefiltered=False,
         debug=bool(getattr(pipe, "debug", False))) for i, c in enumerate(cams)]
 
-    act = 0
+    from .rasterizer import ZERO_MEANS2D
+    act = ZERO_MEANS2D if zero_in_kernel else 0
     fuse = bool(fuse_activations) and not getattr(pipe, "compute_cov3D_python", False) and \
         all(hasattr(pc, a) for a in ("_opacity", "_scaling", "_rotation"))
     scales = rotations = cov3D_precomp = None
     if fuse:
         from .rasterizer import ACT_OPACITY_SIGMOID, ACT_ROTATION_NORMALIZE, ACT_SCALE_EXP
-        act = ACT_OPACITY_SIGMOID | ACT_SCALE_EXP | ACT_ROTATION_NORMALIZE
+        act |= ACT_OPACITY_SIGMOID | ACT_SCALE_EXP | ACT_ROTATION_NORMALIZE
         opacity, scales, rotations = pc._opacity, pc._scaling, pc._rotation
     else:
         opacity = pc.get_opacity

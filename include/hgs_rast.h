@@ -195,6 +195,21 @@ int hgs_forward_batch_act(const hgs_settings* views, int32_t B, int32_t P, int32
                           int32_t store_bwd_state, int32_t max_tile_entries_hint,
                           hgs_status* status_host, int32_t status_host_mapped, void* status_event,
                           void* const* stage_events, int32_t activation_flags, void* stream);
+/* v16: hgs_forward_batch_act that also ZERO-FILLS the caller's screen-space leaf.  The reference creates
+ * `screenspace_points = torch.zeros_like(xyz) + 0` per view (gaussian_renderer/__init__.py:26) only to receive
+ * dL/dmeans2D in its .grad: a fill (and an add) launch in front of every forward.  means2D_leaf [B][P][3] (or NULL:
+ * exactly hgs_forward_batch_act) is written with zeros by the per-Gaussian kernel of the forward itself - row (b, i) by
+ * the thread that projects Gaussian i of view b - so the caller hands over UNINITIALISED storage and reads zeros behind
+ * the call: no launch, no kernel boundary (2.6 us of a 158 us step at 100k Gaussians). */
+int hgs_forward_batch_act_leaf(const hgs_settings* views, int32_t B, int32_t P, int32_t M,
+                               const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, const float* rotations,
+                               const float* cov3D_precomp,
+                               float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                               void* geom, void* bin, int64_t entry_capacity, void* img,
+                               int32_t store_bwd_state, int32_t max_tile_entries_hint,
+                               hgs_status* status_host, int32_t status_host_mapped, void* status_event,
+                               void* const* stage_events, int32_t activation_flags, float* means2D_leaf, void* stream);
 int hgs_backward_batch_act(const hgs_settings* views, int32_t B, int32_t P, int32_t M,
                            const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, const float* rotations,

@@ -436,6 +436,51 @@ def test_render_with_fused_activations_matches_the_reference_shaped_call(deg):
         assert torch.equal(a, b)                                      # argument and switch are the same path
 
 
+def test_the_forward_zero_fills_the_screen_space_leaf_itself():
+    """ABI v16 (`hgs_forward_batch_act_leaf`): the leaf `render()` hands out comes from torch.empty and holds the
+    reference's zeros behind the call - written by the forward's per-Gaussian kernel, no fill launch.  Checked on leaves
+    that hold NaN before the call (single view, batched call, and through the drop-in wrappers on a poisoned allocator)."""
+    from humangaussian_amd import renderer
+    from humangaussian_amd.rasterizer import ZERO_MEANS2D
+    from test_gpu_api_contract import FakeCamera, FakeGaussianModel, Pipe
+    dev = torch.device(DEV)
+    B, P, H, W = 3, 1300, 64, 72                     # (P not a multiple of the 256-Gaussian chunks)
+    sc = make_scene(P=P, sh_degree=1, seed=63, H=H, W=W, spread=0.3)
+    ins = {k: sc[k].to(dev) for k in NAMES}
+    cams = _cams(B, H, W, seed=15)
+    rsl = [_settings(c, sc["bg"], 1) for c in cams]
+    # the raw entry points on NaN-filled leaves
+    m2 = torch.full((P, 3), float("nan"), device=dev).requires_grad_(True)
+    c1, r1, d1, a1 = GaussianRasterizer(rsl[0])(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                                scales=ins["scales"], rotations=ins["rotations"], zero_means2D=True)
+    assert float(m2.detach().abs().max()) == 0.0 and m2.is_leaf
+    m2b = torch.full((B, P, 3), float("nan"), device=dev).requires_grad_(True)
+    cb, rb, db, ab = rasterize_gaussians_batch(ins["means3D"], m2b, ins["shs"], None, ins["opacities"], ins["scales"],
+                                               ins["rotations"], None, rsl, activation_flags=ZERO_MEANS2D)
+    assert float(m2b.detach().abs().max()) == 0.0
+    assert torch.equal(cb[0], c1) and torch.equal(rb[0], r1)       # the flag changes nothing else
+    # without the flag the leaf is left alone
+    m2n = torch.full((P, 3), float("nan"), device=dev).requires_grad_(True)
+    GaussianRasterizer(rsl[0])(means3D=ins["means3D"], means2D=m2n, shs=ins["shs"], opacities=ins["opacities"],
+                               scales=ins["scales"], rotations=ins["rotations"])
+    assert bool(torch.isnan(m2n.detach()).all())
+    # the gradient still arrives in the leaf's .grad
+    (cb.sum() + db.sum()).backward()
+    assert m2b.grad is not None and m2b.grad.shape == (B, P, 3) and float(m2b.grad.abs().max()) > 0
+    # the drop-in wrappers: torch.empty re-uses the block a NaN-filled tensor of the same size just gave back
+    pc, bg = FakeGaussianModel(sc, 1), sc["bg"].to(dev)
+    cam = FakeCamera(cams[0])
+    for call in (lambda: renderer.render(cam, pc, Pipe(), bg),
+                 lambda: renderer.render(cam, pc, Pipe(), bg, fuse_activations=True),
+                 lambda: renderer.render_views([FakeCamera(c) for c in cams], pc, Pipe(), bg)):
+        for _ in range(3):
+            shape = (P, 3) if _ == 0 else (B, P, 3)
+            poison = [torch.full(shape, float("nan"), device=dev) for _k in range(4)]
+            del poison
+            out = call()
+            assert float(out["viewspace_points"].detach().abs().max()) == 0.0 and out["viewspace_points"].is_leaf
+
+
 def test_batch_capacity_overflow_retries_transparently_and_matches_single_calls():
     """Huge splats: R of the batch exceeds the first capacity guess (4 P B entries) - the device reports
     the overflow, the binding re-runs with the exact size, results are those of single calls."""
