@@ -62,12 +62,12 @@ mode_ab() {
 
 run_set() {  # tag, commit, bench args
   local T=$1 C=$2; shift 2
-  local BENCH="python $R/bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5 $@"
+  local BENCH="python $R/bench.py --no-cpu-baseline --no-extra --init-seconds 0 --steps 20 --warmup 5 $@"
   cd /tmp; export TMPDIR=/tmp
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$T -o run -- $BENCH > $O/pmc_fetch_$T.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$T -o run -- $BENCH > $O/pmc_write_$T.log 2>&1
   python $R/tools/pmc_traffic.py $O/pmc_fetch_$T/run_counter_collection.csv $O/pmc_write_$T/run_counter_collection.csv "$C" > $O/${T}_pmc_traffic.json
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o run -- python $R/bench.py --no-cpu-baseline --no-extra --steps 100 --warmup 10 $@ > $O/prof_$T.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -o run -- python $R/bench.py --no-cpu-baseline --no-extra --init-seconds 0 --steps 100 --warmup 10 $@ > $O/prof_$T.log 2>&1
   cp $O/prof_$T/run_kernel_stats.csv $O/${T}_kernel_stats.csv
   echo "== $T"; cut -d, -f1-4 $O/${T}_kernel_stats.csv | head -12
 }
@@ -78,7 +78,7 @@ mode_profile() {
   run_set ${TAG}_cfg3 "$C" --points 500000 --sh-degree 3
   run_set ${TAG}_8views "$C" --views 8
   cd /tmp; export TMPDIR=/tmp
-  local BENCH="python $R/bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5"
+  local BENCH="python $R/bench.py --no-cpu-baseline --no-extra --init-seconds 0 --steps 20 --warmup 5"
   local i=0
   for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" \
@@ -124,7 +124,7 @@ import json;d=json.load(open('$O/${t}_pmc_traffic.json'));print({k:round(v/1e6,1
 
 mode_gap() {   # kernel-trace + HIP-call trace of the bench loop -> per-kernel idle gaps (tools/gap_trace.py); no counters in this run
   cd /tmp; export TMPDIR=/tmp
-  timeout 300 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/gap_$TAG -o run -- python $R/bench.py --no-cpu-baseline --no-extra --steps 100 --warmup 10 > $O/gap_$TAG.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $O/gap_$TAG -o run -- python $R/bench.py --no-cpu-baseline --no-extra --init-seconds 0 --steps 100 --warmup 10 > $O/gap_$TAG.log 2>&1
   python $R/tools/gap_trace.py $O/gap_$TAG > $O/${TAG}_gap_trace.txt 2>&1; cat $O/${TAG}_gap_trace.txt
   rm -rf $O/gap_$TAG
 }
