@@ -739,13 +739,70 @@ __shared__ unsigned long long hgs_s_tq[8];          // finer stamps of the tile 
 // allocation stay in flight across it).  Every cross-wave hand-off in this kernel goes through LDS.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct RankLds {
+struct __attribute__((aligned(16))) RankLds {
   uint32_t hist[HGS_RANK_NB_MAX + 1];   // bucket counts -> exclusive bases (+ sentinel); from step 5 on: the 16-bit masks in list order
   uint32_t wtot[16];                     // block scan (up to 1024 threads: the large class)
   uint32_t tot16[8];                     // cell-list lengths of the tile, two 16-bit fields per word (word 2 q + (c & 1), field (c >> 1) & 1, q = c >> 2)
   uint32_t dmin, dmax, maxcnt, pad;
 };
 static_assert(sizeof(uint32_t) * (HGS_RANK_NB_MAX + 1) >= sizeof(uint16_t) * 4096, "the masks of the longest list fit into the histogram");
+
+// Exclusive scan of the NB bucket counts in place (thread = PER = NB / NT consecutive buckets: 1, 2, 4 or 8), the largest
+// bucket on the way.  The thread's counts are ONE or TWO vector LDS reads, in front of the barrier and again behind it (kept
+// in registers across it they spilled in the eight-keys-per-thread instantiation); a loop of PER dependent reads in front
+// and PER read-modify-writes behind was 1.2 of a typical tile's 15.7 us.
+template <int NT>
+__device__ __forceinline__ void bucket_scan(RankLds& R, uint32_t NB) {
+  int tid = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid));        // (keeps the thread's LDS address local: hoisted out of the persistent tile loop it is spilled)
+  const int lane = tid & 63, wv = tid >> 6;
+  const uint32_t PER = NB / (uint32_t)NT;                 // (NB is a power of two >= 256 and >= NT for every caller)
+  uint32_t* __restrict__ h = R.hist + (uint32_t)tid * PER;
+  uint32_t c[8];
+  auto load_counts = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = 0u;
+    if (PER == 8u) {
+      const uint4 a = *reinterpret_cast<const uint4*>(h), b = *reinterpret_cast<const uint4*>(h + 4);
+      c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else if (PER == 4u) {
+      const uint4 a = *reinterpret_cast<const uint4*>(h);
+      c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+    } else if (PER == 2u) {
+      const uint2 a = *reinterpret_cast<const uint2*>(h);
+      c[0] = a.x; c[1] = a.y;
+    } else {
+      c[0] = h[0];
+    }
+  };
+  load_counts();
+  uint32_t sum = 0, mx = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sum += c[i]; mx = max(mx, c[i]); }
+  const uint32_t inc = hgs_wave_incl_scan(sum);
+  mx = hgs_wave_max_u32(mx);
+  if (lane == 63) R.wtot[wv] = inc;
+  if (lane == 0 && mx) atomicMax(&R.maxcnt, mx);
+  uint32_t base = inc - sum;
+  asm volatile("" : "+v"(base));                           // (the counts are re-read, not carried)
+  lds_barrier();
+  load_counts();
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) base += (w < wv) ? R.wtot[w] : 0u;
+  uint32_t e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] = base; base += c[i]; }
+  if (PER == 8u) {
+    *reinterpret_cast<uint4*>(h) = make_uint4(e[0], e[1], e[2], e[3]);
+    *reinterpret_cast<uint4*>(h + 4) = make_uint4(e[4], e[5], e[6], e[7]);
+  } else if (PER == 4u) {
+    *reinterpret_cast<uint4*>(h) = make_uint4(e[0], e[1], e[2], e[3]);
+  } else if (PER == 2u) {
+    *reinterpret_cast<uint2*>(h) = make_uint2(e[0], e[1]);
+  } else {
+    h[0] = e[0];
+  }
+}
 
 // Cell tables + cell lists of one tile from the masks of its records in list order (what gather_records_single does
 // behind its sweep 1).  All NT threads of the workgroup take part; wave 0 has ISSUED the range allocation (`ca`).
@@ -843,7 +900,9 @@ __device__ __forceinline__ void cell_lists_from_masks(const View& v, const Layou
 template <int E, int NT>
 __device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint32_t n, uint32_t NB, const u64 (&keyp)[HGS_RANK_GU],
                                           unsigned long long* pairs, RankLds& R) {
-  const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int tid = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid));        // (the key offsets e * NT + tid stay local to the tile: hoisted out of the persistent loop they spill)
+  const int lane = tid & 63, wv = tid >> 6;
   u64 key[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -887,27 +946,8 @@ __device__ __forceinline__ bool rank_keys(const Layout& L, uint32_t start, uint3
   lds_barrier();
   HGS_TQ(1)
   // exclusive scan of the NB counts in place (thread = PER consecutive buckets), largest bucket on the way
-  {
-    const uint32_t PER = NB >= (uint32_t)NT ? NB / NT : 1u;         // a power of two <= NB_MAX / NT
-    const uint32_t b0 = (uint32_t)tid * PER;
-    uint32_t sum = 0, mx = 0;
-    for (uint32_t i = 0; i < PER; ++i) {
-      const uint32_t c = (b0 + i < NB) ? R.hist[b0 + i] : 0u;
-      sum += c; mx = max(mx, c);
-    }
-    const uint32_t inc = hgs_wave_incl_scan(sum);
-    mx = hgs_wave_max_u32(mx);
-    if (lane == 63) R.wtot[wv] = inc;
-    if (lane == 0 && mx) atomicMax(&R.maxcnt, mx);
-    lds_barrier();
-    uint32_t base = inc - sum;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) base += (w < wv) ? R.wtot[w] : 0u;
-    for (uint32_t i = 0; i < PER; ++i) {
-      if (b0 + i < NB) { const uint32_t c = R.hist[b0 + i]; R.hist[b0 + i] = base; base += c; }
-    }
-    if (tid == 0) R.hist[NB] = n;
-  }
+  bucket_scan<NT>(R, NB);
+  if (tid == 0) R.hist[NB] = n;
   lds_barrier();
   HGS_TQ(2)
   const bool degenerate = R.maxcnt > (uint32_t)HGS_RANK_BUCKET_MAX;      // (workgroup-uniform)
@@ -1013,26 +1053,7 @@ __device__ __forceinline__ bool rank_keys_stream(const Layout& L, uint32_t start
 #pragma unroll 4
   for (uint32_t k = tid; k < n; k += NT) atomicAdd(&R.hist[bucket_of(keys[k])], 1u);
   lds_barrier();
-  {
-    const uint32_t PER = NB >= (uint32_t)NT ? NB / NT : 1u;
-    const uint32_t b0 = (uint32_t)tid * PER;
-    uint32_t sum = 0, mx = 0;
-    for (uint32_t i = 0; i < PER; ++i) {
-      const uint32_t c = (b0 + i < NB) ? R.hist[b0 + i] : 0u;
-      sum += c; mx = max(mx, c);
-    }
-    const uint32_t inc = hgs_wave_incl_scan(sum);
-    mx = hgs_wave_max_u32(mx);
-    if (lane == 63) R.wtot[wv] = inc;
-    if (lane == 0 && mx) atomicMax(&R.maxcnt, mx);
-    lds_barrier();
-    uint32_t base = inc - sum;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) base += (w < wv) ? R.wtot[w] : 0u;
-    for (uint32_t i = 0; i < PER; ++i) {
-      if (b0 + i < NB) { const uint32_t c = R.hist[b0 + i]; R.hist[b0 + i] = base; base += c; }
-    }
-  }
+  bucket_scan<NT>(R, NB);
   lds_barrier();
   const bool degenerate = R.maxcnt > (uint32_t)HGS_RANK_BUCKET_MAX;      // (workgroup-uniform)
   uint32_t rk[16];
