@@ -46,7 +46,7 @@ INIT_STEPS = 100               # un-timed first-use steps before the W warm-up s
 INIT_SECONDS = 2.0             # ... and the first measurement of a process keeps stepping until this much wall time has
                                # passed: a FRESH box runs the same step 12-20 % slower for its first 0.6-1.0 s (0.175-0.19
                                # ms, then 0.155-0.157 from one step to the next; a second process on the same box starts
-                               # at 0.16 and is at 0.155 within 300 steps: host and GPU clocks ramping, tools/_warm.py).
+                               # at 0.16 and is at 0.155 within 300 steps: host and GPU clocks ramping, tools/warmup_curve.py).
                                # With the driver's --steps 20 --warmup 5 the timed region would sit 20 ms into that ramp.
                                # Reported as init_seconds / init_steps_run; --init-seconds 0 switches it off.
 

@@ -1,5 +1,9 @@
+"""Step time of the headline step against the steps already run in the process (chunks of 25, then 100 steps):
+  python tools/warmup_curve.py          (on the GPU box; run it twice in one call to see a warm box's curve too)
+A fresh box runs the step at 0.175-0.19 ms for its first 0.6-1.0 s and at 0.155-0.157 afterwards: the reason
+for bench.py's un-timed INIT_SECONDS in front of its first measurement."""
 import math, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from humangaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, synth
 t_start = time.perf_counter()
