@@ -223,6 +223,43 @@ inline int hip_rc(hipError_t e) { return e == hipSuccess ? HGS_OK : -(1000 + (in
     }                                                                             \
   } while (0)
 
+// The long-list sort classes (one 1024-thread workgroup per tile of more than 4 096 entries: hgs_k_sort_large / _huge) run
+// BESIDE the LDS class on a per-device side stream - fork behind `fill`, join in front of the blend.  A view of 500k
+// Gaussians has one or two such tiles; launched in front of hgs_k_sort_lds on the caller's stream they held the whole
+// GPU for the 39 us one of them takes (8 % of that step).  The classes write disjoint tiles and share only the bump
+// allocators (atomics), so they may overlap.  The side stream and its two events are created once per device; a device
+// where that fails keeps the launches on the caller's stream.  Calls whose hint rules the classes out never touch it.
+struct SideStream {
+  std::mutex mu;
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool tried = false, ok = false;
+};
+SideStream* side_stream_for(hipStream_t stream) {
+#ifdef HGS_NO_SIDE_STREAM
+  (void)stream;
+  return nullptr;
+#else
+  static SideStream tab[64];
+  int dev = 0;
+  if (hipStreamGetDevice(stream, &dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+  SideStream& t = tab[dev];
+  std::lock_guard<std::mutex> lk(t.mu);
+  if (!t.tried) {
+    t.tried = true;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (have_cur && cur != dev) (void)hipSetDevice(dev);
+    t.ok = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
+    if (have_cur && cur != dev) (void)hipSetDevice(cur);
+    if (!t.ok) (void)hipGetLastError();
+  }
+  return t.ok ? &t : nullptr;
+#endif
+}
+
 bool settings_ok(const hgs_settings* s) {
   return s && s->image_height > 0 && s->image_width > 0 && s->bg && s->viewmatrix &&
          s->projmatrix && s->campos && s->sh_degree >= 0 && s->sh_degree <= 3 &&
@@ -503,21 +540,42 @@ int hgs_forward_batch_act_leaf(const hgs_settings* s, int32_t B, int32_t P, int3
     // the caller's hint (longest tile list it has seen, with margin) lets us skip launching
     // sort classes that cannot occur; a wrong hint is caught on the device (overflow bit 2).
     const int hint = v.max_tile_hint;
-    if (hint <= 0 || hint > 16384) {
-      hipLaunchKernelGGL(hgs_k_sort_huge, dim3(class_grid(16384)), dim3(1024), 0, stream, v, L, status_dev);
+    const bool need_huge = hint <= 0 || hint > 16384, need_large = hint <= 0 || hint > 4096;
+    SideStream* side = (need_huge || need_large) ? side_stream_for(stream) : nullptr;
+    {
+      std::unique_lock<std::mutex> side_lk;
+      hipStream_t s2 = stream;
+      if (side) {                                        // fork: the long-list classes wait for `fill`, nothing else
+        side_lk = std::unique_lock<std::mutex>(side->mu);
+        e = hipEventRecord(side->fork, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side->s, side->fork, 0);
+        if (e != hipSuccess) return hip_rc(e);
+        s2 = side->s;
+      }
+      if (need_huge) {
+        hipLaunchKernelGGL(hgs_k_sort_huge, dim3(class_grid(16384)), dim3(1024), 0, s2, v, L, status_dev);
+        HGS_LAUNCH_CHECK();
+      }
+      if (need_large) {
+        hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, s2, v, L, status_dev);
+        HGS_LAUNCH_CHECK();
+      }
+      if (side) {
+        e = hipEventRecord(side->join, side->s);
+        if (e != hipSuccess) return hip_rc(e);
+      }
+      // persistent workgroups (53 KB of LDS: three per CU), tiles heavy first round-robin
+      const unsigned sort_wgs = std::min<unsigned>(class_grid(1), (unsigned)(hgs_knob("HGS_SORT_WGS_PER_CU", 3) * ncu));
+      if (v.pairchunks)
+        hipLaunchKernelGGL(hgs_k_sort_lds_ch, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
+      else
+        hipLaunchKernelGGL(hgs_k_sort_lds, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
       HGS_LAUNCH_CHECK();
+      if (side) {                                        // join: the blend needs every class
+        e = hipStreamWaitEvent(stream, side->join, 0);
+        if (e != hipSuccess) return hip_rc(e);
+      }
     }
-    if (hint <= 0 || hint > 4096) {
-      hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, stream, v, L, status_dev);
-      HGS_LAUNCH_CHECK();
-    }
-    // persistent workgroups (53 KB of LDS: three per CU), tiles heavy first round-robin
-    const unsigned sort_wgs = std::min<unsigned>(class_grid(1), (unsigned)(hgs_knob("HGS_SORT_WGS_PER_CU", 3) * ncu));
-    if (v.pairchunks)
-      hipLaunchKernelGGL(hgs_k_sort_lds_ch, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
-    else
-      hipLaunchKernelGGL(hgs_k_sort_lds, dim3(sort_wgs), dim3(HGS_SORT_NT), 0, stream, v, L, status_dev);
-    HGS_LAUNCH_CHECK();
   } else {
     HGS_STAGE(3);
   }
