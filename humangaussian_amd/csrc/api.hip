@@ -540,7 +540,7 @@ int hgs_forward_batch_act_leaf(const hgs_settings* s, int32_t B, int32_t P, int3
     // the caller's hint (longest tile list it has seen, with margin) lets us skip launching
     // sort classes that cannot occur; a wrong hint is caught on the device (overflow bit 2).
     const int hint = v.max_tile_hint;
-    const bool need_huge = hint <= 0 || hint > 16384, need_large = hint <= 0 || hint > 4096;
+    const bool need_huge = hint <= 0 || hint > 16384, need_large = hint <= 0 || hint > HGS_SORT_LDS_MAX;
     SideStream* side = (need_huge || need_large) ? side_stream_for(stream) : nullptr;
     {
       std::unique_lock<std::mutex> side_lk;
@@ -557,7 +557,7 @@ int hgs_forward_batch_act_leaf(const hgs_settings* s, int32_t B, int32_t P, int3
         HGS_LAUNCH_CHECK();
       }
       if (need_large) {
-        hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(4096)), dim3(1024), 0, s2, v, L, status_dev);
+        hipLaunchKernelGGL(hgs_k_sort_large, dim3(class_grid(HGS_SORT_LDS_MAX)), dim3(1024), 0, s2, v, L, status_dev);
         HGS_LAUNCH_CHECK();
       }
       if (side) {

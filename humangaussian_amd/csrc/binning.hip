@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, c
     const uint4 tr = L.tile_rec[b];                      // (tile, entries, first entry): one load
     const int g = (int)tr.x;
     const uint32_t n = tr.y, start = tr.z;
-    if (n == 0 || n > 4096u) continue;                   // (longer lists: hgs_k_sort_large / _huge)
+    if (n == 0 || n > (uint32_t)HGS_SORT_LDS_MAX) continue;   // (longer lists: hgs_k_sort_large / _huge)
 #ifdef HGS_TIMELINE
     const unsigned long long tp0 = wall_clock64();
 #endif
@@ -1319,7 +1319,7 @@ hgs_k_sort_large(View v, Layout L, const hgs_status* __restrict__ status) {
   const int t = (int)L.tile_order[b];
   const uint32_t start = L.tile_start[t];
   const uint32_t n = L.tile_n[t];
-  if (n <= 4096u || n > 16384u) return;
+  if (n <= (uint32_t)HGS_SORT_LDS_MAX || n > 16384u) return;
   // long lists (4097 .. 16384 entries): the same bucket ranking as hgs_k_sort_lds, streaming form, 16 keys per thread at
   // most; the keys land in list order in LDS and the gather below takes over.  (The bitonic network it replaces - 91
   // stages of two barriers for 8192 padded keys - was 45 of the 90 us ONE 4411-entry tile cost configs[3].)
