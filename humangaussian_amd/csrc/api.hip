@@ -541,7 +541,10 @@ int hgs_forward_batch_act_leaf(const hgs_settings* s, int32_t B, int32_t P, int3
     // sort classes that cannot occur; a wrong hint is caught on the device (overflow bit 2).
     const int hint = v.max_tile_hint;
     const bool need_huge = hint <= 0 || hint > 16384, need_large = hint <= 0 || hint > HGS_SORT_LDS_MAX;
-    SideStream* side = (need_huge || need_large) ? side_stream_for(stream) : nullptr;
+    // (the side stream costs a cross-stream edge, ~11 us at the join: it is taken when a long list is EXPECTED - a hint
+    // beyond 1.5 x the class boundary, i.e. a list the caller has seen, not the margin on a shorter one - or unknown)
+    const bool expect_long = hint <= 0 || hint > HGS_SORT_LDS_MAX + HGS_SORT_LDS_MAX / 2 + 64;
+    SideStream* side = ((need_huge || need_large) && expect_long) ? side_stream_for(stream) : nullptr;
     {
       std::unique_lock<std::mutex> side_lk;
       hipStream_t s2 = stream;
