@@ -13,6 +13,11 @@ HBM, plus - for N>1 - the all-gather of the per-rank gradient packs, one per ROU
 scaling), each overlapped with the render of the next round (view_parallel.py); with V = 1 there is one collective
 and nothing to hide it behind.
 value = P * V * N * K / t, t = max over ranks of the barrier-bracketed wall time of K steps.
+In front of the W warm-up steps the process's first measurement runs un-timed: `--init-steps` first-use steps (capacity
+estimates settle) and further steps until `--init-seconds` (2.0) of wall time have passed - a fresh box runs the same step
+12-20 % slower for its first 0.6-1.0 s; reported as `init_run`.
+The step's `means2D` leaf is built as renderer.render() builds it: storage from torch.empty, the reference's zeros written
+by the forward's own kernel (ABI v16); `--torch-zero-means2d` / `--uninitialised-means2d` are the two older forms.
 HGS_DIST_BACKEND=gloo + HGS_BENCH_SHARE_DEVICE=1 run the N > 1 branch with all ranks on ONE device (gloo stages the
 packs through the host): the configuration of tests/test_gpu_multirank_one_gpu.py, not a measurement.
 
@@ -24,7 +29,8 @@ Extra objects on the JSON line:
   cpu_baseline  the PyTorch CPU oracle, full fwd+bwd of the same view on the host cores (rank 0, N=1)
   extra         further measurements of the same path, same rules (rank 0, N=1): the 8-view BATCHED call
                 (one launch set for the 8 views of a training step), the `init`-state
-                cloud, configs[3] (500k Gaussians, SH degree 3) and forward-only (configs[4] shape)
+                cloud, configs[3] (500k Gaussians, SH degree 3), forward-only (configs[4] shape), the 300-frame
+                animation loop, the drop-in render() on raw parameters (un-fused and with fuse_activations)
 """
 import argparse
 import json
