@@ -56,20 +56,14 @@ inline int cu_count(hipStream_t stream) {
   cache[dev].store(cus, std::memory_order_relaxed);
   return cus;
 }
-#ifndef HGS_CHUNK_ROWS_MIN_VIEWS
 #define HGS_CHUNK_ROWS_MIN_VIEWS 3     // calls with at least this many views keep the backward's pair rows chunk-cell-major (binning.hip::hgs_put_pair)
-#endif
-#ifndef HGS_PRE_BWD_VPAR_MIN_VIEWS
 #define HGS_PRE_BWD_VPAR_MIN_VIEWS 2   // calls with at least this many views run the per-Gaussian backward with one thread per
-#endif                                 // (Gaussian, view); fewer: one thread per Gaussian
+                                       // (Gaussian, view); fewer: one thread per Gaussian
 constexpr size_t ALIGN = 256;
 constexpr size_t HGS_LDS_BINS_MAX = 16384;   // T*4 bytes of LDS <= 64 KB
-#ifndef HGS_BIN_WGS_PER_VIEW_MAX
 #define HGS_BIN_WGS_PER_VIEW_MAX 512   // (256 until round 5: at 500k Gaussians a workgroup then walked 8 chunks one after the other -
-#endif                                 //  preprocess_fwd 70 -> 54 us with 512, +2 us in `tiles` (twice the histogram rows); 100k: +-0)
-#ifndef HGS_BIN_WGS_TOTAL_MAX
+                                       //  preprocess_fwd 70 -> 54 us with 512, +2 us in `tiles` (twice the histogram rows); 100k: +-0)
 #define HGS_BIN_WGS_TOTAL_MAX 1024
-#endif
 constexpr int HGS_MAX_BIN_WGS_PER_VIEW = HGS_BIN_WGS_PER_VIEW_MAX;
 constexpr int HGS_BIN_WGS_TOTAL = HGS_BIN_WGS_TOTAL_MAX;      // binning workgroups of a batch (all views)
 
@@ -236,10 +230,6 @@ struct SideStream {
   bool tried = false, ok = false;
 };
 SideStream* side_stream_for(hipStream_t stream) {
-#ifdef HGS_NO_SIDE_STREAM
-  (void)stream;
-  return nullptr;
-#else
   static SideStream tab[64];
   int dev = 0;
   if (hipStreamGetDevice(stream, &dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
@@ -257,7 +247,6 @@ SideStream* side_stream_for(hipStream_t stream) {
     if (!t.ok) (void)hipGetLastError();
   }
   return t.ok ? &t : nullptr;
-#endif
 }
 
 bool settings_ok(const hgs_settings* s) {

@@ -64,9 +64,7 @@
 #define HGS_GROW_F4 (HGS_ROW_FLOATS / 4)          // float4 per gradient row
 #define HGS_PROW_FLOATS 10                      // (entry, cell) pair row: the ten sums, packed (40 B: a sixth less pair traffic than 48 B)
 #define HGS_PROW_F2 (HGS_PROW_FLOATS / 2)         // float2 per pair row
-#ifndef HGS_SORT_LDS_MAX
-#define HGS_SORT_LDS_MAX 4096                   // longest tile list of the 256-thread LDS sort class; longer: hgs_k_sort_large (1024 threads)
-#endif
+#define HGS_SORT_LDS_MAX 4096                   // longest tile list of the 256-thread LDS sort class; longer: hgs_k_sort_large (1024 threads; 3072 / 2048 / 1024 swept: EXPERIMENTS.md)
 #define HGS_NCLS 33                             // tile classes by log2(list length); class 0 = empty
 #define HGS_NXCD 8                              // accelerator dies (XCDs), each with its own L2: workgroup b of a launch runs on die b % 8
 #define HGS_NFC 11                              // length classes of the non-empty cells (forward work items)

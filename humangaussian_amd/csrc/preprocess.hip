@@ -565,9 +565,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
       const int tt = rw * rh;
       const float4* rows = reinterpret_cast<const float4*>(grad_rows) +
                            HGS_GROW_F4 * (size_t)(L.chunk_base[(size_t)b * v.nblk + (i >> 8)] + g.offset);
-#ifndef HGS_ROWS_UNROLL_MANY
 #define HGS_ROWS_UNROLL_MANY 4
-#endif
       // Several views: the rows of RU tiles are fetched together (independent loads: one latency round per group
       // instead of one per row - a Gaussian touches 3.3 tiles on average), then added in tile order; 8 views:
       // 95.8 -> 81.8 us.  One view: row by row (grouping measured 15.7 -> 16.3 us: one wave per SIMD has nothing to

@@ -205,7 +205,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       nc = inside ? r_nc : 0u;
       T = has_state ? r_s0 : 1.0f;
       F = has_state ? r_s1 * g0 + r_s2 * g1 + r_s3 * g2 + r_s4 * gd + r_s5 * ga : 0.0f;
-#ifndef HGS_BWD_PREFIX_FORM
       // From here on F is what REMAINS behind the current record: R = F' - (w . S of everything in front of it), carried DOWN
       // from ONE subtraction per work item instead of carried up and subtracted from F' at every record: one VALU
       // instruction per record pair less (render_bwd 40.8 -> 39.5 us by stage events, same box), the same algebra.  It does
@@ -213,7 +212,6 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
       // that one subtraction - F' and the stored prefix state are both O(|F'|), the remainder deep in a list is 1e-2 .. 1e-4
       // of that - and it is inherent to walking the list front to back from stored prefix states (upstream sums from the back).
       F = fp - F;
-#endif
     }
     // ---- operand A of the gradient chain: the row's pixel gradients, transposed through LDS
     // (the k stage is free here: every batch of the previous group has been consumed)
@@ -350,17 +348,10 @@ hgs_k_render_bwd(View v, Layout L, const hgs_status* __restrict__ status,
         const float T1 = T * om2.x;
         const hgs_f32x2 T2 = {T, T1};
         const hgs_f32x2 wgt2 = a2 * T2;
-#ifdef HGS_BWD_PREFIX_FORM
-        const float F0 = __builtin_fmaf(wgt2.x, S2.x, F);
-        const float F1 = __builtin_fmaf(wgt2.y, S2.y, F0);
-        const hgs_f32x2 Fn2 = {F0, F1};
-        const hgs_f32x2 dl2 = __builtin_elementwise_fma(T2, S2, -((fp - Fn2) * rc2));
-#else
         const float F0 = __builtin_fmaf(-wgt2.x, S2.x, F);      // what remains behind record 2p
         const float F1 = __builtin_fmaf(-wgt2.y, S2.y, F0);     //                      ... 2p + 1
         const hgs_f32x2 Fn2 = {F0, F1};
         const hgs_f32x2 dl2 = __builtin_elementwise_fma(T2, S2, -(Fn2 * rc2));
-#endif
         const hgs_f32x2 k2 = am2 * dl2;                      // k = dL/dG * G
         T = T1 * om2.y;
         F = F1;
