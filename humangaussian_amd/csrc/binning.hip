@@ -718,6 +718,9 @@ typedef unsigned long long u64;
 // Steps 1-4 exist in a register form for lists of up to 2 / 4 keys per thread and in a streaming form for longer ones;
 // step 5 is ONE loop for all (it reads (Gaussian, rank) pairs back from LDS), which keeps the kernel's code within the
 // instruction cache.
+#ifndef HGS_SORT_LIGHT
+#define HGS_SORT_LIGHT 16             // heaviest tiles that get the lightest tiles as CU neighbours (sort_rank_body); 0 = off
+#endif
 #define HGS_RANK_BUCKET_MAX 192        // (< 256: bucket lengths travel in 8 bits)
 #define HGS_RANK_NB_MAX 2048
 // 256 threads: three workgroups per CU by LDS (45 KB each) are three waves per SIMD, which leaves a wave 168 VGPRs for
@@ -1261,7 +1264,23 @@ __device__ __forceinline__ void sort_rank_body(const View& v, const Layout& L, c
                                                unsigned long long* pairs, RankLds& R, GatherLds<64>& S) {
   if (status->overflow) return;
   const uint32_t active = status->active_tiles;
-  for (uint32_t b = blockIdx.x; b < active; b += gridDim.x) {
+  // Light neighbours for the heaviest tiles.  Workgroups b, b + ncu, b + 2 ncu of a 3-per-CU grid share a CU (observed:
+  // tools/timeline.py), and tile_order is heavy first: the heaviest tiles - whose chains are the kernel's length - sat beside
+  // mid-sized ones that kept the CU's issue slots and memory queue busy through their record rounds.  In the first pass
+  // the HGS_SORT_LIGHT workgroups beside each of the first HGS_SORT_LIGHT positions swap tiles with the workgroups of
+  // the LAST positions (the lightest tiles: done in a third of the time, a tenth of the traffic).  Placement only: every
+  // position is processed once, by whichever workgroup (the die its tables are filed under follows the POSITION).
+  const uint32_t G = gridDim.x, ncu = G / 3u, na = min(active, G);
+  const bool remap = HGS_SORT_LIGHT > 0 && G == 3u * ncu && status->reserved[1] >= 768u &&
+                     na >= 2u * ncu + 3u * (uint32_t)HGS_SORT_LIGHT;
+  for (uint32_t b0 = blockIdx.x; b0 < active; b0 += gridDim.x) {
+    uint32_t b = b0;
+    if (remap && b0 < na) {
+      constexpr uint32_t H = (uint32_t)HGS_SORT_LIGHT;
+      if (b0 >= ncu && b0 < ncu + H) b = na - 1u - (b0 - ncu);
+      else if (b0 >= 2u * ncu && b0 < 2u * ncu + H) b = na - 1u - H - (b0 - 2u * ncu);
+      else if (b0 >= na - 2u * H) { const uint32_t j = na - 1u - b0; b = j < H ? ncu + j : 2u * ncu + (j - H); }
+    }
     const uint4 tr = L.tile_rec[b];                      // (tile, entries, first entry): one load
     const int g = (int)tr.x;
     const uint32_t n = tr.y, start = tr.z;

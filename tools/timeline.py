@@ -77,6 +77,16 @@ def waves(kid, name, items=False):
     occ = [float(np.clip(np.minimum(en, b) - np.maximum(st, a), 0, None).sum() / (b - a) / 1024) for a, b in zip(edges[:-1], edges[1:])]
     print("resident waves per SIMD over time (%d bins of %.1f us):" % (nb, span / nb), " ".join("%.2f" % o for o in occ))
     simd_balance(((tm[:, 2] >> 32) & 0xf) << 16 | (tm[:, 2] & 0xff30), dur, en, "waves")
+    if kid == 3:     # which sort workgroups share a CU (4 waves per workgroup; CU = XCC id + the SE / SH / CU fields of HW_ID)
+        cu3 = (((tm[:, 2] >> 32) & 0xf) << 16) | (tm[:, 2] & 0xff00)
+        blk3 = slot // 4
+        mates = {}
+        for kx in np.unique(cu3):
+            bs = sorted(set(int(x) for x in blk3[cu3 == kx]))
+            for bb in bs:
+                mates[bb] = bs
+        print("  sort workgroups sharing a CU with workgroups 0..7:", [mates.get(bb) for bb in range(8)])
+        print("  workgroups per CU min/max:", min(len(v) for v in mates.values()), max(len(v) for v in mates.values()), "; CUs seen:", len(np.unique(cu3)))
     order = np.argsort(-en)[:8]
     print("last waves to finish (slot, start, dur, tag):", [(int(slot[i]), round(float(st[i]), 1), round(float(dur[i]), 1), int(tag[i])) for i in order])
     if items:
