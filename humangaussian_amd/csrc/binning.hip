@@ -718,9 +718,7 @@ typedef unsigned long long u64;
 // Steps 1-4 exist in a register form for lists of up to 2 / 4 keys per thread and in a streaming form for longer ones;
 // step 5 is ONE loop for all (it reads (Gaussian, rank) pairs back from LDS), which keeps the kernel's code within the
 // instruction cache.
-#ifndef HGS_SORT_LIGHT
-#define HGS_SORT_LIGHT 16             // heaviest tiles that get the lightest tiles as CU neighbours (sort_rank_body); 0 = off
-#endif
+#define HGS_SORT_LIGHT 16             // heaviest tiles that get the lightest tiles as CU neighbours (sort_rank_body; 8 / 24 / 32 measured the same, 0 = off: +3.4 us)
 #define HGS_RANK_BUCKET_MAX 192        // (< 256: bucket lengths travel in 8 bits)
 #define HGS_RANK_NB_MAX 2048
 // 256 threads: three workgroups per CU by LDS (45 KB each) are three waves per SIMD, which leaves a wave 168 VGPRs for
